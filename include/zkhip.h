@@ -1,0 +1,188 @@
+/*
+ * zkhip.h — C ABI of the MI355X (gfx950) accelerator for the halo2 `create_proof` polynomial pipeline.
+ *
+ * Each entry point replaces one function of the `halo2_proofs 0.3.0` fork that the reference links as an
+ * out-of-tree path dependency (/root/reference/zkevm-circuits/Cargo.toml:15, /root/reference/Cargo.lock:2189-2211)
+ * and reaches through `create_proof` (/root/reference/zkevm-circuits/benches/benchmark_list/main.rs:265,315;
+ * /root/reference/prover/src/chunk/prover.rs:85; /root/reference/prover/src/batch/prover.rs:149-150) and
+ * `keygen_vk/keygen_pk` (/root/reference/zkevm-circuits/benches/benchmark_list/main.rs:121,132,189,194).
+ * The comments name the replaced symbol; a Rust binding for each is sketched in INTEGRATION.md.
+ *
+ * Conventions
+ *  - Field elements (`halo2curves::bn256::{Fr,Fq}`) are 4 x uint64_t little-endian limbs in Montgomery form
+ *    (R = 2^256), exactly the in-memory `Fr([u64;4])`.  G1Affine = x||y (8 x u64, identity = all zero),
+ *    G1 (Jacobian X/Z^2, Y/Z^3) = x||y||z (12 x u64, identity has z = 0).
+ *  - Every function returns 0 on success or a negative zkhip_status; nothing unwinds or aborts across
+ *    the boundary.  zkhip_last_error(ctx) returns a description of the last failure on that context.
+ *  - One context per device.  A context is not re-entrant: serialise calls per context; different
+ *    contexts are independent.  All pointers stay owned by the caller.
+ *  - `_dev` variants take device pointers (hipMalloc'd or zkhip_dev_alloc'd) and enqueue on the context's
+ *    stream without synchronising; host variants copy in, run, copy out and synchronise.
+ *  - There is no CPU fallback: every call fails with ZKHIP_ERR_HIP when no gfx950 device is usable.
+ */
+#ifndef ZKHIP_H
+#define ZKHIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+    ZKHIP_OK = 0,
+    ZKHIP_ERR_INVALID = -1,   /* bad argument (null pointer, size mismatch, unsupported log_n ...) */
+    ZKHIP_ERR_HIP = -2,       /* HIP runtime failure, text in zkhip_last_error */
+    ZKHIP_ERR_OOM = -3,       /* device allocation failed */
+    ZKHIP_ERR_UNSUPPORTED = -4
+} zkhip_status;
+
+typedef struct zkhip_ctx zkhip_ctx;
+typedef struct zkhip_domain zkhip_domain;
+
+/* ------------------------------------------------------------------ context / memory ---------- */
+int zkhip_create(int device, zkhip_ctx** out);
+void zkhip_destroy(zkhip_ctx* ctx);
+const char* zkhip_last_error(const zkhip_ctx* ctx);
+const char* zkhip_version(void);
+/* Use an existing hipStream_t (e.g. the caller's current stream) instead of the context's own. NULL restores it. */
+int zkhip_set_stream(zkhip_ctx* ctx, void* hip_stream);
+int zkhip_sync(zkhip_ctx* ctx);
+int zkhip_dev_alloc(zkhip_ctx* ctx, size_t bytes, void** dptr);
+int zkhip_dev_free(zkhip_ctx* ctx, void* dptr);
+int zkhip_upload(zkhip_ctx* ctx, void* dptr, const void* host, size_t bytes);
+int zkhip_download(zkhip_ctx* ctx, void* host, const void* dptr, size_t bytes);
+
+/* ------------------------------------------------------------------ field / curve vector ops -----
+ * Element-wise helpers used by the parity tests and by callers that keep polynomials on the device
+ * (`Polynomial<F,B>` +,-,* in halo2_proofs::poly).  field: 0 = Fr, 1 = Fq.  op: 0 add, 1 sub, 2 mul. */
+int zkhip_field_binop(zkhip_ctx* ctx, int field, int op, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n);
+/* Batch inversion (`ff::BatchInvert`, zero maps to zero). */
+int zkhip_field_batch_invert(zkhip_ctx* ctx, int field, const uint64_t* a, uint64_t* out, size_t n);
+/* out[i] = affine(P[i] + Q[i]) for affine inputs — exercises the device G1 group law on its own. */
+int zkhip_g1_add_affine(zkhip_ctx* ctx, const uint64_t* p_xy, const uint64_t* q_xy, uint64_t* out_xy, size_t n);
+/* Throughput probe: runs `iters` dependent Montgomery multiplications per lane on every CU and returns
+ * achieved 32x32->64 multiply-adds per second (the VALU integer peak the MSM roofline is quoted against). */
+int zkhip_probe_mad_rate(zkhip_ctx* ctx, int iters, double* mads_per_second, double* fr_mul_per_second);
+
+/* ------------------------------------------------------------------ MSM ---------------------------
+ * Replaces `halo2_proofs::arithmetic::best_multiexp(coeffs, bases) -> C::Curve` as called by
+ * `ParamsKZG::{commit, commit_lagrange}`.  Bases (the SRS `g` or `g_lagrange`) are registered once. */
+int zkhip_register_bases(zkhip_ctx* ctx, const uint64_t* affine_xy, size_t n, uint32_t* out_id);
+int zkhip_release_bases(zkhip_ctx* ctx, uint32_t bases_id);
+/* scalars: n x 4 Montgomery Fr on the host; uses bases[0..n).  out: Jacobian, 12 x u64. */
+int zkhip_msm(zkhip_ctx* ctx, uint32_t bases_id, const uint64_t* scalars, size_t n, uint64_t out_jacobian[12]);
+/* batch of `batch` scalar vectors (device pointers, each n x 4) against the same bases; out: batch x 12 (host). */
+int zkhip_msm_batch_dev(zkhip_ctx* ctx, uint32_t bases_id, const uint64_t* const* d_scalars, size_t batch, size_t n,
+                        uint64_t* out_jacobian);
+/* MSM over a base sub-range [first, first+n): the unit of the multi-GPU base-range split. */
+int zkhip_msm_range_dev(zkhip_ctx* ctx, uint32_t bases_id, size_t first, const uint64_t* d_scalars, size_t n,
+                        uint64_t out_jacobian[12]);
+/* `Curve::batch_normalize` + point addition helpers for folding per-GPU partial sums. */
+int zkhip_g1_sum_jacobian(const uint64_t* jacobians, size_t count, uint64_t out_jacobian[12]);
+int zkhip_g1_to_affine(const uint64_t jacobian[12], uint64_t out_xy[8]);
+
+/* ------------------------------------------------------------------ NTT ---------------------------
+ * Replaces `halo2_proofs::arithmetic::best_fft(a, omega, log_n)`: in place, natural order in and out,
+ * out[i] = sum_j a[j] * omega^(i*j).  omega must have order exactly 2^log_n. */
+int zkhip_ntt(zkhip_ctx* ctx, uint64_t* a, uint32_t log_n, const uint64_t omega[4]);
+/* batch of device-resident vectors laid out back to back (stride = 2^log_n elements). */
+int zkhip_ntt_dev(zkhip_ctx* ctx, uint64_t* d_a, uint32_t log_n, const uint64_t omega[4], size_t batch);
+
+/* ------------------------------------------------------------------ EvaluationDomain --------------
+ * Replaces `halo2_proofs::poly::EvaluationDomain<Fr>`.  zkhip_domain_create = `EvaluationDomain::new(j, k)`. */
+int zkhip_domain_create(zkhip_ctx* ctx, uint32_t j, uint32_t k, zkhip_domain** out);
+void zkhip_domain_destroy(zkhip_domain* dom);
+uint32_t zkhip_domain_k(const zkhip_domain* dom);
+uint32_t zkhip_domain_extended_k(const zkhip_domain* dom);
+uint32_t zkhip_domain_quotient_poly_degree(const zkhip_domain* dom);
+/* which: 0 omega, 1 omega_inv, 2 extended_omega, 3 extended_omega_inv, 4 g_coset, 5 g_coset_inv,
+ *        6 ifft_divisor, 7 extended_ifft_divisor   (`get_omega`, `get_extended_omega`, ...) */
+int zkhip_domain_constant(const zkhip_domain* dom, int which, uint64_t out[4]);
+/* host, in place / out of place, one polynomial: */
+int zkhip_lagrange_to_coeff(zkhip_domain* dom, uint64_t* a /* 2^k */);
+int zkhip_coeff_to_lagrange(zkhip_domain* dom, uint64_t* a /* 2^k */);
+int zkhip_coeff_to_extended(zkhip_domain* dom, const uint64_t* coeff /* 2^k */, uint64_t* out /* 2^ext_k */);
+int zkhip_extended_to_coeff(zkhip_domain* dom, const uint64_t* ext /* 2^ext_k */, uint64_t* out /* 2^k * (j-1) */);
+int zkhip_divide_by_vanishing_poly(zkhip_domain* dom, uint64_t* ext /* 2^ext_k */);
+/* device-resident, batched (vectors back to back); cosets never round-trip to the host: */
+int zkhip_lagrange_to_coeff_dev(zkhip_domain* dom, uint64_t* d_a, size_t batch);
+int zkhip_coeff_to_lagrange_dev(zkhip_domain* dom, uint64_t* d_a, size_t batch);
+int zkhip_coeff_to_extended_dev(zkhip_domain* dom, const uint64_t* d_coeff, uint64_t* d_out, size_t batch);
+int zkhip_extended_to_coeff_dev(zkhip_domain* dom, uint64_t* d_ext /* clobbered */, uint64_t* d_out, size_t batch);
+int zkhip_divide_by_vanishing_poly_dev(zkhip_domain* dom, uint64_t* d_ext, size_t batch);
+
+/* ------------------------------------------------------------------ evaluate_h --------------------
+ * Replaces `halo2_proofs::plonk::evaluation::Evaluator::evaluate_h(pk, advice_polys, instance_polys,
+ * challenges, y, beta, gamma, theta, lookups, shuffles, permutations)` for one circuit instance.
+ *
+ * zkhip_graph is the serialised `GraphEvaluator { constants, rotations, calculations }`.
+ * calc_words: for each calculation, in order (calculation i writes intermediate i):
+ *      op, then its ValueSources as (kind, a, b) triples:
+ *        ADD/SUB/MUL: two;  SQUARE/DOUBLE/NEGATE/STORE: one;
+ *        HORNER: start, factor, nparts, then nparts part triples.
+ *   kind: 0 Constant(a) 1 Intermediate(a) 2 Fixed(col a, rotation index b) 3 Advice(a,b) 4 Instance(a,b)
+ *         5 Challenge(a) 6 Beta 7 Gamma 8 Theta 9 Y 10 PreviousValue
+ *   op:   0 Add 1 Sub 2 Mul 3 Square 4 Double 5 Negate 6 Horner 7 Store
+ */
+typedef struct {
+    const uint64_t* constants;   /* num_constants x 4 */
+    uint32_t num_constants;
+    const int32_t* rotations;
+    uint32_t num_rotations;
+    const uint32_t* calc_words;
+    uint32_t num_calc_words;
+    uint32_t num_calculations;
+} zkhip_graph;
+
+typedef struct {
+    zkhip_graph graph;                 /* last calculation = (a_compressed + beta) * (s_compressed + gamma) */
+    const uint64_t* product;           /* lookup::prover::Committed::product_poly        */
+    const uint64_t* permuted_input;    /* ...::permuted_input_poly                       */
+    const uint64_t* permuted_table;    /* ...::permuted_table_poly                       */
+} zkhip_lookup;
+
+enum { ZKHIP_MEM_HOST = 0, ZKHIP_MEM_DEVICE = 1 };
+enum { ZKHIP_FORM_COEFF = 0, ZKHIP_FORM_EXTENDED = 1 };
+
+typedef struct {
+    uint32_t mem;            /* where every polynomial pointer below (and `out`) lives */
+    uint32_t poly_form;      /* form of advice/instance/lookup polynomials: COEFF (2^k, as upstream passes them;
+                                the library runs coeff_to_extended) or EXTENDED (2^ext_k cosets) */
+    uint32_t num_fixed, num_advice, num_instance, num_challenges;
+    const uint64_t* const* fixed_cosets;   /* pk.fixed_cosets, always extended        */
+    const uint64_t* const* advice;
+    const uint64_t* const* instance;
+    const uint64_t* challenges;            /* host, num_challenges x 4                 */
+    uint64_t y[4], beta[4], gamma[4], theta[4];
+    const uint64_t* l0;                    /* pk.l0, pk.l_last, pk.l_active_row (extended) */
+    const uint64_t* l_last;
+    const uint64_t* l_active_row;
+    const zkhip_graph* custom_gates;       /* may be NULL                              */
+    uint32_t num_lookups;
+    const zkhip_lookup* lookups;
+    uint32_t num_perm_columns;             /* permutation argument columns, in order   */
+    const uint32_t* perm_column_kind;      /* 2 Fixed, 3 Advice, 4 Instance            */
+    const uint32_t* perm_column_index;
+    const uint64_t* const* perm_sigma_cosets;    /* pk.permutation.cosets (extended)   */
+    uint32_t num_perm_sets;
+    const uint64_t* const* perm_product_cosets;  /* permutation_product_coset per set (extended) */
+    uint32_t perm_chunk_len;               /* cs.degree() - 2                          */
+    uint32_t blinding_factors;             /* cs.blinding_factors()                    */
+} zkhip_evalh_desc;
+
+/* out: 2^ext_k x 4 (host or device per desc->mem) = numerator of the quotient on the extended coset. */
+int zkhip_evaluate_h(zkhip_domain* dom, const zkhip_evalh_desc* desc, uint64_t* out);
+
+/* Kernel timing hook: average duration in microseconds of the launches of the named kernel family issued on
+ * this context since the last zkhip_timing_reset (measured with HIP events on the launch stream).
+ * families: "ntt", "msm_accumulate", "msm_reduce", "evalh_gates", "evalh_lookup", "evalh_perm". */
+int zkhip_timing_enable(zkhip_ctx* ctx, int on);
+int zkhip_timing_reset(zkhip_ctx* ctx);
+int zkhip_timing_get(zkhip_ctx* ctx, const char* family, double* avg_us, uint64_t* launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ZKHIP_H */

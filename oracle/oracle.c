@@ -1,0 +1,793 @@
+/*
+ * oracle.c — CPU restatement of the halo2 polynomial pipeline.  TEST INFRASTRUCTURE, NOT A PRODUCT PATH.
+ *
+ * Restates the algorithms of the out-of-tree `halo2_proofs 0.3.0` fork and `halo2curves 0.6.1`
+ * (/root/reference/Cargo.lock:2189-2217) that the reference calls through `create_proof`
+ * (/root/reference/zkevm-circuits/benches/benchmark_list/main.rs:265,315): 4 x u64 Montgomery Fr/Fq,
+ * Jacobian G1, `arithmetic::{multiexp_serial,best_multiexp,best_fft}`, `poly::EvaluationDomain`,
+ * `plonk::evaluation::{GraphEvaluator::evaluate, Evaluator::evaluate_h}`.  Their source is not in the
+ * reference tree; PARITY UNPINNED at this boundary (the reference holds no golden commitments, cosets
+ * or quotient values).  This file is pinned instead against the Python big-int model and through it
+ * against the reference's Poseidon known answers (/root/reference/poseidon/src/hash.rs:903-950).
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library.
+ * Threading: OpenMP, mirroring the rayon chunking of the upstream functions.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+#include "../include/zkhip.h"
+
+typedef unsigned __int128 u128;
+typedef struct { uint64_t l[4]; } fe;
+
+typedef struct {
+    uint64_t p[4], r[4], r2[4], inv;
+} field_t;
+
+static const field_t FR = {
+    {0x43e1f593f0000001ULL, 0x2833e84879b97091ULL, 0xb85045b68181585dULL, 0x30644e72e131a029ULL},
+    {0xac96341c4ffffffbULL, 0x36fc76959f60cd29ULL, 0x666ea36f7879462eULL, 0x0e0a77c19a07df2fULL},
+    {0x1bb8e645ae216da7ULL, 0x53fe3ab1e35c59e3ULL, 0x8c49833d53bb8085ULL, 0x0216d0b17f4e44a5ULL},
+    0xc2e1f593efffffffULL};
+static const field_t FQ = {
+    {0x3c208c16d87cfd47ULL, 0x97816a916871ca8dULL, 0xb85045b68181585dULL, 0x30644e72e131a029ULL},
+    {0xd35d438dc58f0d9dULL, 0x0a78eb28f5c70b3dULL, 0x666ea36f7879462cULL, 0x0e0a77c19a07df2fULL},
+    {0xf32cfc5b538afa89ULL, 0xb5e71911d44501fbULL, 0x47ab1eff0a417ff6ULL, 0x06d89f71cab8351fULL},
+    0x87d20782e4866389ULL};
+
+/* ------------------------------------------------------------------ field arithmetic ----------- */
+static inline int geq(const uint64_t a[4], const uint64_t b[4]) {
+    for (int i = 3; i >= 0; i--) {
+        if (a[i] > b[i]) return 1;
+        if (a[i] < b[i]) return 0;
+    }
+    return 1;
+}
+static inline void sub_p(uint64_t a[4], const uint64_t p[4]) {
+    u128 br = 0;
+    for (int i = 0; i < 4; i++) {
+        u128 d = (u128)a[i] - p[i] - (uint64_t)br;
+        a[i] = (uint64_t)d;
+        br = (d >> 64) & 1;
+    }
+}
+static inline void f_add(const field_t* F, fe* o, const fe* a, const fe* b) {
+    u128 c = 0;
+    uint64_t t[4];
+    for (int i = 0; i < 4; i++) {
+        c += (u128)a->l[i] + b->l[i];
+        t[i] = (uint64_t)c;
+        c >>= 64;
+    }
+    if (c || geq(t, F->p)) sub_p(t, F->p);
+    memcpy(o->l, t, 32);
+}
+static inline void f_sub(const field_t* F, fe* o, const fe* a, const fe* b) {
+    uint64_t t[4];
+    u128 br = 0;
+    for (int i = 0; i < 4; i++) {
+        u128 d = (u128)a->l[i] - b->l[i] - (uint64_t)br;
+        t[i] = (uint64_t)d;
+        br = (d >> 64) & 1;
+    }
+    if (br) {
+        u128 c = 0;
+        for (int i = 0; i < 4; i++) {
+            c += (u128)t[i] + F->p[i];
+            t[i] = (uint64_t)c;
+            c >>= 64;
+        }
+    }
+    memcpy(o->l, t, 32);
+}
+static inline void f_neg(const field_t* F, fe* o, const fe* a) {
+    fe z = {{0, 0, 0, 0}};
+    f_sub(F, o, &z, a);
+}
+/* CIOS Montgomery product a*b*R^-1 mod p */
+static inline void f_mul(const field_t* F, fe* o, const fe* a, const fe* b) {
+    uint64_t t[6] = {0, 0, 0, 0, 0, 0};
+    for (int i = 0; i < 4; i++) {
+        u128 c = 0;
+        for (int j = 0; j < 4; j++) {
+            c += (u128)a->l[j] * b->l[i] + t[j];
+            t[j] = (uint64_t)c;
+            c >>= 64;
+        }
+        c += t[4];
+        t[4] = (uint64_t)c;
+        t[5] = (uint64_t)(c >> 64);
+        uint64_t m = t[0] * F->inv;
+        c = (u128)m * F->p[0] + t[0];
+        c >>= 64;
+        for (int j = 1; j < 4; j++) {
+            c += (u128)m * F->p[j] + t[j];
+            t[j - 1] = (uint64_t)c;
+            c >>= 64;
+        }
+        c += t[4];
+        t[3] = (uint64_t)c;
+        t[4] = t[5] + (uint64_t)(c >> 64);
+    }
+    if (t[4] || geq(t, F->p)) sub_p(t, F->p);
+    memcpy(o->l, t, 32);
+}
+static inline void f_sqr(const field_t* F, fe* o, const fe* a) { f_mul(F, o, a, a); }
+static inline int f_is_zero(const fe* a) { return (a->l[0] | a->l[1] | a->l[2] | a->l[3]) == 0; }
+static inline int f_eq(const fe* a, const fe* b) { return memcmp(a->l, b->l, 32) == 0; }
+static inline fe f_one(const field_t* F) {
+    fe o;
+    memcpy(o.l, F->r, 32);
+    return o;
+}
+static fe f_pow(const field_t* F, const fe* a, const uint64_t e[4]) {
+    fe acc = f_one(F);
+    for (int i = 255; i >= 0; i--) {
+        f_sqr(F, &acc, &acc);
+        if ((e[i / 64] >> (i % 64)) & 1) f_mul(F, &acc, &acc, a);
+    }
+    return acc;
+}
+static fe f_pow_u64(const field_t* F, const fe* a, uint64_t e) {
+    uint64_t ee[4] = {e, 0, 0, 0};
+    return f_pow(F, a, ee);
+}
+static fe f_inv(const field_t* F, const fe* a) { /* a^(p-2); 0 -> 0 */
+    uint64_t e[4];
+    memcpy(e, F->p, 32);
+    e[0] -= 2; /* p is odd and > 2 in the low limb for both fields */
+    return f_pow(F, a, e);
+}
+static fe f_from_u64(const field_t* F, uint64_t v) {
+    fe a = {{v, 0, 0, 0}}, r2;
+    memcpy(r2.l, F->r2, 32);
+    fe o;
+    f_mul(F, &o, &a, &r2);
+    return o;
+}
+/* Montgomery -> canonical limbs (`to_repr`) */
+static void f_to_canonical(const field_t* F, uint64_t out[4], const fe* a) {
+    fe one = {{1, 0, 0, 0}}, o;
+    f_mul(F, &o, a, &one);
+    memcpy(out, o.l, 32);
+}
+
+static const field_t* pick(int field) { return field == 0 ? &FR : &FQ; }
+
+void oracle_field_binop(int field, int op, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n) {
+    const field_t* F = pick(field);
+    for (size_t i = 0; i < n; i++) {
+        const fe* x = (const fe*)(a + 4 * i);
+        const fe* y = (const fe*)(b + 4 * i);
+        fe o;
+        if (op == 0) f_add(F, &o, x, y);
+        else if (op == 1) f_sub(F, &o, x, y);
+        else f_mul(F, &o, x, y);
+        memcpy(out + 4 * i, o.l, 32);
+    }
+}
+void oracle_field_invert(int field, const uint64_t* a, uint64_t* out, size_t n) {
+    const field_t* F = pick(field);
+    for (size_t i = 0; i < n; i++) {
+        fe o = f_inv(F, (const fe*)(a + 4 * i));
+        memcpy(out + 4 * i, o.l, 32);
+    }
+}
+void oracle_field_to_canonical(int field, const uint64_t* a, uint64_t* out, size_t n) {
+    for (size_t i = 0; i < n; i++) f_to_canonical(pick(field), out + 4 * i, (const fe*)(a + 4 * i));
+}
+void oracle_field_from_canonical(int field, const uint64_t* a, uint64_t* out, size_t n) {
+    const field_t* F = pick(field);
+    fe r2;
+    memcpy(r2.l, F->r2, 32);
+    for (size_t i = 0; i < n; i++) {
+        fe o;
+        f_mul(F, &o, (const fe*)(a + 4 * i), &r2);
+        memcpy(out + 4 * i, o.l, 32);
+    }
+}
+
+/* ------------------------------------------------------------------ G1 (Jacobian, a = 0, b = 3) - */
+typedef struct { fe x, y, z; } g1j;
+typedef struct { fe x, y; } g1a;
+#define Q (&FQ)
+
+static inline int g1a_is_identity(const g1a* p) { return f_is_zero(&p->x) && f_is_zero(&p->y); }
+static inline void g1j_set_identity(g1j* p) { memset(p, 0, sizeof *p); }
+static inline int g1j_is_identity(const g1j* p) { return f_is_zero(&p->z); }
+
+static void g1j_double(g1j* o, const g1j* p) {
+    if (g1j_is_identity(p)) { *o = *p; return; }
+    fe a, b, c, d, e, f, t;
+    f_sqr(Q, &a, &p->x);
+    f_sqr(Q, &b, &p->y);
+    f_sqr(Q, &c, &b);
+    f_add(Q, &d, &p->x, &b);
+    f_sqr(Q, &d, &d);
+    f_sub(Q, &d, &d, &a);
+    f_sub(Q, &d, &d, &c);
+    f_add(Q, &d, &d, &d);
+    f_add(Q, &e, &a, &a);
+    f_add(Q, &e, &e, &a);
+    f_sqr(Q, &f, &e);
+    fe z3;
+    f_mul(Q, &z3, &p->y, &p->z);
+    f_add(Q, &z3, &z3, &z3);
+    fe x3;
+    f_sub(Q, &x3, &f, &d);
+    f_sub(Q, &x3, &x3, &d);
+    f_add(Q, &c, &c, &c);
+    f_add(Q, &c, &c, &c);
+    f_add(Q, &c, &c, &c);
+    f_sub(Q, &t, &d, &x3);
+    f_mul(Q, &t, &e, &t);
+    f_sub(Q, &o->y, &t, &c);
+    o->x = x3;
+    o->z = z3;
+}
+static void g1j_add_mixed(g1j* o, const g1j* p, const g1a* q) {
+    if (g1a_is_identity(q)) { *o = *p; return; }
+    if (g1j_is_identity(p)) {
+        o->x = q->x; o->y = q->y; o->z = f_one(Q);
+        return;
+    }
+    fe z1z1, u2, s2, h, hh, i, j, r, v, t;
+    f_sqr(Q, &z1z1, &p->z);
+    f_mul(Q, &u2, &q->x, &z1z1);
+    f_mul(Q, &s2, &q->y, &p->z);
+    f_mul(Q, &s2, &s2, &z1z1);
+    if (f_eq(&u2, &p->x)) {
+        if (f_eq(&s2, &p->y)) { g1j_double(o, p); return; }
+        g1j_set_identity(o);
+        return;
+    }
+    f_sub(Q, &h, &u2, &p->x);
+    f_sqr(Q, &hh, &h);
+    f_add(Q, &i, &hh, &hh);
+    f_add(Q, &i, &i, &i);
+    f_mul(Q, &j, &h, &i);
+    f_sub(Q, &r, &s2, &p->y);
+    f_add(Q, &r, &r, &r);
+    f_mul(Q, &v, &p->x, &i);
+    fe x3, y3, z3;
+    f_sqr(Q, &x3, &r);
+    f_sub(Q, &x3, &x3, &j);
+    f_sub(Q, &x3, &x3, &v);
+    f_sub(Q, &x3, &x3, &v);
+    f_mul(Q, &t, &p->y, &j);
+    f_add(Q, &t, &t, &t);
+    f_sub(Q, &y3, &v, &x3);
+    f_mul(Q, &y3, &y3, &r);
+    f_sub(Q, &y3, &y3, &t);
+    f_add(Q, &z3, &p->z, &h);
+    f_sqr(Q, &z3, &z3);
+    f_sub(Q, &z3, &z3, &z1z1);
+    f_sub(Q, &z3, &z3, &hh);
+    o->x = x3; o->y = y3; o->z = z3;
+}
+static void g1j_add(g1j* o, const g1j* p, const g1j* q) {
+    if (g1j_is_identity(p)) { *o = *q; return; }
+    if (g1j_is_identity(q)) { *o = *p; return; }
+    fe z1z1, z2z2, u1, u2, s1, s2, h, i, j, r, v, t;
+    f_sqr(Q, &z1z1, &p->z);
+    f_sqr(Q, &z2z2, &q->z);
+    f_mul(Q, &u1, &p->x, &z2z2);
+    f_mul(Q, &u2, &q->x, &z1z1);
+    f_mul(Q, &s1, &p->y, &q->z);
+    f_mul(Q, &s1, &s1, &z2z2);
+    f_mul(Q, &s2, &q->y, &p->z);
+    f_mul(Q, &s2, &s2, &z1z1);
+    if (f_eq(&u1, &u2)) {
+        if (f_eq(&s1, &s2)) { g1j_double(o, p); return; }
+        g1j_set_identity(o);
+        return;
+    }
+    f_sub(Q, &h, &u2, &u1);
+    f_add(Q, &i, &h, &h);
+    f_sqr(Q, &i, &i);
+    f_mul(Q, &j, &h, &i);
+    f_sub(Q, &r, &s2, &s1);
+    f_add(Q, &r, &r, &r);
+    f_mul(Q, &v, &u1, &i);
+    fe x3, y3, z3;
+    f_sqr(Q, &x3, &r);
+    f_sub(Q, &x3, &x3, &j);
+    f_sub(Q, &x3, &x3, &v);
+    f_sub(Q, &x3, &x3, &v);
+    f_mul(Q, &t, &s1, &j);
+    f_add(Q, &t, &t, &t);
+    f_sub(Q, &y3, &v, &x3);
+    f_mul(Q, &y3, &y3, &r);
+    f_sub(Q, &y3, &y3, &t);
+    f_add(Q, &z3, &p->z, &q->z);
+    f_sqr(Q, &z3, &z3);
+    f_sub(Q, &z3, &z3, &z1z1);
+    f_sub(Q, &z3, &z3, &z2z2);
+    f_mul(Q, &z3, &z3, &h);
+    o->x = x3; o->y = y3; o->z = z3;
+}
+static void g1j_to_affine(g1a* o, const g1j* p) {
+    if (g1j_is_identity(p)) { memset(o, 0, sizeof *o); return; }
+    fe zi = f_inv(Q, &p->z), zi2, zi3;
+    f_sqr(Q, &zi2, &zi);
+    f_mul(Q, &zi3, &zi2, &zi);
+    f_mul(Q, &o->x, &p->x, &zi2);
+    f_mul(Q, &o->y, &p->y, &zi3);
+}
+
+void oracle_g1_to_affine(const uint64_t* jac, uint64_t* out_xy) {
+    g1j_to_affine((g1a*)out_xy, (const g1j*)jac);
+}
+void oracle_g1_add_affine(const uint64_t* p_xy, const uint64_t* q_xy, uint64_t* out_xy, size_t n) {
+    for (size_t i = 0; i < n; i++) {
+        g1j acc;
+        g1j_set_identity(&acc);
+        g1j_add_mixed(&acc, &acc, (const g1a*)(p_xy + 8 * i));
+        g1j_add_mixed(&acc, &acc, (const g1a*)(q_xy + 8 * i));
+        g1j_to_affine((g1a*)(out_xy + 8 * i), &acc);
+    }
+}
+void oracle_g1_sum_jacobian(const uint64_t* jacs, size_t count, uint64_t* out) {
+    g1j acc;
+    g1j_set_identity(&acc);
+    for (size_t i = 0; i < count; i++) g1j_add(&acc, &acc, (const g1j*)(jacs + 12 * i));
+    memcpy(out, &acc, sizeof acc);
+}
+/* bases[i] = (i+1)*G, G = (1,2), by running mixed addition + per-point normalisation in blocks. */
+void oracle_g1_bases(uint64_t* out_xy, size_t n) {
+    g1a g;
+    g.x = f_from_u64(Q, 1);
+    g.y = f_from_u64(Q, 2);
+    g1j acc;
+    g1j_set_identity(&acc);
+    const size_t B = 1024;
+    g1j* blk = malloc(B * sizeof(g1j));
+    fe* pre = malloc(B * sizeof(fe));
+    for (size_t s = 0; s < n; s += B) {
+        size_t m = n - s < B ? n - s : B;
+        for (size_t i = 0; i < m; i++) {
+            g1j_add_mixed(&acc, &acc, &g);
+            blk[i] = acc;
+        }
+        /* batch-normalise: prefix products of z (never zero: (i+1)G != O for i+1 < r) */
+        fe run = f_one(Q);
+        for (size_t i = 0; i < m; i++) { pre[i] = run; f_mul(Q, &run, &run, &blk[i].z); }
+        fe inv = f_inv(Q, &run);
+        for (size_t i = m; i-- > 0;) {
+            fe zi, zi2, zi3;
+            f_mul(Q, &zi, &inv, &pre[i]);
+            f_mul(Q, &inv, &inv, &blk[i].z);
+            f_sqr(Q, &zi2, &zi);
+            f_mul(Q, &zi3, &zi2, &zi);
+            g1a* o = (g1a*)(out_xy + 8 * (s + i));
+            f_mul(Q, &o->x, &blk[i].x, &zi2);
+            f_mul(Q, &o->y, &blk[i].y, &zi3);
+        }
+    }
+    free(blk);
+    free(pre);
+}
+
+/* ------------------------------------------------------------------ multiexp -------------------- */
+static inline uint64_t get_at(int segment, int c, const uint64_t repr[4]) {
+    int skip_bits = segment * c;
+    if (skip_bits >= 256) return 0;
+    int limb = skip_bits / 64, off = skip_bits % 64;
+    uint64_t v = repr[limb] >> off;
+    if (off + c > 64 && limb + 1 < 4) v |= repr[limb + 1] << (64 - off);
+    return v & ((1ULL << c) - 1);
+}
+/* `multiexp_serial`: unsigned c-bit windows, high to low, running-sum bucket fold. */
+static void multiexp_serial(const uint64_t* coeffs, const uint64_t* bases, size_t n, g1j* acc) {
+    int c;
+    if (n < 4) c = 1;
+    else if (n < 32) c = 3;
+    else c = (int)ceil(log((double)n));
+    uint64_t* repr = malloc(n * 32);
+    for (size_t i = 0; i < n; i++) f_to_canonical(&FR, repr + 4 * i, (const fe*)(coeffs + 4 * i));
+    int segments = 256 / c + 1;
+    size_t nb = ((size_t)1 << c) - 1;
+    g1j* buckets = malloc(nb * sizeof(g1j));
+    for (int seg = segments - 1; seg >= 0; seg--) {
+        for (int k = 0; k < c; k++) g1j_double(acc, acc);
+        memset(buckets, 0, nb * sizeof(g1j));
+        for (size_t i = 0; i < n; i++) {
+            uint64_t w = get_at(seg, c, repr + 4 * i);
+            if (w) g1j_add_mixed(&buckets[w - 1], &buckets[w - 1], (const g1a*)(bases + 8 * i));
+        }
+        g1j running;
+        g1j_set_identity(&running);
+        for (size_t b = nb; b-- > 0;) {
+            g1j_add(&running, &running, &buckets[b]);
+            g1j_add(acc, acc, &running);
+        }
+    }
+    free(buckets);
+    free(repr);
+}
+/* `best_multiexp`: n/threads-sized chunks, one serial Pippenger each, partials summed in order. */
+void oracle_best_multiexp(const uint64_t* coeffs, const uint64_t* bases, size_t n, int threads, uint64_t* out_jac) {
+    g1j total;
+    g1j_set_identity(&total);
+    if (threads < 1) threads = 1;
+    if (n > (size_t)threads) {
+        size_t chunk = n / threads;
+        size_t nchunks = (n + chunk - 1) / chunk;
+        g1j* parts = calloc(nchunks, sizeof(g1j));
+#pragma omp parallel for schedule(dynamic, 1) num_threads(threads)
+        for (long ci = 0; ci < (long)nchunks; ci++) {
+            size_t s = (size_t)ci * chunk, m = n - s < chunk ? n - s : chunk;
+            multiexp_serial(coeffs + 4 * s, bases + 8 * s, m, &parts[ci]);
+        }
+        for (size_t ci = 0; ci < nchunks; ci++) g1j_add(&total, &total, &parts[ci]);
+        free(parts);
+    } else {
+        multiexp_serial(coeffs, bases, n, &total);
+    }
+    memcpy(out_jac, &total, sizeof total);
+}
+
+/* ------------------------------------------------------------------ best_fft -------------------- */
+static inline uint32_t bitrev(uint32_t v, uint32_t l) {
+    uint32_t r = 0;
+    for (uint32_t i = 0; i < l; i++) { r = (r << 1) | (v & 1); v >>= 1; }
+    return r;
+}
+/* in place, natural order in/out; bit-reversal permutation then radix-2 butterflies with a shared
+ * twiddle table of n/2 powers, levels parallelised over butterflies. */
+void oracle_best_fft(uint64_t* a_, const uint64_t* omega_, uint32_t log_n, int threads) {
+    fe* a = (fe*)a_;
+    const fe* omega = (const fe*)omega_;
+    size_t n = (size_t)1 << log_n;
+    if (threads < 1) threads = 1;
+    for (size_t k = 0; k < n; k++) {
+        size_t rk = bitrev((uint32_t)k, log_n);
+        if (k < rk) { fe t = a[k]; a[k] = a[rk]; a[rk] = t; }
+    }
+    size_t half = n / 2 ? n / 2 : 1;
+    fe* tw = malloc(half * sizeof(fe));
+    tw[0] = f_one(&FR);
+    for (size_t i = 1; i < n / 2; i++) f_mul(&FR, &tw[i], &tw[i - 1], omega);
+    for (size_t m = 1; m < n; m *= 2) {
+        size_t step = n / (2 * m);
+#pragma omp parallel for schedule(static) num_threads(threads) if (n >= 4096)
+        for (long b = 0; b < (long)(n / 2); b++) {
+            size_t k = ((size_t)b / m) * 2 * m, j = (size_t)b % m;
+            fe t;
+            f_mul(&FR, &t, &a[k + j + m], &tw[j * step]);
+            f_sub(&FR, &a[k + j + m], &a[k + j], &t);
+            f_add(&FR, &a[k + j], &a[k + j], &t);
+        }
+    }
+    free(tw);
+}
+
+/* ------------------------------------------------------------------ EvaluationDomain ------------ */
+typedef struct {
+    uint32_t k, extended_k, quotient_poly_degree;
+    fe omega, omega_inv, extended_omega, extended_omega_inv, g_coset, g_coset_inv, ifft_divisor,
+        extended_ifft_divisor;
+    fe* t_evaluations; /* 2^(extended_k - k) inverted values */
+    int threads;
+} odomain;
+
+static const uint64_t ROOT_OF_UNITY_CANON[4] = {0xd34f1ed960c37c9cULL, 0x3215cf6dd39329c8ULL, 0x98865ea93dd31f74ULL,
+                                               0x03ddb9f5166d18b7ULL};
+static const uint64_t ZETA_CANON[4] = {0x8b17ea66b99c90ddULL, 0x5bfc41088d8daaa7ULL, 0xb3c4d79d41a91758ULL, 0};
+static const uint64_t DELTA_CANON[4] = {0x870e56bbe533e9a2ULL, 0x5b5f898e5e963f25ULL, 0x64ec26aad4c86e71ULL,
+                                        0x09226b6e22c6f0caULL};
+static fe from_canon(const uint64_t c[4]) {
+    fe o;
+    oracle_field_from_canonical(0, c, o.l, 1);
+    return o;
+}
+
+odomain* oracle_domain_new(uint32_t j, uint32_t k, int threads) {
+    odomain* d = calloc(1, sizeof *d);
+    d->k = k;
+    d->quotient_poly_degree = j - 1;
+    d->threads = threads;
+    uint64_t n = 1ULL << k;
+    uint32_t ek = k;
+    while ((1ULL << ek) < n * (uint64_t)(j - 1)) ek++;
+    d->extended_k = ek;
+    fe w = from_canon(ROOT_OF_UNITY_CANON);
+    for (uint32_t i = ek; i < 28; i++) f_sqr(&FR, &w, &w);
+    d->extended_omega = w;
+    d->extended_omega_inv = f_inv(&FR, &w);
+    for (uint32_t i = k; i < ek; i++) f_sqr(&FR, &w, &w);
+    d->omega = w;
+    d->omega_inv = f_inv(&FR, &w);
+    d->g_coset = from_canon(ZETA_CANON);
+    f_sqr(&FR, &d->g_coset_inv, &d->g_coset);
+    fe nn = f_from_u64(&FR, n);
+    d->ifft_divisor = f_inv(&FR, &nn);
+    fe en = f_from_u64(&FR, 1ULL << ek);
+    d->extended_ifft_divisor = f_inv(&FR, &en);
+    size_t m = (size_t)1 << (ek - k);
+    d->t_evaluations = malloc(m * sizeof(fe));
+    fe one = f_one(&FR);
+    for (size_t i = 0; i < m; i++) {
+        fe wi = f_pow_u64(&FR, &d->extended_omega, i), c, t;
+        f_mul(&FR, &c, &d->g_coset, &wi);
+        t = f_pow_u64(&FR, &c, n);
+        f_sub(&FR, &t, &t, &one);
+        d->t_evaluations[i] = f_inv(&FR, &t);
+    }
+    return d;
+}
+void oracle_domain_free(odomain* d) {
+    if (d) { free(d->t_evaluations); free(d); }
+}
+uint32_t oracle_domain_extended_k(const odomain* d) { return d->extended_k; }
+void oracle_domain_constant(const odomain* d, int which, uint64_t* out) {
+    const fe* src[8] = {&d->omega, &d->omega_inv, &d->extended_omega, &d->extended_omega_inv,
+                        &d->g_coset, &d->g_coset_inv, &d->ifft_divisor, &d->extended_ifft_divisor};
+    memcpy(out, src[which]->l, 32);
+}
+void oracle_lagrange_to_coeff(const odomain* d, uint64_t* a) {
+    oracle_best_fft(a, d->omega_inv.l, d->k, d->threads);
+    size_t n = (size_t)1 << d->k;
+    for (size_t i = 0; i < n; i++) f_mul(&FR, (fe*)(a + 4 * i), (fe*)(a + 4 * i), &d->ifft_divisor);
+}
+void oracle_coeff_to_lagrange(const odomain* d, uint64_t* a) { oracle_best_fft(a, d->omega.l, d->k, d->threads); }
+static void distribute_powers_zeta(const odomain* d, fe* a, size_t len, int into_coset) {
+    fe cz[2];
+    cz[0] = into_coset ? d->g_coset : d->g_coset_inv;
+    cz[1] = into_coset ? d->g_coset_inv : d->g_coset;
+    for (size_t i = 0; i < len; i++) {
+        size_t r = i % 3;
+        if (r) f_mul(&FR, &a[i], &a[i], &cz[r - 1]);
+    }
+}
+void oracle_coeff_to_extended(const odomain* d, const uint64_t* coeff, uint64_t* out) {
+    size_t n = (size_t)1 << d->k, en = (size_t)1 << d->extended_k;
+    memcpy(out, coeff, n * 32);
+    memset(out + 4 * n, 0, (en - n) * 32);
+    distribute_powers_zeta(d, (fe*)out, n, 1);
+    oracle_best_fft(out, d->extended_omega.l, d->extended_k, d->threads);
+}
+void oracle_extended_to_coeff(const odomain* d, const uint64_t* ext, uint64_t* out) {
+    size_t n = (size_t)1 << d->k, en = (size_t)1 << d->extended_k;
+    fe* a = malloc(en * sizeof(fe));
+    memcpy(a, ext, en * 32);
+    oracle_best_fft((uint64_t*)a, d->extended_omega_inv.l, d->extended_k, d->threads);
+    for (size_t i = 0; i < en; i++) f_mul(&FR, &a[i], &a[i], &d->extended_ifft_divisor);
+    distribute_powers_zeta(d, a, en, 0);
+    memcpy(out, a, n * d->quotient_poly_degree * 32);
+    free(a);
+}
+void oracle_divide_by_vanishing_poly(const odomain* d, uint64_t* ext) {
+    size_t en = (size_t)1 << d->extended_k, m = (size_t)1 << (d->extended_k - d->k);
+    for (size_t i = 0; i < en; i++) f_mul(&FR, (fe*)(ext + 4 * i), (fe*)(ext + 4 * i), &d->t_evaluations[i % m]);
+}
+
+/* ------------------------------------------------------------------ GraphEvaluator -------------- */
+typedef struct {
+    const fe* const* fixed;
+    const fe* const* advice;
+    const fe* const* instance;
+    const fe* challenges;
+    fe beta, gamma, theta, y;
+} eval_in;
+
+static inline size_t rot_idx(size_t idx, int32_t rot, size_t rot_scale, size_t isize) {
+    long long v = ((long long)idx + (long long)rot * (long long)rot_scale) % (long long)isize;
+    if (v < 0) v += (long long)isize;
+    return (size_t)v;
+}
+static inline fe vs_get(const uint32_t* vs, const zkhip_graph* g, const fe* inter, const size_t* rots,
+                        const eval_in* in, const fe* prev) {
+    uint32_t a = vs[1], b = vs[2];
+    switch (vs[0]) {
+        case 0: return *(const fe*)(g->constants + 4 * a);
+        case 1: return inter[a];
+        case 2: return in->fixed[a][rots[b]];
+        case 3: return in->advice[a][rots[b]];
+        case 4: return in->instance[a][rots[b]];
+        case 5: return in->challenges[a];
+        case 6: return in->beta;
+        case 7: return in->gamma;
+        case 8: return in->theta;
+        case 9: return in->y;
+        default: return *prev;
+    }
+}
+/* `GraphEvaluator::evaluate`: fill rotations, run every calculation, return the last intermediate. */
+static fe graph_evaluate(const zkhip_graph* g, fe* inter, size_t* rots, const eval_in* in, const fe* prev,
+                         size_t idx, size_t rot_scale, size_t isize) {
+    for (uint32_t r = 0; r < g->num_rotations; r++) rots[r] = rot_idx(idx, g->rotations[r], rot_scale, isize);
+    const uint32_t* w = g->calc_words;
+    fe last;
+    memset(&last, 0, sizeof last);
+    for (uint32_t t = 0; t < g->num_calculations; t++) {
+        uint32_t op = *w++;
+        fe v, x, y2;
+        switch (op) {
+            case 0: case 1: case 2:
+                x = vs_get(w, g, inter, rots, in, prev);
+                y2 = vs_get(w + 3, g, inter, rots, in, prev);
+                w += 6;
+                if (op == 0) f_add(&FR, &v, &x, &y2);
+                else if (op == 1) f_sub(&FR, &v, &x, &y2);
+                else f_mul(&FR, &v, &x, &y2);
+                break;
+            case 3: x = vs_get(w, g, inter, rots, in, prev); w += 3; f_sqr(&FR, &v, &x); break;
+            case 4: x = vs_get(w, g, inter, rots, in, prev); w += 3; f_add(&FR, &v, &x, &x); break;
+            case 5: x = vs_get(w, g, inter, rots, in, prev); w += 3; f_neg(&FR, &v, &x); break;
+            case 6: {
+                v = vs_get(w, g, inter, rots, in, prev);
+                fe f = vs_get(w + 3, g, inter, rots, in, prev);
+                uint32_t np = w[6];
+                w += 7;
+                for (uint32_t p = 0; p < np; p++, w += 3) {
+                    fe part = vs_get(w, g, inter, rots, in, prev);
+                    f_mul(&FR, &v, &v, &f);
+                    f_add(&FR, &v, &v, &part);
+                }
+                break;
+            }
+            default: v = vs_get(w, g, inter, rots, in, prev); w += 3; break;
+        }
+        inter[t] = v;
+        last = v;
+    }
+    return last;
+}
+
+/* `Evaluator::evaluate_h` for one circuit instance.  Every polynomial pointer in `desc` must be a host
+ * pointer to an EXTENDED coset (desc->poly_form == ZKHIP_FORM_EXTENDED). */
+int oracle_evaluate_h(const odomain* d, const zkhip_evalh_desc* desc, uint64_t* out_) {
+    if (desc->poly_form != ZKHIP_FORM_EXTENDED || desc->mem != ZKHIP_MEM_HOST) return -1;
+    size_t size = (size_t)1 << d->extended_k, rot_scale = (size_t)1 << (d->extended_k - d->k);
+    fe* values = (fe*)out_;
+    memset(values, 0, size * sizeof(fe));
+    eval_in in;
+    in.fixed = (const fe* const*)desc->fixed_cosets;
+    in.advice = (const fe* const*)desc->advice;
+    in.instance = (const fe* const*)desc->instance;
+    in.challenges = (const fe*)desc->challenges;
+    memcpy(&in.beta, desc->beta, 32);
+    memcpy(&in.gamma, desc->gamma, 32);
+    memcpy(&in.theta, desc->theta, 32);
+    memcpy(&in.y, desc->y, 32);
+    const fe* l0 = (const fe*)desc->l0;
+    const fe* l_last = (const fe*)desc->l_last;
+    const fe* l_active = (const fe*)desc->l_active_row;
+    const fe one = f_one(&FR);
+    int threads = d->threads < 1 ? 1 : d->threads;
+
+    if (desc->custom_gates) {
+        const zkhip_graph* g = desc->custom_gates;
+#pragma omp parallel num_threads(threads)
+        {
+            fe* inter = malloc((g->num_calculations + 1) * sizeof(fe));
+            size_t* rots = malloc((g->num_rotations + 1) * sizeof(size_t));
+#pragma omp for schedule(static)
+            for (long idx = 0; idx < (long)size; idx++)
+                values[idx] = graph_evaluate(g, inter, rots, &in, &values[idx], (size_t)idx, rot_scale, size);
+            free(inter);
+            free(rots);
+        }
+    }
+
+    if (desc->num_perm_sets) {
+        const fe* const* z = (const fe* const*)desc->perm_product_cosets;
+        const fe* const* sigma = (const fe* const*)desc->perm_sigma_cosets;
+        uint32_t nsets = desc->num_perm_sets, chunk = desc->perm_chunk_len, ncols = desc->num_perm_columns;
+        int32_t last_rot = -((int32_t)desc->blinding_factors + 1);
+        fe zeta = from_canon(ZETA_CANON), delta = from_canon(DELTA_CANON), delta_start;
+        f_mul(&FR, &delta_start, &in.beta, &zeta);
+#pragma omp parallel for schedule(static) num_threads(threads)
+        for (long idx_ = 0; idx_ < (long)size; idx_++) {
+            size_t idx = (size_t)idx_;
+            fe v = values[idx], t, u;
+            size_t r_next = rot_idx(idx, 1, rot_scale, size), r_last = rot_idx(idx, last_rot, rot_scale, size);
+            f_mul(&FR, &v, &v, &in.y);
+            f_sub(&FR, &t, &one, &z[0][idx]);
+            f_mul(&FR, &t, &t, &l0[idx]);
+            f_add(&FR, &v, &v, &t);
+            f_mul(&FR, &v, &v, &in.y);
+            f_sqr(&FR, &t, &z[nsets - 1][idx]);
+            f_sub(&FR, &t, &t, &z[nsets - 1][idx]);
+            f_mul(&FR, &t, &t, &l_last[idx]);
+            f_add(&FR, &v, &v, &t);
+            for (uint32_t s = 1; s < nsets; s++) {
+                f_mul(&FR, &v, &v, &in.y);
+                f_sub(&FR, &t, &z[s][idx], &z[s - 1][r_last]);
+                f_mul(&FR, &t, &t, &l0[idx]);
+                f_add(&FR, &v, &v, &t);
+            }
+            fe beta_term = f_pow_u64(&FR, &d->extended_omega, idx), current_delta;
+            f_mul(&FR, &current_delta, &delta_start, &beta_term);
+            for (uint32_t s = 0; s < nsets; s++) {
+                uint32_t c0 = s * chunk, c1 = c0 + chunk > ncols ? ncols : c0 + chunk;
+                fe left = z[s][r_next], right = z[s][idx];
+                for (uint32_t c = c0; c < c1; c++) {
+                    const fe* col = desc->perm_column_kind[c] == 3 ? in.advice[desc->perm_column_index[c]]
+                                    : desc->perm_column_kind[c] == 2 ? in.fixed[desc->perm_column_index[c]]
+                                                                      : in.instance[desc->perm_column_index[c]];
+                    f_mul(&FR, &t, &in.beta, &sigma[c][idx]);
+                    f_add(&FR, &t, &t, &col[idx]);
+                    f_add(&FR, &t, &t, &in.gamma);
+                    f_mul(&FR, &left, &left, &t);
+                    f_add(&FR, &u, &col[idx], &current_delta);
+                    f_add(&FR, &u, &u, &in.gamma);
+                    f_mul(&FR, &right, &right, &u);
+                    f_mul(&FR, &current_delta, &current_delta, &delta);
+                }
+                f_mul(&FR, &v, &v, &in.y);
+                f_sub(&FR, &t, &left, &right);
+                f_mul(&FR, &t, &t, &l_active[idx]);
+                f_add(&FR, &v, &v, &t);
+            }
+            values[idx] = v;
+        }
+    }
+
+    for (uint32_t n = 0; n < desc->num_lookups; n++) {
+        const zkhip_lookup* lk = &desc->lookups[n];
+        const zkhip_graph* g = &lk->graph;
+        const fe* zc = (const fe*)lk->product;
+        const fe* ac = (const fe*)lk->permuted_input;
+        const fe* sc = (const fe*)lk->permuted_table;
+        fe zero;
+        memset(&zero, 0, sizeof zero);
+#pragma omp parallel num_threads(threads)
+        {
+            fe* inter = malloc((g->num_calculations + 1) * sizeof(fe));
+            size_t* rots = malloc((g->num_rotations + 1) * sizeof(size_t));
+#pragma omp for schedule(static)
+            for (long idx_ = 0; idx_ < (long)size; idx_++) {
+                size_t idx = (size_t)idx_;
+                fe table_value = graph_evaluate(g, inter, rots, &in, &zero, idx, rot_scale, size);
+                size_t r_next = rot_idx(idx, 1, rot_scale, size), r_prev = rot_idx(idx, -1, rot_scale, size);
+                fe v = values[idx], t, u, a_minus_s;
+                f_sub(&FR, &a_minus_s, &ac[idx], &sc[idx]);
+                f_mul(&FR, &v, &v, &in.y);
+                f_sub(&FR, &t, &one, &zc[idx]);
+                f_mul(&FR, &t, &t, &l0[idx]);
+                f_add(&FR, &v, &v, &t);
+                f_mul(&FR, &v, &v, &in.y);
+                f_sqr(&FR, &t, &zc[idx]);
+                f_sub(&FR, &t, &t, &zc[idx]);
+                f_mul(&FR, &t, &t, &l_last[idx]);
+                f_add(&FR, &v, &v, &t);
+                f_mul(&FR, &v, &v, &in.y);
+                f_add(&FR, &t, &ac[idx], &in.beta);
+                f_add(&FR, &u, &sc[idx], &in.gamma);
+                f_mul(&FR, &t, &t, &u);
+                f_mul(&FR, &t, &t, &zc[r_next]);
+                f_mul(&FR, &u, &zc[idx], &table_value);
+                f_sub(&FR, &t, &t, &u);
+                f_mul(&FR, &t, &t, &l_active[idx]);
+                f_add(&FR, &v, &v, &t);
+                f_mul(&FR, &v, &v, &in.y);
+                f_mul(&FR, &t, &a_minus_s, &l0[idx]);
+                f_add(&FR, &v, &v, &t);
+                f_mul(&FR, &v, &v, &in.y);
+                f_sub(&FR, &t, &ac[idx], &ac[r_prev]);
+                f_mul(&FR, &t, &t, &a_minus_s);
+                f_mul(&FR, &t, &t, &l_active[idx]);
+                f_add(&FR, &v, &v, &t);
+                values[idx] = v;
+            }
+            free(inter);
+            free(rots);
+        }
+    }
+    return 0;
+}
+
+int oracle_max_threads(void) {
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}

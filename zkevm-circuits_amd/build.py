@@ -1,0 +1,51 @@
+"""Builds libzkhip.so (HIP kernels + C ABI) for gfx950 with hipcc, in-tree."""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "libzkhip.so")
+SOURCES = ["api.hip", "ntt.hip", "domain.hip", "msm.hip", "evalh.hip", "host_math.cpp"]
+
+
+def _newer(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    srcs = [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
+    deps = srcs + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".h", ".cuh"))]
+    deps.append(os.path.join(HERE, "..", "include", "zkhip.h"))
+    objs = []
+    os.makedirs(os.path.join(HERE, "build"), exist_ok=True)
+    procs = []
+    for s in srcs:
+        o = os.path.join(HERE, "build", os.path.basename(s) + ".o")
+        objs.append(o)
+        if force or _newer(o, deps):
+            cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-c", "-x", "hip", s, "-o", o,
+                   "-Wall", "-Wno-unused-function", "-Wno-unused-result"]
+            if verbose:
+                print(" ".join(cmd), file=sys.stderr)
+            procs.append((s, subprocess.Popen(cmd)))
+    for s, p in procs:
+        if p.wait() != 0:
+            raise RuntimeError(f"hipcc failed on {s}")
+    if force or procs or _newer(LIB, objs):
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,91 @@
+// Shared host-side declarations of libzkhip (context, error plumbing, timing hooks).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <map>
+#include <string>
+#include <vector>
+#include "../../include/zkhip.h"
+#include "field.cuh"
+
+namespace zkhip {
+
+struct BaseSet {
+    void* d_points = nullptr;   // device copy of the affine bases (n x 64 B)
+    size_t n = 0;
+};
+
+struct NttPlan;
+
+struct TimingSlot {
+    double total_us = 0;
+    uint64_t launches = 0;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
+};
+
+}  // namespace zkhip
+
+struct zkhip_ctx {
+    int device = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    std::string last_error;
+    std::map<uint32_t, zkhip::BaseSet> bases;
+    uint32_t next_bases_id = 1;
+    // scratch arena reused across calls (grown on demand, never shrunk)
+    void* scratch = nullptr;
+    size_t scratch_bytes = 0;
+    bool timing = false;
+    std::map<std::string, zkhip::TimingSlot> timers;
+    int num_cus = 256;
+    std::vector<zkhip::NttPlan*> plans;   // cached per (log_n, omega)
+};
+
+namespace zkhip {
+
+int set_error(zkhip_ctx* ctx, int code, const char* fmt, ...);
+int ensure_scratch(zkhip_ctx* ctx, size_t bytes);
+
+#define ZK_HIP(ctx, expr)                                                                             \
+    do {                                                                                              \
+        hipError_t _e = (expr);                                                                       \
+        if (_e != hipSuccess)                                                                         \
+            return zkhip::set_error((ctx), _e == hipErrorOutOfMemory ? ZKHIP_ERR_OOM : ZKHIP_ERR_HIP, \
+                                    "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+    } while (0)
+
+#define ZK_CHECK(ctx, cond, ...)                                                  \
+    do {                                                                          \
+        if (!(cond)) return zkhip::set_error((ctx), ZKHIP_ERR_INVALID, __VA_ARGS__); \
+    } while (0)
+
+// RAII-less timing bracket: records HIP events around a kernel family when timing is enabled.
+struct TimedRegion {
+    zkhip_ctx* ctx;
+    const char* family;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    TimedRegion(zkhip_ctx* c, const char* f);
+    ~TimedRegion();
+};
+
+// ---- host-side field helpers (4 x u64 Montgomery) used for constants and final folds --------------
+struct HostField {
+    uint64_t p[4], r[4], r2[4], inv;
+};
+extern const HostField HFR, HFQ;
+void h_mul(const HostField& F, uint64_t o[4], const uint64_t a[4], const uint64_t b[4]);
+void h_add(const HostField& F, uint64_t o[4], const uint64_t a[4], const uint64_t b[4]);
+void h_sub(const HostField& F, uint64_t o[4], const uint64_t a[4], const uint64_t b[4]);
+void h_inv(const HostField& F, uint64_t o[4], const uint64_t a[4]);
+void h_pow(const HostField& F, uint64_t o[4], const uint64_t a[4], uint64_t e);
+void h_from_u64(const HostField& F, uint64_t o[4], uint64_t v);
+bool h_is_zero(const uint64_t a[4]);
+bool h_eq(const uint64_t a[4], const uint64_t b[4]);
+// Jacobian G1 on the host (final window fold / partial-sum fold only: O(10^2..10^3) operations per MSM)
+void h_g1_double(uint64_t o[12], const uint64_t p[12]);
+void h_g1_add(uint64_t o[12], const uint64_t p[12], const uint64_t q[12]);
+void h_g1_to_affine(uint64_t o[8], const uint64_t p[12]);
+
+}  // namespace zkhip

@@ -1,0 +1,19 @@
+// EvaluationDomain state (internal to libzkhip).
+#pragma once
+#include "common.h"
+#include "ntt.h"
+
+struct zkhip_domain {
+    zkhip_ctx* ctx = nullptr;
+    uint32_t k = 0, extended_k = 0, quotient_poly_degree = 0;
+    uint64_t omega[4], omega_inv[4], extended_omega[4], extended_omega_inv[4];
+    uint64_t g_coset[4], g_coset_inv[4], ifft_divisor[4], extended_ifft_divisor[4];
+    std::vector<uint64_t> t_evaluations;   // 2^(extended_k - k) inverted values, Montgomery limbs
+    void* d_t_evaluations = nullptr;
+    zkhip::NttPlan *plan_fwd = nullptr, *plan_inv = nullptr, *plan_ext_fwd = nullptr, *plan_ext_inv = nullptr;
+};
+
+namespace zkhip {
+// coeff (2^k per member, stride 2^k) -> extended coset (2^extended_k per member); tmp0/tmp1: batch * 2^extended_k each
+int domain_coeff_to_extended(zkhip_domain* dom, const fe* d_coeff, fe* d_out, size_t batch, fe* tmp0, fe* tmp1);
+}  // namespace zkhip

@@ -1,0 +1,247 @@
+// `poly::EvaluationDomain<Fr>` on the device: domain constants on the host (a few hundred field
+// operations), every per-element step as an NTT pass or a fused scaling.
+#include <cstring>
+#include "domain.h"
+
+using namespace zkhip;
+
+namespace zkhip {
+
+static void to_fe(fe& o, const uint64_t v[4]) { memcpy(o.l, v, 32); }
+
+int domain_coeff_to_extended(zkhip_domain* dom, const fe* d_coeff, fe* d_out, size_t batch, fe* tmp0, fe* tmp1) {
+    NttFuse fuse;
+    fuse.pre_mode = 1;
+    to_fe(fuse.pre[0], HFR.r);
+    to_fe(fuse.pre[1], dom->g_coset);
+    to_fe(fuse.pre[2], dom->g_coset_inv);
+    const size_t n = (size_t)1 << dom->k, en = (size_t)1 << dom->extended_k;
+    return ntt_run(dom->ctx, dom->plan_ext_fwd, d_coeff, n, (uint32_t)n, d_out, en, (uint32_t)en, batch, fuse, tmp0, tmp1);
+}
+
+}  // namespace zkhip
+
+extern "C" {
+
+int zkhip_internal_get_plan(zkhip_ctx* ctx, uint32_t log_n, const uint64_t omega[4], zkhip::NttPlan** out);
+
+int zkhip_domain_create(zkhip_ctx* ctx, uint32_t j, uint32_t k, zkhip_domain** out) {
+    if (!ctx || !out) return ZKHIP_ERR_INVALID;
+    *out = nullptr;
+    ZK_CHECK(ctx, j >= 2, "domain: constraint degree j=%u must be >= 2", j);
+    ZK_CHECK(ctx, k >= 1 && k <= 27, "domain: k=%u outside [1, 27]", k);
+    ZK_HIP(ctx, hipSetDevice(ctx->device));
+    auto dom = new zkhip_domain();
+    dom->ctx = ctx;
+    dom->k = k;
+    dom->quotient_poly_degree = j - 1;
+    const uint64_t n = 1ULL << k;
+    uint32_t ek = k;
+    while ((1ULL << ek) < n * (uint64_t)(j - 1)) ek++;
+    if (ek > FrParams::S) {
+        delete dom;
+        return set_error(ctx, ZKHIP_ERR_INVALID, "domain: extended_k=%u exceeds the field's 2-adicity 28", ek);
+    }
+    dom->extended_k = ek;
+    uint64_t w[4];
+    memcpy(w, FrParams::ROOT_OF_UNITY, 32);
+    for (uint32_t i = ek; i < FrParams::S; i++) h_mul(HFR, w, w, w);
+    memcpy(dom->extended_omega, w, 32);
+    h_inv(HFR, dom->extended_omega_inv, w);
+    for (uint32_t i = k; i < ek; i++) h_mul(HFR, w, w, w);
+    memcpy(dom->omega, w, 32);
+    h_inv(HFR, dom->omega_inv, w);
+    memcpy(dom->g_coset, FrParams::ZETA, 32);
+    h_mul(HFR, dom->g_coset_inv, dom->g_coset, dom->g_coset);
+    uint64_t t[4];
+    h_from_u64(HFR, t, n);
+    h_inv(HFR, dom->ifft_divisor, t);
+    h_from_u64(HFR, t, 1ULL << ek);
+    h_inv(HFR, dom->extended_ifft_divisor, t);
+    // t_evaluations[i] = 1 / ((zeta * extended_omega^i)^n - 1)
+    const size_t m = (size_t)1 << (ek - k);
+    dom->t_evaluations.resize(4 * m);
+    uint64_t cur[4];
+    memcpy(cur, dom->g_coset, 32);
+    for (size_t i = 0; i < m; i++) {
+        uint64_t v[4];
+        h_pow(HFR, v, cur, n);
+        h_sub(HFR, v, v, HFR.r);
+        h_inv(HFR, &dom->t_evaluations[4 * i], v);
+        h_mul(HFR, cur, cur, dom->extended_omega);
+    }
+    hipError_t e = hipMalloc(&dom->d_t_evaluations, m * 32);
+    if (e == hipSuccess) e = hipMemcpy(dom->d_t_evaluations, dom->t_evaluations.data(), m * 32, hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        delete dom;
+        return set_error(ctx, ZKHIP_ERR_HIP, "domain: t_evaluations upload failed: %s", hipGetErrorString(e));
+    }
+    int rc = zkhip_internal_get_plan(ctx, k, dom->omega, &dom->plan_fwd);
+    if (!rc) rc = zkhip_internal_get_plan(ctx, k, dom->omega_inv, &dom->plan_inv);
+    if (!rc) rc = zkhip_internal_get_plan(ctx, ek, dom->extended_omega, &dom->plan_ext_fwd);
+    if (!rc) rc = zkhip_internal_get_plan(ctx, ek, dom->extended_omega_inv, &dom->plan_ext_inv);
+    if (rc) {
+        zkhip_domain_destroy(dom);
+        return rc;
+    }
+    *out = dom;
+    return ZKHIP_OK;
+}
+
+void zkhip_domain_destroy(zkhip_domain* dom) {
+    if (!dom) return;
+    if (dom->d_t_evaluations) (void)hipFree(dom->d_t_evaluations);
+    delete dom;   // NTT plans are owned by the context
+}
+
+uint32_t zkhip_domain_k(const zkhip_domain* dom) { return dom ? dom->k : 0; }
+uint32_t zkhip_domain_extended_k(const zkhip_domain* dom) { return dom ? dom->extended_k : 0; }
+uint32_t zkhip_domain_quotient_poly_degree(const zkhip_domain* dom) { return dom ? dom->quotient_poly_degree : 0; }
+
+int zkhip_domain_constant(const zkhip_domain* dom, int which, uint64_t out[4]) {
+    if (!dom || !out || which < 0 || which > 7) return ZKHIP_ERR_INVALID;
+    const uint64_t* src[8] = {dom->omega, dom->omega_inv, dom->extended_omega, dom->extended_omega_inv,
+                              dom->g_coset, dom->g_coset_inv, dom->ifft_divisor, dom->extended_ifft_divisor};
+    memcpy(out, src[which], 32);
+    return ZKHIP_OK;
+}
+
+// ---- device-resident, batched ---------------------------------------------------------------------
+static int scratch2(zkhip_domain* dom, size_t batch, uint32_t log_n, fe** t0, fe** t1) {
+    const size_t N = (size_t)1 << log_n;
+    int rc = ensure_scratch(dom->ctx, 2 * batch * N * 32);
+    if (rc) return rc;
+    *t0 = (fe*)dom->ctx->scratch;
+    *t1 = *t0 + batch * N;
+    return ZKHIP_OK;
+}
+
+int zkhip_lagrange_to_coeff_dev(zkhip_domain* dom, uint64_t* d_a, size_t batch) {
+    if (!dom) return ZKHIP_ERR_INVALID;
+    zkhip_ctx* ctx = dom->ctx;
+    ZK_CHECK(ctx, d_a && batch >= 1, "lagrange_to_coeff: null pointer or empty batch");
+    ZK_HIP(ctx, hipSetDevice(ctx->device));
+    fe *t0, *t1;
+    int rc = scratch2(dom, batch, dom->k, &t0, &t1);
+    if (rc) return rc;
+    NttFuse fuse;
+    fuse.post_mode = 1;
+    memcpy(fuse.post[0].l, dom->ifft_divisor, 32);
+    const size_t n = (size_t)1 << dom->k;
+    return ntt_run(ctx, dom->plan_inv, (const fe*)d_a, n, (uint32_t)n, (fe*)d_a, n, (uint32_t)n, batch, fuse, t0, t1);
+}
+
+int zkhip_coeff_to_lagrange_dev(zkhip_domain* dom, uint64_t* d_a, size_t batch) {
+    if (!dom) return ZKHIP_ERR_INVALID;
+    zkhip_ctx* ctx = dom->ctx;
+    ZK_CHECK(ctx, d_a && batch >= 1, "coeff_to_lagrange: null pointer or empty batch");
+    ZK_HIP(ctx, hipSetDevice(ctx->device));
+    fe *t0, *t1;
+    int rc = scratch2(dom, batch, dom->k, &t0, &t1);
+    if (rc) return rc;
+    NttFuse fuse;
+    const size_t n = (size_t)1 << dom->k;
+    return ntt_run(ctx, dom->plan_fwd, (const fe*)d_a, n, (uint32_t)n, (fe*)d_a, n, (uint32_t)n, batch, fuse, t0, t1);
+}
+
+int zkhip_coeff_to_extended_dev(zkhip_domain* dom, const uint64_t* d_coeff, uint64_t* d_out, size_t batch) {
+    if (!dom) return ZKHIP_ERR_INVALID;
+    zkhip_ctx* ctx = dom->ctx;
+    ZK_CHECK(ctx, d_coeff && d_out && batch >= 1, "coeff_to_extended: null pointer or empty batch");
+    ZK_CHECK(ctx, (const void*)d_coeff != (const void*)d_out, "coeff_to_extended: in and out must differ");
+    ZK_HIP(ctx, hipSetDevice(ctx->device));
+    fe *t0, *t1;
+    int rc = scratch2(dom, batch, dom->extended_k, &t0, &t1);
+    if (rc) return rc;
+    return domain_coeff_to_extended(dom, (const fe*)d_coeff, (fe*)d_out, batch, t0, t1);
+}
+
+int zkhip_extended_to_coeff_dev(zkhip_domain* dom, uint64_t* d_ext, uint64_t* d_out, size_t batch) {
+    if (!dom) return ZKHIP_ERR_INVALID;
+    zkhip_ctx* ctx = dom->ctx;
+    ZK_CHECK(ctx, d_ext && d_out && batch >= 1, "extended_to_coeff: null pointer or empty batch");
+    ZK_CHECK(ctx, (const void*)d_ext != (const void*)d_out, "extended_to_coeff: in and out must differ");
+    ZK_HIP(ctx, hipSetDevice(ctx->device));
+    fe *t0, *t1;
+    int rc = scratch2(dom, batch, dom->extended_k, &t0, &t1);
+    if (rc) return rc;
+    NttFuse fuse;
+    fuse.post_mode = 2;   // x extended_ifft_divisor x [1, zeta^2, zeta][i % 3]
+    uint64_t c[4];
+    memcpy(fuse.post[0].l, dom->extended_ifft_divisor, 32);
+    h_mul(HFR, c, dom->extended_ifft_divisor, dom->g_coset_inv);
+    memcpy(fuse.post[1].l, c, 32);
+    h_mul(HFR, c, dom->extended_ifft_divisor, dom->g_coset);
+    memcpy(fuse.post[2].l, c, 32);
+    const size_t n = (size_t)1 << dom->k, en = (size_t)1 << dom->extended_k, no = n * dom->quotient_poly_degree;
+    return ntt_run(ctx, dom->plan_ext_inv, (const fe*)d_ext, en, (uint32_t)en, (fe*)d_out, no, (uint32_t)no, batch, fuse,
+                   t0, t1);
+}
+
+int zkhip_divide_by_vanishing_poly_dev(zkhip_domain* dom, uint64_t* d_ext, size_t batch) {
+    if (!dom) return ZKHIP_ERR_INVALID;
+    zkhip_ctx* ctx = dom->ctx;
+    ZK_CHECK(ctx, d_ext && batch >= 1, "divide_by_vanishing_poly: null pointer or empty batch");
+    ZK_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t en = (size_t)1 << dom->extended_k;
+    return scale_periodic(ctx, (fe*)d_ext, (const fe*)dom->d_t_evaluations, 1u << (dom->extended_k - dom->k), batch * en);
+}
+
+// ---- host variants: upload, run, download ---------------------------------------------------------
+static int host_roundtrip(zkhip_domain* dom, const uint64_t* in, size_t n_in, uint64_t* out, size_t n_out, int which) {
+    zkhip_ctx* ctx = dom->ctx;
+    ZK_CHECK(ctx, in && out, "null pointer");
+    ZK_HIP(ctx, hipSetDevice(ctx->device));
+    void *d_in = nullptr, *d_out = nullptr;
+    ZK_HIP(ctx, hipMalloc(&d_in, n_in * 32));
+    hipError_t e = hipSuccess;
+    const bool separate_out = (which == 2 || which == 3);
+    if (separate_out) e = hipMalloc(&d_out, n_out * 32);
+    int rc = ZKHIP_OK;
+    if (e == hipSuccess) e = hipMemcpyAsync(d_in, in, n_in * 32, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) {
+        switch (which) {
+            case 0: rc = zkhip_lagrange_to_coeff_dev(dom, (uint64_t*)d_in, 1); break;
+            case 1: rc = zkhip_coeff_to_lagrange_dev(dom, (uint64_t*)d_in, 1); break;
+            case 2: rc = zkhip_coeff_to_extended_dev(dom, (const uint64_t*)d_in, (uint64_t*)d_out, 1); break;
+            case 3: rc = zkhip_extended_to_coeff_dev(dom, (uint64_t*)d_in, (uint64_t*)d_out, 1); break;
+            default: rc = zkhip_divide_by_vanishing_poly_dev(dom, (uint64_t*)d_in, 1); break;
+        }
+        if (rc == ZKHIP_OK)
+            e = hipMemcpyAsync(out, separate_out ? d_out : d_in, n_out * 32, hipMemcpyDeviceToHost, ctx->stream);
+    }
+    hipError_t e2 = hipStreamSynchronize(ctx->stream);
+    (void)hipFree(d_in);
+    if (d_out) (void)hipFree(d_out);
+    if (rc) return rc;
+    if (e != hipSuccess) return set_error(ctx, ZKHIP_ERR_HIP, "domain op failed: %s", hipGetErrorString(e));
+    if (e2 != hipSuccess) return set_error(ctx, ZKHIP_ERR_HIP, "domain op failed: %s", hipGetErrorString(e2));
+    return ZKHIP_OK;
+}
+
+int zkhip_lagrange_to_coeff(zkhip_domain* dom, uint64_t* a) {
+    if (!dom) return ZKHIP_ERR_INVALID;
+    const size_t n = (size_t)1 << dom->k;
+    return host_roundtrip(dom, a, n, a, n, 0);
+}
+int zkhip_coeff_to_lagrange(zkhip_domain* dom, uint64_t* a) {
+    if (!dom) return ZKHIP_ERR_INVALID;
+    const size_t n = (size_t)1 << dom->k;
+    return host_roundtrip(dom, a, n, a, n, 1);
+}
+int zkhip_coeff_to_extended(zkhip_domain* dom, const uint64_t* coeff, uint64_t* out) {
+    if (!dom) return ZKHIP_ERR_INVALID;
+    return host_roundtrip(dom, coeff, (size_t)1 << dom->k, out, (size_t)1 << dom->extended_k, 2);
+}
+int zkhip_extended_to_coeff(zkhip_domain* dom, const uint64_t* ext, uint64_t* out) {
+    if (!dom) return ZKHIP_ERR_INVALID;
+    return host_roundtrip(dom, ext, (size_t)1 << dom->extended_k, out,
+                          ((size_t)1 << dom->k) * dom->quotient_poly_degree, 3);
+}
+int zkhip_divide_by_vanishing_poly(zkhip_domain* dom, uint64_t* ext) {
+    if (!dom) return ZKHIP_ERR_INVALID;
+    const size_t en = (size_t)1 << dom->extended_k;
+    return host_roundtrip(dom, ext, en, ext, en, 4);
+}
+
+}  // extern "C"

@@ -1,0 +1,30 @@
+// NTT plan / launcher interface (internal to libzkhip).
+#pragma once
+#include "common.h"
+
+namespace zkhip {
+
+struct NttPlan {
+    uint32_t log_n = 0;
+    uint64_t omega[4] = {0, 0, 0, 0};
+    uint32_t h = 0;              // low table holds omega^i for i < 2^h
+    void* d_lo = nullptr;
+    void* d_hi = nullptr;
+    std::vector<uint32_t> radix; // log2 radix of each pass
+    ~NttPlan();
+};
+
+struct NttFuse {
+    uint32_t pre_mode = 0;    // 1: input i multiplied by pre[i % 3]
+    uint32_t post_mode = 0;   // 1: output multiplied by post[0]; 2: output i multiplied by post[i % 3]
+    fe pre[3];
+    fe post[3];
+};
+
+int ntt_plan_create(zkhip_ctx* ctx, uint32_t log_n, const uint64_t omega[4], NttPlan** out);
+int ntt_run(zkhip_ctx* ctx, const NttPlan* plan, const fe* src, size_t src_stride, uint32_t n_in, fe* dst,
+            size_t dst_stride, uint32_t n_out, size_t batch, const NttFuse& fuse, fe* tmp0, fe* tmp1);
+int scale_periodic(zkhip_ctx* ctx, fe* a, const fe* d_scale, uint32_t period, size_t n);
+int ntt_init(zkhip_ctx* ctx);
+
+}  // namespace zkhip

@@ -1,0 +1,361 @@
+"""ctypes binding of libzkhip.so (include/zkhip.h).  Plumbing only: every computation is a HIP kernel.
+
+Field elements travel as numpy uint64 arrays whose last axis holds the 4 Montgomery limbs (8 for affine
+points, 12 for Jacobian), exactly the in-memory layout of `halo2curves::bn256::{Fr, G1Affine, G1}`.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libzkhip.so")
+_LIB = None
+
+EXPORTS = [
+    "zkhip_create", "zkhip_destroy", "zkhip_last_error", "zkhip_version", "zkhip_set_stream", "zkhip_sync",
+    "zkhip_dev_alloc", "zkhip_dev_free", "zkhip_upload", "zkhip_download",
+    "zkhip_field_binop", "zkhip_field_batch_invert", "zkhip_g1_add_affine", "zkhip_probe_mad_rate",
+    "zkhip_register_bases", "zkhip_release_bases", "zkhip_msm", "zkhip_msm_batch_dev", "zkhip_msm_range_dev",
+    "zkhip_g1_sum_jacobian", "zkhip_g1_to_affine",
+    "zkhip_ntt", "zkhip_ntt_dev",
+    "zkhip_domain_create", "zkhip_domain_destroy", "zkhip_domain_k", "zkhip_domain_extended_k",
+    "zkhip_domain_quotient_poly_degree", "zkhip_domain_constant",
+    "zkhip_lagrange_to_coeff", "zkhip_coeff_to_lagrange", "zkhip_coeff_to_extended", "zkhip_extended_to_coeff",
+    "zkhip_divide_by_vanishing_poly",
+    "zkhip_lagrange_to_coeff_dev", "zkhip_coeff_to_lagrange_dev", "zkhip_coeff_to_extended_dev",
+    "zkhip_extended_to_coeff_dev", "zkhip_divide_by_vanishing_poly_dev",
+    "zkhip_evaluate_h",
+    "zkhip_timing_enable", "zkhip_timing_reset", "zkhip_timing_get",
+]
+
+
+class ZkhipError(RuntimeError):
+    pass
+
+
+def lib():
+    """Loads libzkhip.so.  There is no fallback: a missing library is an error."""
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise ZkhipError(f"{LIB_PATH} is missing: build it with `python -m` __graft_entry__.build() "
+                             "(hipcc --offload-arch=gfx950); there is no CPU fallback")
+        _LIB = C.CDLL(LIB_PATH)
+        _LIB.zkhip_last_error.restype = C.c_char_p
+        _LIB.zkhip_version.restype = C.c_char_p
+        for name in ("zkhip_domain_k", "zkhip_domain_extended_k", "zkhip_domain_quotient_poly_degree"):
+            getattr(_LIB, name).restype = C.c_uint32
+        _LIB.zkhip_destroy.restype = None
+        _LIB.zkhip_domain_destroy.restype = None
+    return _LIB
+
+
+# ----------------------------------------------------------------------------- descriptor structs
+class Graph(C.Structure):
+    _fields_ = [("constants", C.c_void_p), ("num_constants", C.c_uint32),
+                ("rotations", C.c_void_p), ("num_rotations", C.c_uint32),
+                ("calc_words", C.c_void_p), ("num_calc_words", C.c_uint32),
+                ("num_calculations", C.c_uint32)]
+
+
+class Lookup(C.Structure):
+    _fields_ = [("graph", Graph), ("product", C.c_void_p), ("permuted_input", C.c_void_p),
+                ("permuted_table", C.c_void_p)]
+
+
+class EvalhDesc(C.Structure):
+    _fields_ = [("mem", C.c_uint32), ("poly_form", C.c_uint32),
+                ("num_fixed", C.c_uint32), ("num_advice", C.c_uint32), ("num_instance", C.c_uint32),
+                ("num_challenges", C.c_uint32),
+                ("fixed_cosets", C.POINTER(C.c_void_p)), ("advice", C.POINTER(C.c_void_p)),
+                ("instance", C.POINTER(C.c_void_p)), ("challenges", C.c_void_p),
+                ("y", C.c_uint64 * 4), ("beta", C.c_uint64 * 4), ("gamma", C.c_uint64 * 4), ("theta", C.c_uint64 * 4),
+                ("l0", C.c_void_p), ("l_last", C.c_void_p), ("l_active_row", C.c_void_p),
+                ("custom_gates", C.POINTER(Graph)),
+                ("num_lookups", C.c_uint32), ("lookups", C.POINTER(Lookup)),
+                ("num_perm_columns", C.c_uint32), ("perm_column_kind", C.c_void_p),
+                ("perm_column_index", C.c_void_p), ("perm_sigma_cosets", C.POINTER(C.c_void_p)),
+                ("num_perm_sets", C.c_uint32), ("perm_product_cosets", C.POINTER(C.c_void_p)),
+                ("perm_chunk_len", C.c_uint32), ("blinding_factors", C.c_uint32)]
+
+
+MEM_HOST, MEM_DEVICE = 0, 1
+FORM_COEFF, FORM_EXTENDED = 0, 1
+
+
+def _p(a):
+    return C.c_void_p(a.ctypes.data)
+
+
+def u64(a):
+    return np.ascontiguousarray(a, dtype=np.uint64)
+
+
+class DescBuilder:
+    """Builds a zkhip_evalh_desc from numpy / device pointers and keeps every referenced buffer alive."""
+
+    def __init__(self):
+        self.keep = []
+
+    def graph(self, g, to_mont) -> Graph:
+        """g: plonk.GraphEvaluator; to_mont: canonical int -> 4 Montgomery limbs."""
+        consts = np.array([to_mont(c) for c in g.constants], dtype=np.uint64).reshape(-1, 4)
+        rots = np.array(g.rotations, dtype=np.int32)
+        words = np.array(g.wire_words(), dtype=np.uint32)
+        self.keep += [consts, rots, words]
+        return Graph(_p(consts), len(g.constants), _p(rots) if len(rots) else None, len(rots),
+                     _p(words), len(words), len(g.calculations))
+
+    def ptr_array(self, ptrs):
+        arr = (C.c_void_p * max(len(ptrs), 1))(*[C.c_void_p(int(p)) for p in ptrs])
+        self.keep.append(arr)
+        return C.cast(arr, C.POINTER(C.c_void_p))
+
+    def host_ptrs(self, arrays):
+        arrays = [u64(a) for a in arrays]
+        self.keep += arrays
+        return self.ptr_array([a.ctypes.data for a in arrays])
+
+    def limbs(self, v4):
+        return (C.c_uint64 * 4)(*[int(x) for x in v4])
+
+
+# ----------------------------------------------------------------------------- context
+class Context:
+    def __init__(self, device: int = 0):
+        self._l = lib()
+        h = C.c_void_p()
+        rc = self._l.zkhip_create(C.c_int(device), C.byref(h))
+        if rc != 0:
+            raise ZkhipError(f"zkhip_create(device={device}) failed with status {rc}: no usable gfx950 device "
+                             "(there is no CPU fallback)")
+        self.h = h
+        self.device = device
+
+    def close(self):
+        if getattr(self, "h", None):
+            self._l.zkhip_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _ck(self, rc):
+        if rc != 0:
+            raise ZkhipError(f"status {rc}: {self._l.zkhip_last_error(self.h).decode()}")
+
+    # -- memory ---------------------------------------------------------------------------------
+    def set_stream(self, stream_handle):
+        self._ck(self._l.zkhip_set_stream(self.h, C.c_void_p(stream_handle)))
+
+    def sync(self):
+        self._ck(self._l.zkhip_sync(self.h))
+
+    def alloc(self, nbytes: int) -> int:
+        d = C.c_void_p()
+        self._ck(self._l.zkhip_dev_alloc(self.h, C.c_size_t(nbytes), C.byref(d)))
+        return d.value
+
+    def free(self, dptr: int):
+        self._ck(self._l.zkhip_dev_free(self.h, C.c_void_p(dptr)))
+
+    def upload(self, arr, dptr: int | None = None) -> int:
+        arr = u64(arr)
+        if dptr is None:
+            dptr = self.alloc(arr.nbytes)
+        self._ck(self._l.zkhip_upload(self.h, C.c_void_p(dptr), _p(arr), C.c_size_t(arr.nbytes)))
+        return dptr
+
+    def download(self, dptr: int, shape) -> np.ndarray:
+        out = np.empty(shape, dtype=np.uint64)
+        self._ck(self._l.zkhip_download(self.h, _p(out), C.c_void_p(dptr), C.c_size_t(out.nbytes)))
+        return out
+
+    # -- field / curve --------------------------------------------------------------------------
+    def field_binop(self, field: int, op: int, a, b):
+        a, b = u64(a), u64(b)
+        out = np.empty_like(a)
+        self._ck(self._l.zkhip_field_binop(self.h, C.c_int(field), C.c_int(op), _p(a), _p(b), _p(out),
+                                           C.c_size_t(a.size // 4)))
+        return out
+
+    def field_batch_invert(self, field: int, a):
+        a = u64(a)
+        out = np.empty_like(a)
+        self._ck(self._l.zkhip_field_batch_invert(self.h, C.c_int(field), _p(a), _p(out), C.c_size_t(a.size // 4)))
+        return out
+
+    def g1_add_affine(self, p, q):
+        p, q = u64(p), u64(q)
+        out = np.empty_like(p)
+        self._ck(self._l.zkhip_g1_add_affine(self.h, _p(p), _p(q), _p(out), C.c_size_t(p.size // 8)))
+        return out
+
+    def probe_mad_rate(self, iters=2048):
+        mads, muls = C.c_double(), C.c_double()
+        self._ck(self._l.zkhip_probe_mad_rate(self.h, C.c_int(iters), C.byref(mads), C.byref(muls)))
+        return mads.value, muls.value
+
+    # -- MSM ------------------------------------------------------------------------------------
+    def register_bases(self, affine_xy) -> int:
+        a = u64(affine_xy)
+        bid = C.c_uint32()
+        self._ck(self._l.zkhip_register_bases(self.h, _p(a), C.c_size_t(a.size // 8), C.byref(bid)))
+        return bid.value
+
+    def release_bases(self, bid: int):
+        self._ck(self._l.zkhip_release_bases(self.h, C.c_uint32(bid)))
+
+    def msm(self, bid: int, scalars):
+        """`best_multiexp(coeffs, bases[..n])` -> Jacobian limbs (12,)."""
+        s = u64(scalars)
+        out = np.zeros(12, dtype=np.uint64)
+        self._ck(self._l.zkhip_msm(self.h, C.c_uint32(bid), _p(s), C.c_size_t(s.size // 4), _p(out)))
+        return out
+
+    def msm_batch_dev(self, bid: int, d_scalars, n: int):
+        ptrs = (C.c_void_p * len(d_scalars))(*[C.c_void_p(int(p)) for p in d_scalars])
+        out = np.zeros((len(d_scalars), 12), dtype=np.uint64)
+        self._ck(self._l.zkhip_msm_batch_dev(self.h, C.c_uint32(bid), ptrs, C.c_size_t(len(d_scalars)),
+                                             C.c_size_t(n), _p(out)))
+        return out
+
+    def msm_range_dev(self, bid: int, first: int, d_scalars: int, n: int):
+        out = np.zeros(12, dtype=np.uint64)
+        self._ck(self._l.zkhip_msm_range_dev(self.h, C.c_uint32(bid), C.c_size_t(first), C.c_void_p(d_scalars),
+                                             C.c_size_t(n), _p(out)))
+        return out
+
+    def g1_sum_jacobian(self, jacs):
+        j = u64(jacs)
+        out = np.zeros(12, dtype=np.uint64)
+        self._ck(self._l.zkhip_g1_sum_jacobian(_p(j), C.c_size_t(j.size // 12), _p(out)))
+        return out
+
+    def g1_to_affine(self, jac):
+        j = u64(jac)
+        out = np.zeros(8, dtype=np.uint64)
+        self._ck(self._l.zkhip_g1_to_affine(_p(j), _p(out)))
+        return out
+
+    # -- NTT ------------------------------------------------------------------------------------
+    def ntt(self, a, log_n: int, omega):
+        """`best_fft(a, omega, log_n)`; returns the transformed copy."""
+        a = u64(a).copy()
+        om = u64(omega)
+        self._ck(self._l.zkhip_ntt(self.h, _p(a), C.c_uint32(log_n), _p(om)))
+        return a
+
+    def ntt_dev(self, d_a: int, log_n: int, omega, batch: int = 1):
+        om = u64(omega)
+        self._ck(self._l.zkhip_ntt_dev(self.h, C.c_void_p(d_a), C.c_uint32(log_n), _p(om), C.c_size_t(batch)))
+
+    # -- timing ---------------------------------------------------------------------------------
+    def timing_enable(self, on=True):
+        self._ck(self._l.zkhip_timing_enable(self.h, C.c_int(1 if on else 0)))
+
+    def timing_reset(self):
+        self._ck(self._l.zkhip_timing_reset(self.h))
+
+    def timing_get(self, family: str):
+        us, cnt = C.c_double(), C.c_uint64()
+        self._ck(self._l.zkhip_timing_get(self.h, family.encode(), C.byref(us), C.byref(cnt)))
+        return us.value, cnt.value
+
+
+class Domain:
+    """`EvaluationDomain::new(j, k)` on the device."""
+
+    def __init__(self, ctx: Context, j: int, k: int):
+        self.ctx = ctx
+        self._l = ctx._l
+        h = C.c_void_p()
+        ctx._ck(self._l.zkhip_domain_create(ctx.h, C.c_uint32(j), C.c_uint32(k), C.byref(h)))
+        self.h = h
+        self.k = self._l.zkhip_domain_k(h)
+        self.extended_k = self._l.zkhip_domain_extended_k(h)
+        self.quotient_poly_degree = self._l.zkhip_domain_quotient_poly_degree(h)
+        self.n = 1 << self.k
+        self.extended_len = 1 << self.extended_k
+
+    def close(self):
+        if getattr(self, "h", None) and getattr(self.ctx, "h", None):
+            self._l.zkhip_domain_destroy(self.h)
+        self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def constant(self, which: int):
+        out = np.zeros(4, dtype=np.uint64)
+        self.ctx._ck(self._l.zkhip_domain_constant(self.h, C.c_int(which), _p(out)))
+        return out
+
+    def lagrange_to_coeff(self, a):
+        a = u64(a).copy()
+        assert a.size // 4 == self.n
+        self.ctx._ck(self._l.zkhip_lagrange_to_coeff(self.h, _p(a)))
+        return a
+
+    def coeff_to_lagrange(self, a):
+        a = u64(a).copy()
+        assert a.size // 4 == self.n
+        self.ctx._ck(self._l.zkhip_coeff_to_lagrange(self.h, _p(a)))
+        return a
+
+    def coeff_to_extended(self, a):
+        a = u64(a)
+        assert a.size // 4 == self.n
+        out = np.empty((self.extended_len, 4), dtype=np.uint64)
+        self.ctx._ck(self._l.zkhip_coeff_to_extended(self.h, _p(a), _p(out)))
+        return out
+
+    def extended_to_coeff(self, a):
+        a = u64(a)
+        assert a.size // 4 == self.extended_len
+        out = np.empty((self.n * self.quotient_poly_degree, 4), dtype=np.uint64)
+        self.ctx._ck(self._l.zkhip_extended_to_coeff(self.h, _p(a), _p(out)))
+        return out
+
+    def divide_by_vanishing_poly(self, a):
+        a = u64(a).copy()
+        assert a.size // 4 == self.extended_len
+        self.ctx._ck(self._l.zkhip_divide_by_vanishing_poly(self.h, _p(a)))
+        return a
+
+    # device-resident, batched
+    def lagrange_to_coeff_dev(self, d_a: int, batch: int = 1):
+        self.ctx._ck(self._l.zkhip_lagrange_to_coeff_dev(self.h, C.c_void_p(d_a), C.c_size_t(batch)))
+
+    def coeff_to_lagrange_dev(self, d_a: int, batch: int = 1):
+        self.ctx._ck(self._l.zkhip_coeff_to_lagrange_dev(self.h, C.c_void_p(d_a), C.c_size_t(batch)))
+
+    def coeff_to_extended_dev(self, d_coeff: int, d_out: int, batch: int = 1):
+        self.ctx._ck(self._l.zkhip_coeff_to_extended_dev(self.h, C.c_void_p(d_coeff), C.c_void_p(d_out),
+                                                         C.c_size_t(batch)))
+
+    def extended_to_coeff_dev(self, d_ext: int, d_out: int, batch: int = 1):
+        self.ctx._ck(self._l.zkhip_extended_to_coeff_dev(self.h, C.c_void_p(d_ext), C.c_void_p(d_out),
+                                                         C.c_size_t(batch)))
+
+    def divide_by_vanishing_poly_dev(self, d_ext: int, batch: int = 1):
+        self.ctx._ck(self._l.zkhip_divide_by_vanishing_poly_dev(self.h, C.c_void_p(d_ext), C.c_size_t(batch)))
+
+    def evaluate_h(self, desc: EvalhDesc, out_dev: int | None = None):
+        """`Evaluator::evaluate_h`.  Host descriptor -> numpy result; device descriptor -> writes out_dev."""
+        if desc.mem == MEM_HOST:
+            out = np.empty((self.extended_len, 4), dtype=np.uint64)
+            self.ctx._ck(self._l.zkhip_evaluate_h(self.h, C.byref(desc), _p(out)))
+            return out
+        assert out_dev is not None
+        self.ctx._ck(self._l.zkhip_evaluate_h(self.h, C.byref(desc), C.c_void_p(out_dev)))
+        return None
