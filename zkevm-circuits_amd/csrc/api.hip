@@ -7,6 +7,8 @@
 using namespace zkhip;
 
 namespace zkhip {
+int msm_init(zkhip_ctx* ctx);
+void msm_drop_ctx(zkhip_ctx* ctx);
 
 int set_error(zkhip_ctx* ctx, int code, const char* fmt, ...) {
     char buf[512];
@@ -120,7 +122,7 @@ int zkhip_create(int device, zkhip_ctx** out) {
         return ZKHIP_ERR_HIP;
     }
     ctx->stream = ctx->own_stream;
-    if (ntt_init(ctx) != ZKHIP_OK) {
+    if (ntt_init(ctx) != ZKHIP_OK || msm_init(ctx) != ZKHIP_OK) {
         delete ctx;
         return ZKHIP_ERR_HIP;
     }
@@ -132,8 +134,7 @@ void zkhip_destroy(zkhip_ctx* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
-    for (auto& kv : ctx->bases)
-        if (kv.second.d_points) (void)hipFree(kv.second.d_points);
+    msm_drop_ctx(ctx);
     for (auto& kv : ctx->timers)
         for (auto& pr : kv.second.pending) {
             (void)hipEventDestroy(pr.first);

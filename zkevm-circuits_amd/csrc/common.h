@@ -12,11 +12,6 @@
 
 namespace zkhip {
 
-struct BaseSet {
-    void* d_points = nullptr;   // device copy of the affine bases (n x 64 B)
-    size_t n = 0;
-};
-
 struct NttPlan;
 
 struct TimingSlot {
@@ -32,7 +27,6 @@ struct zkhip_ctx {
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
     std::string last_error;
-    std::map<uint32_t, zkhip::BaseSet> bases;
     uint32_t next_bases_id = 1;
     // scratch arena reused across calls (grown on demand, never shrunk)
     void* scratch = nullptr;
