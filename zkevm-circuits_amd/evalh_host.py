@@ -1,0 +1,88 @@
+"""Host-side assembly of the `evaluate_h` call: ConstraintSystem + Evaluator + column data -> zkhip_evalh_desc.
+
+Mirrors what `plonk::prover::create_proof` hands to `Evaluator::evaluate_h` (pk cosets, advice / instance
+polynomials, challenges, y, beta, gamma, theta, lookup and permutation commitments-in-progress).
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import ffi
+from .plonk import ANY_ADVICE, ANY_FIXED, ANY_INSTANCE, FR_MODULUS, ConstraintSystem, Evaluator
+
+R256 = (1 << 256) % FR_MODULUS
+
+
+def fr_to_mont_limbs(v: int):
+    m = (v % FR_MODULUS) * R256 % FR_MODULUS
+    return [(m >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for i in range(4)]
+
+
+class EvalhCall:
+    """Column data for one evaluate_h call.
+
+    All arrays are numpy uint64 (len, 4) Montgomery limbs, or device pointers (ints) when mem == MEM_DEVICE.
+    fixed / l0 / l_last / l_active / perm_sigma / perm_z are extended cosets; advice / instance / lookup
+    polynomials are in `form` (coefficients of length 2^k, or extended cosets).
+    """
+
+    def __init__(self, cs: ConstraintSystem, ev: Evaluator | None = None):
+        self.cs = cs
+        self.ev = ev or Evaluator(cs)
+        self.fixed, self.advice, self.instance = [], [], []
+        self.challenges = np.zeros((0, 4), dtype=np.uint64)
+        self.y = self.beta = self.gamma = self.theta = None
+        self.l0 = self.l_last = self.l_active = None
+        self.lookups = []        # [(product, permuted_input, permuted_table)]
+        self.perm_sigma, self.perm_z = [], []
+
+    def build(self, mem=ffi.MEM_HOST, form=ffi.FORM_EXTENDED):
+        cs, ev = self.cs, self.ev
+        b = ffi.DescBuilder()
+        d = ffi.EvalhDesc()
+        d.mem, d.poly_form = mem, form
+        d.num_fixed, d.num_advice, d.num_instance = len(self.fixed), len(self.advice), len(self.instance)
+        d.num_challenges = len(self.challenges)
+
+        def ptrs(arrs):
+            return b.host_ptrs(arrs) if mem == ffi.MEM_HOST else b.ptr_array(arrs)
+
+        def ptr(a):
+            if mem == ffi.MEM_HOST:
+                a = ffi.u64(a)
+                b.keep.append(a)
+                return C.c_void_p(a.ctypes.data)
+            return C.c_void_p(int(a))
+
+        d.fixed_cosets, d.advice, d.instance = ptrs(self.fixed), ptrs(self.advice), ptrs(self.instance)
+        ch = ffi.u64(self.challenges)
+        b.keep.append(ch)
+        d.challenges = C.c_void_p(ch.ctypes.data) if len(ch) else None
+        d.y, d.beta, d.gamma, d.theta = (b.limbs(self.y), b.limbs(self.beta), b.limbs(self.gamma),
+                                         b.limbs(self.theta))
+        d.l0, d.l_last, d.l_active_row = ptr(self.l0), ptr(self.l_last), ptr(self.l_active)
+        gates = b.graph(ev.custom_gates, fr_to_mont_limbs)
+        b.keep.append(gates)
+        d.custom_gates = C.pointer(gates)
+        lk_arr = (ffi.Lookup * max(len(self.lookups), 1))()
+        for i, (g, (prod, pin, ptab)) in enumerate(zip(ev.lookups, self.lookups)):
+            lk_arr[i].graph = b.graph(g, fr_to_mont_limbs)
+            lk_arr[i].product, lk_arr[i].permuted_input, lk_arr[i].permuted_table = ptr(prod), ptr(pin), ptr(ptab)
+        b.keep.append(lk_arr)
+        d.num_lookups = len(self.lookups)
+        d.lookups = C.cast(lk_arr, C.POINTER(ffi.Lookup))
+        kinds = np.array([k for k, _ in cs.permutation_columns], dtype=np.uint32)
+        idxs = np.array([i for _, i in cs.permutation_columns], dtype=np.uint32)
+        b.keep += [kinds, idxs]
+        d.num_perm_columns = len(kinds) if self.perm_z else 0
+        d.perm_column_kind = C.c_void_p(kinds.ctypes.data) if len(kinds) else None
+        d.perm_column_index = C.c_void_p(idxs.ctypes.data) if len(idxs) else None
+        d.perm_sigma_cosets = ptrs(self.perm_sigma)
+        d.num_perm_sets = len(self.perm_z)
+        d.perm_product_cosets = ptrs(self.perm_z)
+        d.perm_chunk_len = cs.permutation_chunk_len()
+        d.blinding_factors = cs.blinding_factors()
+        self._keep = b
+        return d
