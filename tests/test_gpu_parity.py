@@ -1,0 +1,309 @@
+"""GPU suite: the HIP path, called through the C ABI, against the golden vectors, the C oracle on seeded inputs, and
+size-independent properties at the benchmark's full sizes.  Bit-exact everywhere (integer arithmetic)."""
+import numpy as np
+import pytest
+
+import bn254 as bn
+from util import (affine_arr, affine_pt, fq_arr, fq_ints, fr_arr, fr_ints, golden, hex_fr, hex_pt, rand_fr,
+                  witness_like)
+
+from zkevm_circuits_amd import evalh_host, ffi, plonk, synthetic
+import zkevm_circuits_amd as zk
+
+pytestmark = pytest.mark.gpu
+P = bn.FR_MODULUS
+
+
+# ------------------------------------------------------------------------------------------------ field / curve
+@pytest.mark.parametrize("fname,fid", [("fr", 0), ("fq", 1)])
+def test_field_golden_and_random(ctx, co, fname, fid):
+    g = golden("field.json")["fields"][fname]
+    to_arr = fr_arr if fid == 0 else fq_arr
+    to_int = fr_ints if fid == 0 else fq_ints
+    a = to_arr([int(c["a"], 16) for c in g["cases"]])
+    b = to_arr([int(c["b"], 16) for c in g["cases"]])
+    for op, key in ((0, "add"), (1, "sub"), (2, "mul")):
+        assert to_int(ctx.field_binop(fid, op, a, b)) == [int(c[key], 16) for c in g["cases"]], key
+    assert to_int(ctx.field_batch_invert(fid, a)) == [int(c["inv"], 16) for c in g["cases"]]
+    rng = np.random.default_rng(1)
+    x, y = rand_fr(rng, 20000), rand_fr(rng, 20000)
+    for op in (0, 1, 2):
+        assert np.array_equal(ctx.field_binop(fid, op, x, y), co.field_binop(fid, op, x, y))
+    assert np.array_equal(ctx.field_binop(fid, 3, x, y), co.field_binop(fid, 2, co.field_binop(fid, 2, x, x), y))
+    assert np.array_equal(ctx.field_binop(fid, 2, np.zeros((0, 4), np.uint64), np.zeros((0, 4), np.uint64)),
+                          np.zeros((0, 4), np.uint64))
+
+
+def test_poseidon_kat_through_device_fr(ctx):
+    """The reference's Poseidon known answer (/root/reference/poseidon/src/hash.rs:903-918) recomputed with every
+    field operation running on the device."""
+    k = golden("reference_kats.json")
+    rounds = [[int(c, 16) for c in r] for r in k["poseidon_params"]["round_constants"]]
+    mds = [[fr_arr([int(c, 16)]) for c in r] for r in k["poseidon_params"]["mds"]]
+    kat = k["poseidon_hash_with_domain"][0]
+    st = fr_arr([int(kat["domain"], 16)] + [int(x, 16) for x in kat["inputs"]])
+    mul = lambda x, y: ctx.field_binop(0, 2, x, y)   # noqa: E731
+    add = lambda x, y: ctx.field_binop(0, 0, x, y)   # noqa: E731
+    for rnd, rcs in enumerate(rounds):
+        st = add(st, fr_arr(rcs))
+        ns = 3 if (rnd < 4 or rnd >= 61) else 1
+        x = st[:ns]
+        x2 = mul(x, x)
+        st = np.concatenate([mul(mul(x2, x2), x), st[ns:]])
+        st = np.array([add(add(mul(mds[i][0], st[0:1]), mul(mds[i][1], st[1:2])), mul(mds[i][2], st[2:3]))[0]
+                       for i in range(3)], dtype=np.uint64)
+    assert fr_ints(st)[0] == int(kat["expected"], 16)
+
+
+def test_curve_add_golden(ctx, co):
+    g = golden("curve.json")
+    p = affine_arr([hex_pt(c["p"]) for c in g["add"]])
+    q = affine_arr([hex_pt(c["q"]) for c in g["add"]])
+    assert [affine_pt(r) for r in ctx.g1_add_affine(p, q)] == [hex_pt(c["sum"]) for c in g["add"]]
+    bases = co.g1_bases(3000)
+    assert np.array_equal(ctx.g1_add_affine(bases[:1500], bases[1500:]), co.g1_add_affine(bases[:1500], bases[1500:]))
+
+
+# ------------------------------------------------------------------------------------------------ MSM
+def test_msm_golden(ctx, co):
+    g = golden("msm.json")
+    bids = {}
+    for case in g["cases"]:
+        n = case["n"]
+        if n not in bids:
+            bids[n] = ctx.register_bases(co.g1_bases(n))
+        jac = ctx.msm(bids[n], hex_fr(case["scalars"]))
+        assert affine_pt(ctx.g1_to_affine(jac)) == hex_pt(case["result"]), (n, case["dist"])
+    for b in bids.values():
+        ctx.release_bases(b)
+
+
+@pytest.mark.parametrize("n", [1, 3, 1000, 4097, 1 << 14, (1 << 16) + 11])
+def test_msm_vs_oracle(ctx, co, n):
+    rng = np.random.default_rng(n)
+    bases = co.g1_bases(n)
+    bid = ctx.register_bases(bases)
+    dists = {"uniform": rand_fr(rng, n), "witness": witness_like(rng, n, lambda c: co.from_canonical(0, c)),
+             "ones": fr_arr([1] * min(n, 4097)) if n <= 4097 else None,
+             "zeros": np.zeros((n, 4), dtype=np.uint64)}
+    for name, sc in dists.items():
+        if sc is None:
+            continue
+        m = len(sc)
+        got = ctx.g1_to_affine(ctx.msm(bid, sc))
+        exp = co.g1_to_affine(co.best_multiexp(sc, bases[:m], threads=8))
+        assert np.array_equal(got, exp), (n, name)
+    # empty input and a prefix of the registered bases
+    assert not ctx.msm(bid, np.zeros((0, 4), np.uint64)).any()
+    if n > 3:
+        sc = rand_fr(rng, n // 2)
+        assert np.array_equal(ctx.g1_to_affine(ctx.msm(bid, sc)),
+                              co.g1_to_affine(co.best_multiexp(sc, bases[:n // 2], threads=8)))
+    ctx.release_bases(bid)
+
+
+def test_msm_base_range_split_and_fold(ctx, co):
+    n = 5000
+    rng = np.random.default_rng(2)
+    bases, sc = co.g1_bases(n), rand_fr(rng, n)
+    bid = ctx.register_bases(bases)
+    d_sc = ctx.upload(sc)
+    whole = ctx.g1_to_affine(ctx.msm(bid, sc))
+    from zkevm_circuits_amd import sharding
+    parts = []
+    for r in range(3):
+        first, cnt = sharding.base_range_for_rank(n, r, 3)
+        parts.append(ctx.msm_range_dev(bid, first, d_sc + first * 32, cnt))
+    assert np.array_equal(ctx.g1_to_affine(ctx.g1_sum_jacobian(np.stack(parts))), whole)
+    batch = ctx.msm_batch_dev(bid, [d_sc, d_sc], n)
+    assert np.array_equal(ctx.g1_to_affine(batch[0]), whole) and np.array_equal(ctx.g1_to_affine(batch[1]), whole)
+    ctx.free(d_sc)
+    ctx.release_bases(bid)
+
+
+def test_msm_full_size_known_answer(ctx, co):
+    """n = 2^19 with bases (i+1)G: sum_i s_i (i+1) G = (sum_i s_i (i+1) mod r) G, checked with one scalar
+    multiplication instead of a CPU MSM; uniform and witness-like scalars."""
+    n = 1 << 19
+    rng = np.random.default_rng(20250523)
+    bases = co.g1_bases(n)
+    bid = ctx.register_bases(bases)
+    for name in ("uniform", "witness"):
+        sc = rand_fr(rng, n) if name == "uniform" else witness_like(rng, n, lambda c: co.from_canonical(0, c))
+        canon = co.to_canonical(0, sc)
+        k = 0
+        vals = [sum(int(x) << (64 * j) for j, x in enumerate(row)) for row in canon]
+        k = sum(v * (i + 1) for i, v in enumerate(vals)) % P
+        exp = bn.g1_mul(bn.G1_GENERATOR, k)
+        got = affine_pt(ctx.g1_to_affine(ctx.msm(bid, sc)))
+        assert got == exp, name
+    ctx.release_bases(bid)
+
+
+# ------------------------------------------------------------------------------------------------ NTT / domain
+def test_ntt_golden(ctx):
+    for case in golden("ntt.json")["cases"]:
+        out = ctx.ntt(hex_fr(case["input"]), case["log_n"], fr_arr([int(case["omega"], 16)])[0])
+        assert np.array_equal(out, hex_fr(case["output"])), case["log_n"]
+
+
+@pytest.mark.parametrize("log_n", [1, 4, 8, 9, 11, 13, 16, 17, 18])
+def test_ntt_vs_oracle(ctx, co, log_n):
+    rng = np.random.default_rng(log_n)
+    omega = fr_arr([pow(bn.FR_ROOT_OF_UNITY, 1 << (28 - log_n), P)])[0]
+    a = rand_fr(rng, 1 << log_n)
+    assert np.array_equal(ctx.ntt(a, log_n, omega), co.best_fft(a, omega, log_n, threads=8))
+
+
+def test_ntt_rejects_bad_omega(ctx):
+    with pytest.raises(zk.ZkhipError):
+        ctx.ntt(np.zeros((8, 4), np.uint64), 3, fr_arr([5])[0])
+
+
+def test_domain_golden(ctx):
+    for case in golden("domain.json")["cases"]:
+        d = zk.Domain(ctx, case["j"], case["k"])
+        assert d.extended_k == case["extended_k"]
+        assert fr_ints(d.constant(0)) == [int(case["omega"], 16)]
+        assert fr_ints(d.constant(2)) == [int(case["extended_omega"], 16)]
+        coeff = hex_fr(case["coeff"])
+        assert np.array_equal(d.coeff_to_lagrange(coeff), hex_fr(case["lagrange"]))
+        assert np.array_equal(d.lagrange_to_coeff(hex_fr(case["lagrange"])), coeff)
+        assert np.array_equal(d.coeff_to_extended(coeff), hex_fr(case["extended"]))
+        assert np.array_equal(d.extended_to_coeff(hex_fr(case["big_extended"])), hex_fr(case["big_coeff"]))
+        assert np.array_equal(d.divide_by_vanishing_poly(hex_fr(case["big_extended"])), hex_fr(case["big_divided"]))
+        d.close()
+
+
+@pytest.mark.parametrize("j,k", [(5, 12), (9, 11), (3, 13), (4, 10)])
+def test_domain_vs_oracle_batched(ctx, co, j, k):
+    rng = np.random.default_rng(j * 100 + k)
+    d, od = zk.Domain(ctx, j, k), co.Domain(j, k, threads=8)
+    n, en = d.n, d.extended_len
+    batch = 3
+    cols = [rand_fr(rng, n) for _ in range(batch)]
+    d_in = ctx.upload(np.concatenate(cols))
+    d_ext = ctx.alloc(batch * en * 32)
+    d.coeff_to_extended_dev(d_in, d_ext, batch)
+    ext = ctx.download(d_ext, (batch, en, 4))
+    for b in range(batch):
+        assert np.array_equal(ext[b], od.coeff_to_extended(cols[b]))
+    d.divide_by_vanishing_poly_dev(d_ext, batch)
+    div = ctx.download(d_ext, (batch, en, 4))
+    for b in range(batch):
+        assert np.array_equal(div[b], od.divide_by_vanishing_poly(ext[b]))
+    d_co = ctx.alloc(batch * n * d.quotient_poly_degree * 32)
+    d.extended_to_coeff_dev(d_ext, d_co, batch)
+    back = ctx.download(d_co, (batch, n * d.quotient_poly_degree, 4))
+    for b in range(batch):
+        assert np.array_equal(back[b], od.extended_to_coeff(div[b]))
+    d.lagrange_to_coeff_dev(d_in, batch)
+    l2c = ctx.download(d_in, (batch, n, 4))
+    for b in range(batch):
+        assert np.array_equal(l2c[b], od.lagrange_to_coeff(cols[b]))
+    d.coeff_to_lagrange_dev(d_in, batch)
+    assert np.array_equal(ctx.download(d_in, (batch, n, 4)), np.stack(cols))      # round trip
+    for p in (d_in, d_ext, d_co):
+        ctx.free(p)
+
+
+@pytest.mark.parametrize("ext_k", [21, 22])
+def test_coset_extension_full_size_properties(ctx, co, ext_k):
+    """k = 19 -> 2^21 / 2^22: (a) a few outputs against direct evaluation p(zeta * w^i) by Horner on big ints,
+    (b) extended_to_coeff inverts coeff_to_extended, (c) linearity."""
+    k = 19
+    j = 5 if ext_k == 21 else 9
+    d = zk.Domain(ctx, j, k)
+    assert d.extended_k == ext_k
+    rng = np.random.default_rng(ext_k)
+    n, en = d.n, d.extended_len
+    a, b = rand_fr(rng, n), rand_fr(rng, n)
+    d_a, d_b = ctx.upload(a), ctx.upload(b)
+    d_ea, d_eb = ctx.alloc(en * 32), ctx.alloc(en * 32)
+    d.coeff_to_extended_dev(d_a, d_ea)
+    d.coeff_to_extended_dev(d_b, d_eb)
+    ea, eb = ctx.download(d_ea, (en, 4)), ctx.download(d_eb, (en, 4))
+    coeffs = fr_ints(a)
+    w = fr_ints(d.constant(2))[0]
+    for i in (0, 1, en // 3 + 5, en - 1):
+        x = bn.FR_ZETA * pow(w, i, P) % P
+        acc = 0
+        for c in reversed(coeffs):
+            acc = (acc * x + c) % P
+        assert fr_ints(ea[i])[0] == acc, i
+    d_s = ctx.upload(co.field_binop(0, 0, a, b))
+    d_es = ctx.alloc(en * 32)
+    d.coeff_to_extended_dev(d_s, d_es)
+    assert np.array_equal(ctx.download(d_es, (en, 4)), ctx.field_binop(0, 0, ea, eb))
+    d_back = ctx.alloc(n * d.quotient_poly_degree * 32)
+    d.extended_to_coeff_dev(d_ea, d_back)
+    back = ctx.download(d_back, (n * d.quotient_poly_degree, 4))
+    assert np.array_equal(back[:n], a) and not back[n:].any()
+    for p in (d_a, d_b, d_ea, d_eb, d_s, d_es, d_back):
+        ctx.free(p)
+    d.close()
+
+
+# ------------------------------------------------------------------------------------------------ evaluate_h
+def test_evaluate_h_golden(ctx):
+    from evalh_cases import build_call
+    for case in golden("evalh.json")["cases"]:
+        cs, call = build_call(case)
+        d = zk.Domain(ctx, cs.degree(), case["k"])
+        out = d.evaluate_h(call.build(ffi.MEM_HOST, ffi.FORM_EXTENDED))
+        assert np.array_equal(out, hex_fr(case["h"])), case["cs"]
+        d.close()
+
+
+def _random_call(cs, rng, n, en, od):
+    call = evalh_host.EvalhCall(cs)
+    call.fixed = [rand_fr(rng, en) for _ in range(cs.num_fixed_columns)]
+    coeff = {"advice": [rand_fr(rng, n) for _ in range(cs.num_advice_columns)],
+             "instance": [rand_fr(rng, n) for _ in range(cs.num_instance_columns)],
+             "lookups": [tuple(rand_fr(rng, n) for _ in range(3)) for _ in cs.lookups]}
+    call.challenges = rand_fr(rng, cs.num_challenges)
+    call.y, call.beta, call.gamma, call.theta = (rand_fr(rng, 1)[0] for _ in range(4))
+    call.l0, call.l_last, call.l_active = rand_fr(rng, en), rand_fr(rng, en), rand_fr(rng, en)
+    call.perm_sigma = [rand_fr(rng, en) for _ in cs.permutation_columns]
+    call.perm_z = [rand_fr(rng, en) for _ in range(cs.num_permutation_sets())]
+    ext = {"advice": [od.coeff_to_extended(a) for a in coeff["advice"]],
+           "instance": [od.coeff_to_extended(a) for a in coeff["instance"]],
+           "lookups": [tuple(od.coeff_to_extended(p) for p in t) for t in coeff["lookups"]]}
+    return call, coeff, ext
+
+
+@pytest.mark.parametrize("k,kw", [
+    (7, dict()),
+    (9, dict(num_advice=12, num_gate_polys=40, num_lookups=3, num_perm_cols=7)),
+    (11, dict(num_advice=24, num_fixed=6, num_gate_polys=160, num_lookups=4, num_perm_cols=9,
+              rotations=(-5, -2, -1, 0, 1, 3))),
+    (10, dict(num_advice=40, num_fixed=8, num_gate_polys=300, max_degree=9, num_lookups=2, num_perm_cols=11)),
+    (8, dict(num_lookups=0, num_perm_cols=0)),
+])
+def test_evaluate_h_vs_oracle(ctx, co, k, kw):
+    cs = synthetic.synthetic_cs(**kw)
+    d, od = zk.Domain(ctx, cs.degree(), k), co.Domain(cs.degree(), k, threads=8)
+    rng = np.random.default_rng(k)
+    call, coeff, ext = _random_call(cs, rng, d.n, d.extended_len, od)
+    call.advice, call.instance, call.lookups = ext["advice"], ext["instance"], ext["lookups"]
+    desc = call.build(ffi.MEM_HOST, ffi.FORM_EXTENDED)
+    exp = od.evaluate_h(desc)
+    assert np.array_equal(d.evaluate_h(desc), exp)
+    # upstream's calling convention: advice / instance / lookup polynomials in coefficient form
+    call.advice, call.instance, call.lookups = coeff["advice"], coeff["instance"], coeff["lookups"]
+    assert np.array_equal(d.evaluate_h(call.build(ffi.MEM_HOST, ffi.FORM_COEFF)), exp)
+    # quotient tail: divide by the vanishing polynomial, back to coefficients
+    assert np.array_equal(d.extended_to_coeff(d.divide_by_vanishing_poly(exp)),
+                          od.extended_to_coeff(od.divide_by_vanishing_poly(exp)))
+    d.close()
+
+
+def test_evaluate_h_rejects_malformed_graph(ctx):
+    cs = synthetic.synthetic_cs(num_lookups=0, num_perm_cols=0)
+    d = zk.Domain(ctx, cs.degree(), 6)
+    rng = np.random.default_rng(0)
+    call, coeff, ext = _random_call(cs, rng, d.n, d.extended_len, type("O", (), {"coeff_to_extended": lambda s, a: np.zeros((d.extended_len, 4), np.uint64)})())
+    call.advice, call.instance = ext["advice"][:-1], ext["instance"]      # one advice column short
+    with pytest.raises(zk.ZkhipError):
+        d.evaluate_h(call.build(ffi.MEM_HOST, ffi.FORM_EXTENDED))
+    d.close()

@@ -1,0 +1,124 @@
+"""CPU suite, part 2: host logic — Expression -> GraphEvaluator lowering, ConstraintSystem quantities, the wire
+format, and the multi-GPU partition helpers."""
+import random
+
+import numpy as np
+
+import bn254 as bn
+import halo2_model as hm
+from zkevm_circuits_amd import plonk, sharding, synthetic
+
+P = bn.FR_MODULUS
+
+
+def _direct(e, cols, ch, idx, rs, size):
+    t = e[0]
+    if t == "const":
+        return e[1]
+    if t in ("fixed", "advice", "instance"):
+        return cols[t][e[1]][(idx + e[2] * rs) % size]
+    if t == "challenge":
+        return ch[e[1]]
+    if t == "neg":
+        return (-_direct(e[1], cols, ch, idx, rs, size)) % P
+    if t == "sum":
+        return (_direct(e[1], cols, ch, idx, rs, size) + _direct(e[2], cols, ch, idx, rs, size)) % P
+    if t == "prod":
+        return _direct(e[1], cols, ch, idx, rs, size) * _direct(e[2], cols, ch, idx, rs, size) % P
+    return _direct(e[1], cols, ch, idx, rs, size) * e[2] % P
+
+
+def test_add_expression_matches_direct_evaluation():
+    rnd = random.Random(3)
+    cs = synthetic.synthetic_cs(num_advice=5, num_fixed=3, num_gate_polys=24, seed=9)
+    size, rs = 64, 4
+    cols = {k: [[rnd.randrange(P) for _ in range(size)] for _ in range(n)]
+            for k, n in (("fixed", 3), ("advice", 5), ("instance", 1))}
+    ch = [rnd.randrange(P)]
+    inp = hm.EvalInputs(cols["fixed"], cols["advice"], cols["instance"], ch, 11, 13, 17, 19)
+    for gate in cs.gates:
+        for poly in gate:
+            g = plonk.GraphEvaluator()
+            g.add_expression(poly)
+            prog = g.to_model()
+            for idx in (0, 1, 17, 63):
+                assert hm.graph_evaluate(prog, inp, 0, idx, rs, size) == _direct(poly, cols, ch, idx, rs, size)
+
+
+def test_constant_folding_rules():
+    g = plonk.GraphEvaluator()
+    A = plonk.Advice
+    assert g.add_expression(plonk.Product(plonk.Constant(0), A(0))) == (plonk.VS_CONSTANT, 0, 0)
+    one_times = g.add_expression(plonk.Product(plonk.Constant(1), A(0)))
+    assert one_times == g.add_expression(A(0))                      # 1 * a = a, and Store is de-duplicated
+    dbl = g.add_expression(plonk.Product(plonk.Constant(2), A(0)))
+    assert g.calculations[dbl[1]][0] == plonk.OP_DOUBLE
+    sq = g.add_expression(plonk.Product(A(0), A(0)))
+    assert g.calculations[sq[1]][0] == plonk.OP_SQUARE
+    sub = g.add_expression(plonk.Sub(A(0), A(1)))
+    assert g.calculations[sub[1]][0] == plonk.OP_SUB
+    n = len(g.calculations)
+    g.add_expression(plonk.Sub(A(0), A(1)))                          # common sub-expression: nothing new
+    assert len(g.calculations) == n
+    assert g.add_expression(plonk.Scaled(A(0), 0)) == (plonk.VS_CONSTANT, 0, 0)
+    assert g.add_expression(plonk.Neg(plonk.Constant(5))) == (plonk.VS_CONSTANT, g.constants.index(P - 5), 0)
+
+
+def test_constraint_system_quantities():
+    cs = synthetic.synthetic_cs()
+    assert cs.degree() == 5                    # max gate degree 5; lookups need max(4, 2 + 1 + 1) = 4
+    assert cs.permutation_chunk_len() == 3
+    assert cs.num_permutation_sets() == 2
+    assert cs.blinding_factors() >= 5 and cs.minimum_rows() == cs.blinding_factors() + 3
+    lk = plonk.Lookup([plonk.Product(plonk.Advice(0), plonk.Product(plonk.Advice(1), plonk.Advice(2)))], [plonk.Fixed(0)])
+    assert lk.required_degree() == 2 + 3 + 1
+    # the reference's core lookups: degree-5 condition * degree-1 entry against a degree-1 table -> degree 9 -> e = 3
+    cond = plonk.Advice(0)
+    for i in range(4):
+        cond = plonk.Product(cond, plonk.Advice(i + 1))
+    assert plonk.Lookup([plonk.Product(cond, plonk.Advice(6))], [plonk.Advice(7)]).required_degree() == 9
+    assert hm.EvaluationDomain(9, 19).extended_k == 22
+
+
+def test_wire_format_roundtrip():
+    cs = synthetic.synthetic_cs(num_gate_polys=8)
+    ev = plonk.Evaluator(cs)
+    words = ev.custom_gates.wire_words()
+    # re-parse the stream and compare with the calculation list
+    pos, parsed = 0, []
+    while pos < len(words):
+        op = words[pos]
+        pos += 1
+        if op == plonk.OP_HORNER:
+            start, factor, npart = tuple(words[pos:pos + 3]), tuple(words[pos + 3:pos + 6]), words[pos + 6]
+            pos += 7
+            parts = tuple(tuple(words[pos + 3 * i:pos + 3 * i + 3]) for i in range(npart))
+            pos += 3 * npart
+            parsed.append((op, start, parts, factor))
+        else:
+            nsrc = 2 if op in (plonk.OP_ADD, plonk.OP_SUB, plonk.OP_MUL) else 1
+            parsed.append((op,) + tuple(tuple(words[pos + 3 * i:pos + 3 * i + 3]) for i in range(nsrc)))
+            pos += 3 * nsrc
+    assert parsed == [tuple(c) for c in ev.custom_gates.calculations]
+    last = ev.custom_gates.calculations[-1]
+    assert last[0] == plonk.OP_HORNER and last[1] == (plonk.VS_PREVIOUS, 0, 0) and last[3] == (plonk.VS_Y, 0, 0)
+    assert len(ev.lookups) == len(cs.lookups)
+    assert ev.lookups[0].calculations[-1][0] == plonk.OP_MUL
+
+
+def test_partition_helpers():
+    for n, world in ((10, 1), (10, 3), (7, 8), (524288, 8), (5, 2)):
+        cover = []
+        for r in range(world):
+            first, count = sharding.base_range_for_rank(n, r, world)
+            cover += list(range(first, first + count))
+        assert cover == list(range(n))
+        cols = sorted(c for r in range(world) for c in sharding.columns_for_rank(n if n < 100 else 97, r, world))
+        assert cols == list(range(n if n < 100 else 97))
+    assert sharding.cosets_for_rank(21, 19, 1, 2) == [1, 3]
+    assert sorted(sum((sharding.cosets_for_rank(22, 19, r, 8) for r in range(8)), [])) == list(range(8))
+    # coset partition is rotation-closed: (idx + rot * 2^e) mod 2^ext_k stays in idx's coset
+    e, ek = 2, 8
+    for idx in range(1 << ek):
+        for rot in (-5, -1, 1, 3):
+            assert ((idx + rot * (1 << e)) % (1 << ek)) % (1 << e) == idx % (1 << e)

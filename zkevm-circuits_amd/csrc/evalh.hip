@@ -81,6 +81,7 @@ __global__ void __launch_bounds__(EV_THREADS) evalh_interp_kernel(const InterpAr
     fe* lds = reinterpret_cast<fe*>(smem);
     const uint32_t idx = blockIdx.x * EV_THREADS + threadIdx.x;
     const uint32_t mask = (1u << a.log_size) - 1;
+    if (idx > mask) return;   // domains smaller than one workgroup
     const fe prev = load_fe(a.out + idx);
     const fe pv = (a.mode == 0) ? prev : Fr::zero();   // `previous_value` of GraphEvaluator::evaluate
     fe acc = pv;
@@ -156,6 +157,7 @@ struct PermArgs {
 __global__ void __launch_bounds__(EV_THREADS) evalh_perm_kernel(const PermArgs a) {
     const uint32_t idx = blockIdx.x * EV_THREADS + threadIdx.x;
     const uint32_t mask = (1u << a.log_size) - 1;
+    if (idx > mask) return;
     const fe y = load_fe(a.scalars + SC_Y), beta = load_fe(a.scalars + SC_BETA), gamma = load_fe(a.scalars + SC_GAMMA);
     const fe l0 = load_fe(a.l0 + idx), l_last = load_fe(a.l_last + idx), l_active = load_fe(a.l_active + idx);
     const uint32_t r_next = rot_row(idx, 1, a.rot_scale, mask), r_last = rot_row(idx, a.last_rot, a.rot_scale, mask);
@@ -517,7 +519,6 @@ extern "C" int zkhip_evaluate_h(zkhip_domain* dom, const zkhip_evalh_desc* desc,
     ZK_HIP(ctx, hipSetDevice(ctx->device));
     const uint32_t ek = dom->extended_k, k = dom->k;
     const size_t size = (size_t)1 << ek, n = (size_t)1 << k;
-    ZK_CHECK(ctx, size >= (size_t)EV_THREADS, "evaluate_h: extended domain smaller than %d rows", EV_THREADS);
     const bool host = desc->mem == ZKHIP_MEM_HOST;
     const bool coeff = desc->poly_form == ZKHIP_FORM_COEFF;
     Arena ar{ctx, {}};
@@ -596,7 +597,7 @@ extern "C" int zkhip_evaluate_h(zkhip_domain* dom, const zkhip_evalh_desc* desc,
 
     const uint32_t lds_slots = 16;
     const size_t lds_bytes = (size_t)lds_slots * EV_THREADS * sizeof(fe);
-    const dim3 grid((unsigned)(size / EV_THREADS));
+    const dim3 grid((unsigned)((size + EV_THREADS - 1) / EV_THREADS));
     ZK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(evalh_interp_kernel),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
 
