@@ -62,6 +62,8 @@ int zkhip_field_binop(zkhip_ctx* ctx, int field, int op, const uint64_t* a, cons
 int zkhip_field_batch_invert(zkhip_ctx* ctx, int field, const uint64_t* a, uint64_t* out, size_t n);
 /* out[i] = affine(P[i] + Q[i]) for affine inputs — exercises the device G1 group law on its own. */
 int zkhip_g1_add_affine(zkhip_ctx* ctx, const uint64_t* p_xy, const uint64_t* q_xy, uint64_t* out_xy, size_t n);
+/* out[i] = affine((first + i) * P): synthetic SRS ([1]G, [2]G, ...) for benchmarks and tests. */
+int zkhip_g1_multiples(zkhip_ctx* ctx, const uint64_t base_xy[8], uint64_t first, size_t n, uint64_t* out_xy);
 /* Throughput probe: runs `iters` dependent Montgomery multiplications per lane on every CU and returns
  * achieved 32x32->64 multiply-adds per second (the VALU integer peak the MSM roofline is quoted against). */
 int zkhip_probe_mad_rate(zkhip_ctx* ctx, int iters, double* mads_per_second, double* fr_mul_per_second);
@@ -177,7 +179,8 @@ int zkhip_evaluate_h(zkhip_domain* dom, const zkhip_evalh_desc* desc, uint64_t* 
 
 /* Kernel timing hook: average duration in microseconds of the launches of the named kernel family issued on
  * this context since the last zkhip_timing_reset (measured with HIP events on the launch stream).
- * families: "ntt", "msm_accumulate", "msm_reduce", "evalh_gates", "evalh_lookup", "evalh_perm". */
+ * families: "ntt", "msm_sort", "msm_accumulate", "msm_merge", "msm_reduce", "evalh_gates", "evalh_lookup",
+ * "evalh_perm".  A family brackets every launch of its stage in one call (e.g. the passes of one NTT). */
 int zkhip_timing_enable(zkhip_ctx* ctx, int on);
 int zkhip_timing_reset(zkhip_ctx* ctx);
 int zkhip_timing_get(zkhip_ctx* ctx, const char* family, double* avg_us, uint64_t* launches);

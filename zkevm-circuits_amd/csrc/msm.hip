@@ -337,6 +337,20 @@ __global__ void __launch_bounds__(REDUCE_THREADS) bucket_reduce_kernel(const g1_
     if (threadIdx.x == 0) store_xyzz(block_sums + blockIdx.x, v);
 }
 
+// out[i] = (first + i) * P for an affine point P: the synthetic SRS of the benchmark and the parity tests
+__global__ void __launch_bounds__(256) g1_multiples_kernel(const g1_affine* base, uint64_t first, size_t n, g1_affine* out) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const g1_affine p = load_affine(base);
+    const uint64_t k = first + i;
+    g1_xyzz acc = xyzz_identity();
+    for (int bit = 63; bit >= 0; bit--) {
+        acc = xyzz_double(acc);
+        if ((k >> bit) & 1) xyzz_add_affine(acc, p);
+    }
+    store_affine(out + i, xyzz_to_affine(acc));
+}
+
 __global__ void __launch_bounds__(256) g1_add_affine_kernel(const g1_affine* p, const g1_affine* q, g1_affine* o, size_t n) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -617,6 +631,23 @@ int zkhip_g1_add_affine(zkhip_ctx* ctx, const uint64_t* p_xy, const uint64_t* q_
     ZK_HIP(ctx, hipMemcpyAsync(dp, p_xy, n * 64, hipMemcpyHostToDevice, ctx->stream));
     ZK_HIP(ctx, hipMemcpyAsync(dq, q_xy, n * 64, hipMemcpyHostToDevice, ctx->stream));
     hipLaunchKernelGGL(g1_add_affine_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, dp, dq, dout, n);
+    ZK_HIP(ctx, hipGetLastError());
+    ZK_HIP(ctx, hipMemcpyAsync(out_xy, dout, n * 64, hipMemcpyDeviceToHost, ctx->stream));
+    ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return ZKHIP_OK;
+}
+
+int zkhip_g1_multiples(zkhip_ctx* ctx, const uint64_t base_xy[8], uint64_t first, size_t n, uint64_t* out_xy) {
+    if (!ctx) return ZKHIP_ERR_INVALID;
+    ZK_CHECK(ctx, base_xy && (out_xy || n == 0), "g1_multiples: null pointer");
+    if (n == 0) return ZKHIP_OK;
+    ZK_HIP(ctx, hipSetDevice(ctx->device));
+    int rc = ensure_scratch(ctx, (n + 1) * 64);
+    if (rc) return rc;
+    g1_affine* dbase = (g1_affine*)ctx->scratch;
+    g1_affine* dout = dbase + 1;
+    ZK_HIP(ctx, hipMemcpyAsync(dbase, base_xy, 64, hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(g1_multiples_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, dbase, first, n, dout);
     ZK_HIP(ctx, hipGetLastError());
     ZK_HIP(ctx, hipMemcpyAsync(out_xy, dout, n * 64, hipMemcpyDeviceToHost, ctx->stream));
     ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));

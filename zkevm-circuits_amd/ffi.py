@@ -17,7 +17,7 @@ _LIB = None
 EXPORTS = [
     "zkhip_create", "zkhip_destroy", "zkhip_last_error", "zkhip_version", "zkhip_set_stream", "zkhip_sync",
     "zkhip_dev_alloc", "zkhip_dev_free", "zkhip_upload", "zkhip_download",
-    "zkhip_field_binop", "zkhip_field_batch_invert", "zkhip_g1_add_affine", "zkhip_probe_mad_rate",
+    "zkhip_field_binop", "zkhip_field_batch_invert", "zkhip_g1_add_affine", "zkhip_g1_multiples", "zkhip_probe_mad_rate",
     "zkhip_register_bases", "zkhip_release_bases", "zkhip_msm", "zkhip_msm_batch_dev", "zkhip_msm_range_dev",
     "zkhip_g1_sum_jacobian", "zkhip_g1_to_affine",
     "zkhip_ntt", "zkhip_ntt_dev",
@@ -195,6 +195,17 @@ class Context:
         p, q = u64(p), u64(q)
         out = np.empty_like(p)
         self._ck(self._l.zkhip_g1_add_affine(self.h, _p(p), _p(q), _p(out), C.c_size_t(p.size // 8)))
+        return out
+
+    def g1_multiples(self, n: int, first: int = 1, base=None):
+        """[(first + i) * base] for i < n, affine; base defaults to the generator (1, 2)."""
+        if base is None:
+            one = [0xd35d438dc58f0d9d, 0x0a78eb28f5c70b3d, 0x666ea36f7879462c, 0x0e0a77c19a07df2f]   # Fq one (Montgomery)
+            two = [0xa6ba871b8b1e1b3a, 0x14f1d651eb8e167b, 0xccdd46def0f28c58, 0x1c14ef83340fbe5e]   # Fq two
+            base = np.array(one + two, dtype=np.uint64)
+        base = u64(base)
+        out = np.empty((n, 8), dtype=np.uint64)
+        self._ck(self._l.zkhip_g1_multiples(self.h, _p(base), C.c_uint64(first), C.c_size_t(n), _p(out)))
         return out
 
     def probe_mad_rate(self, iters=2048):
