@@ -185,6 +185,20 @@ def main():
     intt_ms = e0.elapsed_time(e1) / 5
     extra["intt_2p19_ms"] = intt_ms
     extra["intt_2p19_GBps"] = 32.0 * 2 * n / (intt_ms * 1e-3) / 1e9
+    # 64-column batch against the same bases (8 distinct scalar vectors cycled): the prover's commit phase
+    with torch.cuda.stream(stream):
+        cols = [rand_fr_device(n, gen) for _ in range(8)]
+    stream.synchronize()
+    ptrs = [cols[i % 8].data_ptr() for i in range(64)]
+    ctx.msm_batch_dev(bid, ptrs[:4], n)
+    torch.cuda.synchronize()
+    tb0 = time.perf_counter()
+    ctx.msm_batch_dev(bid, ptrs, n)
+    torch.cuda.synchronize()
+    tb = time.perf_counter() - tb0
+    extra["msm_batch64_ms_per_msm"] = tb * 1e3 / 64
+    extra["msm_batch64_Mpts_per_s"] = 64 * n / tb / 1e6
+    del cols
     mads, muls = ctx.probe_mad_rate(1024)
     extra["fr_mul_probe_Gps"] = muls / 1e9
 

@@ -34,17 +34,17 @@ int ensure_scratch(zkhip_ctx* ctx, size_t bytes) {
     return ZKHIP_OK;
 }
 
-TimedRegion::TimedRegion(zkhip_ctx* c, const char* f) : ctx(c), family(f) {
-    if (!ctx->timing) return;
+TimedRegion::TimedRegion(zkhip_ctx* c, const char* f, hipStream_t s) : ctx(c), family(f), stream(s ? s : c->stream) {
+    if (!ctx->timing || !family) return;
     if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) {
         e0 = e1 = nullptr;
         return;
     }
-    (void)hipEventRecord(e0, ctx->stream);
+    (void)hipEventRecord(e0, stream);
 }
 TimedRegion::~TimedRegion() {
     if (!e0) return;
-    (void)hipEventRecord(e1, ctx->stream);
+    (void)hipEventRecord(e1, stream);
     ctx->timers[family].pending.emplace_back(e0, e1);
 }
 

@@ -60,7 +60,9 @@ struct TimedRegion {
     zkhip_ctx* ctx;
     const char* family;
     hipEvent_t e0 = nullptr, e1 = nullptr;
-    TimedRegion(zkhip_ctx* c, const char* f);
+    hipStream_t stream = nullptr;
+    // family == nullptr or timing disabled: no-op.  s == nullptr: the context's stream.
+    TimedRegion(zkhip_ctx* c, const char* f, hipStream_t s = nullptr);
     ~TimedRegion();
 };
 

@@ -16,7 +16,7 @@ struct g1_xyzz {
     fe x, y, zz, zzz;
 };
 
-ZK_DEV bool affine_is_identity(const g1_affine& p) { return Fq::is_zero(p.x) & Fq::is_zero(p.y); }
+ZK_DEV bool affine_is_identity(const g1_affine& p) { return Fq::is_zero(p.x) && Fq::is_zero(p.y); }
 ZK_DEV bool xyzz_is_identity(const g1_xyzz& p) { return Fq::is_zero(p.zz); }
 ZK_DEV g1_xyzz xyzz_identity() {
     g1_xyzz o;

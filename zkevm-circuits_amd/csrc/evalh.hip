@@ -13,6 +13,7 @@
 // reads are (row + rotation * 2^(ext_k - k)) mod 2^ext_k, i.e. coalesced 32-byte loads per lane.
 // Permutation and lookup argument terms are fixed-function code following the upstream formulas.
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include "domain.h"
 
@@ -208,7 +209,7 @@ struct Program {
     std::vector<uint32_t> words;   // 4 per instruction
     uint32_t result = 0;
     uint32_t n_slots = 0;          // total slots (LDS + spill)
-    std::vector<uint32_t> slot_rank;
+    uint32_t lds_slots = 1;        // slots kept in LDS
 };
 
 static bool parse_graph(const zkhip_graph* g, std::vector<Calc>& out, std::string& err) {
@@ -375,8 +376,11 @@ struct Lowering {
 };
 
 // liveness-based slot assignment; the `lds_slots` slots with the smallest average gap between accesses stay on chip
-static void assign_slots(std::vector<uint32_t>& words, uint32_t& result, uint32_t n_virtual, uint32_t lds_slots,
-                         uint32_t& n_slots_out) {
+// lds_budget: LDS slots the caller is willing to give one lane.  Returns through lds_slots_out the number actually
+// used (the peak number of simultaneously live values when that is smaller), so the launch reserves no more LDS than
+// the program needs and more workgroups fit on a CU.
+static void assign_slots(std::vector<uint32_t>& words, uint32_t& result, uint32_t n_virtual, uint32_t lds_budget,
+                         uint32_t& lds_slots_out, uint32_t& n_slots_out) {
     const size_t ni = words.size() / 4;
     std::vector<uint32_t> first(n_virtual, UINT32_MAX), last(n_virtual, 0), uses(n_virtual, 0);
     auto touch = [&](uint32_t v, uint32_t pc) {
@@ -405,7 +409,10 @@ static void assign_slots(std::vector<uint32_t>& words, uint32_t& result, uint32_
         return (uint32_t)mx;
     };
     std::vector<uint8_t> spilled(n_virtual, 0);
-    if (pressure(spilled) > lds_slots) {
+    const uint32_t peak = pressure(spilled);
+    const uint32_t lds_slots = std::max(1u, std::min(peak, lds_budget));
+    lds_slots_out = lds_slots;
+    if (peak > lds_slots) {
         // smallest prefix of `order` whose demotion brings the on-chip pressure within budget
         size_t lo = 0, hi = n_virtual;
         while (lo < hi) {
@@ -452,13 +459,14 @@ static void assign_slots(std::vector<uint32_t>& words, uint32_t& result, uint32_
     n_slots_out = lds_slots + next_sp;
 }
 
-static int lower_graph(zkhip_ctx* ctx, const zkhip_graph* g, const zkhip_evalh_desc* desc, uint32_t lds_slots, Program& out) {
+static int lower_graph(zkhip_ctx* ctx, const zkhip_graph* g, const zkhip_evalh_desc* desc, uint32_t lds_budget, Program& out) {
     Lowering lw;
     lw.g = g;
     lw.desc = desc;
     if (!parse_graph(g, lw.calcs, lw.err)) return set_error(ctx, ZKHIP_ERR_INVALID, "evaluate_h: %s", lw.err.c_str());
     if (lw.calcs.empty()) {
         out.result = K_ZERO << 28;
+        out.lds_slots = 1;
         return ZKHIP_OK;
     }
     lw.val.assign(lw.calcs.size(), 0);
@@ -468,7 +476,25 @@ static int lower_graph(zkhip_ctx* ctx, const zkhip_graph* g, const zkhip_evalh_d
     out.words.swap(lw.words);
     out.result = lw.val[lw.root];
     ZK_CHECK(ctx, lw.n_virtual < DST_ACC, "evaluate_h: program too large");
-    assign_slots(out.words, out.result, lw.n_virtual, lds_slots, out.n_slots);
+    uint32_t lds_slots = 1;
+    assign_slots(out.words, out.result, lw.n_virtual, lds_budget, lds_slots, out.n_slots);
+    out.lds_slots = lds_slots;
+    if (getenv("ZKHIP_DEBUG")) {
+        size_t nmul = 0, ncol = 0, nspill = 0;
+        for (size_t pc = 0; pc < out.words.size() / 4; pc++) {
+            const uint32_t op = out.words[4 * pc] & 0xff;
+            if (op == D_MUL || op == D_SQR || op == D_MULADD) nmul++;
+            for (int k = 1; k <= 3; k++) {
+                const uint32_t w = out.words[4 * pc + k];
+                if ((w >> 28) == K_COL) ncol++;
+                if ((w >> 28) == K_SLOT && (w & 0x0fffffffu) >= lds_slots) nspill++;
+            }
+            const uint32_t dst = out.words[4 * pc] >> 8;
+            if (dst != DST_ACC && dst >= lds_slots) nspill++;
+        }
+        fprintf(stderr, "[zkhip] graph: %u calculations -> %zu instructions (%zu multiplications, %zu column reads, %zu spill accesses), %u virtual values, %u slots (%u in LDS)\n",
+                g->num_calculations, out.words.size() / 4, nmul, ncol, nspill, lw.n_virtual, out.n_slots, lds_slots);
+    }
     return ZKHIP_OK;
 }
 
@@ -595,8 +621,9 @@ extern "C" int zkhip_evaluate_h(zkhip_domain* dom, const zkhip_evalh_desc* desc,
     }
     ZK_HIP(ctx, hipMemsetAsync(d_out, 0, size * 32, ctx->stream));
 
-    const uint32_t lds_slots = 16;
-    const size_t lds_bytes = (size_t)lds_slots * EV_THREADS * sizeof(fe);
+    // LDS budget per lane: 6 slots of 32 B keep three 256-lane workgroups on a CU (the register file allows three)
+    const char* env_slots = getenv("ZKHIP_EVALH_LDS_SLOTS");
+    const uint32_t lds_budget = env_slots && *env_slots ? (uint32_t)atoi(env_slots) : 6;
     const dim3 grid((unsigned)((size + EV_THREADS - 1) / EV_THREADS));
     ZK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(evalh_interp_kernel),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -607,8 +634,10 @@ extern "C" int zkhip_evaluate_h(zkhip_domain* dom, const zkhip_evalh_desc* desc,
                           (g->calc_words || !g->num_calc_words),
                  "evaluate_h: graph arrays missing");
         Program prog;
-        int r = lower_graph(ctx, g, desc, lds_slots, prog);
+        int r = lower_graph(ctx, g, desc, lds_budget, prog);
         if (r) return r;
+        const uint32_t lds_slots = prog.lds_slots;
+        const size_t lds_bytes = (size_t)lds_slots * EV_THREADS * sizeof(fe);
         InterpArgs a;
         memset(&a, 0, sizeof a);
         uint32_t* d_prog;

@@ -16,6 +16,7 @@
 //   6. reduce             : every lane multiplies its bucket sum by its weight (b + 1) and a block tree-sum in
 //                           LDS folds 512 buckets; the <= 64 block sums are added on the host
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include "common.h"
 #include "curve.cuh"
@@ -78,9 +79,9 @@ struct DigitIter {
 };
 
 __global__ void __launch_bounds__(HIST_THREADS) digits_hist_kernel(const fe* scalars, size_t n, size_t chunk, uint32_t c,
-                                                                    uint32_t W, uint32_t* counts /*[B][G]*/) {
+                                                                    uint32_t W, uint32_t* counts /*[G][B]*/) {
     extern __shared__ uint32_t hist[];
-    const uint32_t B = 1u << (c - 1), G = gridDim.x, g = blockIdx.x;
+    const uint32_t B = 1u << (c - 1), g = blockIdx.x;
     for (uint32_t b = threadIdx.x; b < B; b += HIST_THREADS) hist[b] = 0;
     __syncthreads();
     const size_t lo = (size_t)g * chunk, hi = lo + chunk < n ? lo + chunk : n;
@@ -93,15 +94,15 @@ __global__ void __launch_bounds__(HIST_THREADS) digits_hist_kernel(const fe* sca
         }
     }
     __syncthreads();
-    for (uint32_t b = threadIdx.x; b < B; b += HIST_THREADS) counts[(size_t)b * G + g] = hist[b];
+    for (uint32_t b = threadIdx.x; b < B; b += HIST_THREADS) counts[(size_t)g * B + b] = hist[b];
 }
 
 __global__ void __launch_bounds__(HIST_THREADS) scatter_kernel(const fe* scalars, size_t n, size_t chunk, uint32_t c,
-                                                               uint32_t W, const uint32_t* offsets /*[B][G]*/,
-                                                               uint32_t* entries) {
+                                                               uint32_t W, const uint32_t* offsets /*[G][B]*/,
+                                                               const uint32_t* start /*[B]*/, uint32_t* entries) {
     extern __shared__ uint32_t cursor[];
-    const uint32_t B = 1u << (c - 1), G = gridDim.x, g = blockIdx.x;
-    for (uint32_t b = threadIdx.x; b < B; b += HIST_THREADS) cursor[b] = offsets[(size_t)b * G + g];
+    const uint32_t B = 1u << (c - 1), g = blockIdx.x;
+    for (uint32_t b = threadIdx.x; b < B; b += HIST_THREADS) cursor[b] = start[b] + offsets[(size_t)g * B + b];
     __syncthreads();
     const size_t lo = (size_t)g * chunk, hi = lo + chunk < n ? lo + chunk : n;
     for (size_t i = lo + threadIdx.x; i < hi; i += HIST_THREADS) {
@@ -118,10 +119,6 @@ __global__ void __launch_bounds__(HIST_THREADS) scatter_kernel(const fe* scalars
 }
 
 // ---- scans -----------------------------------------------------------------------------------------
-constexpr int SCAN_THREADS = 256;
-constexpr int SCAN_ITEMS = 16;
-constexpr int SCAN_TILE = SCAN_THREADS * SCAN_ITEMS;
-
 __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t* lds /*[blockDim]*/, uint32_t* total) {
     const uint32_t tid = threadIdx.x, nt = blockDim.x;
     lds[tid] = v;
@@ -138,119 +135,59 @@ __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t* l
     return incl - v;
 }
 
-__global__ void __launch_bounds__(SCAN_THREADS) scan_tile_sums_kernel(const uint32_t* in, size_t n, uint32_t* tile_sums) {
-    __shared__ uint32_t lds[SCAN_THREADS];
-    const size_t base = (size_t)blockIdx.x * SCAN_TILE + (size_t)threadIdx.x * SCAN_ITEMS;
-    uint32_t s = 0;
-    for (int k = 0; k < SCAN_ITEMS; k++)
-        if (base + k < n) s += in[base + k];
-    uint32_t total;
-    block_exclusive_scan(s, lds, &total);
-    if (threadIdx.x == 0) tile_sums[blockIdx.x] = total;
-}
-// single block: exclusive scan of `m` values in place (m arbitrary), total to *total_out
-__global__ void __launch_bounds__(1024) scan_single_block_kernel(uint32_t* data, size_t m, uint32_t* total_out) {
-    __shared__ uint32_t lds[1024];
-    __shared__ uint32_t carry_s;
-    if (threadIdx.x == 0) carry_s = 0;
-    __syncthreads();
-    for (size_t base = 0; base < m; base += 1024) {
-        const size_t i = base + threadIdx.x;
-        const uint32_t v = i < m ? data[i] : 0;
-        uint32_t total;
-        const uint32_t ex = block_exclusive_scan(v, lds, &total);
-        const uint32_t carry = carry_s;
-        if (i < m) data[i] = ex + carry;
-        __syncthreads();
-        if (threadIdx.x == 0) carry_s = carry + total;
-        __syncthreads();
-    }
-    if (threadIdx.x == 0 && total_out) *total_out = carry_s;
-}
-__global__ void __launch_bounds__(SCAN_THREADS) scan_apply_kernel(const uint32_t* in, size_t n, const uint32_t* tile_offsets,
-                                                                  uint32_t* out) {
-    __shared__ uint32_t lds[SCAN_THREADS];
-    const size_t base = (size_t)blockIdx.x * SCAN_TILE + (size_t)threadIdx.x * SCAN_ITEMS;
-    uint32_t v[SCAN_ITEMS];
-    uint32_t s = 0;
+// counts[g][b] -> exclusive prefix over g (in place), cnt[b] = bucket size.  One lane per bucket, coalesced over b.
+__global__ void __launch_bounds__(256) column_scan_kernel(uint32_t* counts /*[G][B]*/, uint32_t G, uint32_t B, uint32_t* cnt) {
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    uint32_t run = 0;
+    uint32_t g = 0;
+    for (; g + 8 <= G; g += 8) {
+        uint32_t v[8];
 #pragma unroll
-    for (int k = 0; k < SCAN_ITEMS; k++) {
-        v[k] = (base + k < n) ? in[base + k] : 0;
-        s += v[k];
-    }
-    uint32_t run = block_exclusive_scan(s, lds, nullptr) + tile_offsets[blockIdx.x];
+        for (int k = 0; k < 8; k++) v[k] = counts[(size_t)(g + k) * B + b];
 #pragma unroll
-    for (int k = 0; k < SCAN_ITEMS; k++) {
-        if (base + k < n) out[base + k] = run;
-        run += v[k];
+        for (int k = 0; k < 8; k++) {
+            counts[(size_t)(g + k) * B + b] = run;
+            run += v[k];
+        }
     }
+    for (; g < G; g++) {
+        const uint32_t v = counts[(size_t)g * B + b];
+        counts[(size_t)g * B + b] = run;
+        run += v;
+    }
+    cnt[b] = run;
 }
 
-// Per-bucket bookkeeping after the big scan.  One block.
-//   cnt[b]  = number of entries in bucket b, start[b] = first entry
-//   slots[b] = ceil(cnt / L), slot_off = exclusive scan of slots; info = {total entries, max cnt, total slots}
-__global__ void __launch_bounds__(1024) bucket_plan_kernel(const uint32_t* offsets /*[B][G]*/, uint32_t G, uint32_t B,
-                                                           uint32_t total_entries_last_count, const uint32_t* counts,
-                                                           uint32_t L, uint32_t* start, uint32_t* cnt, uint32_t* slot_off,
-                                                           uint32_t* info) {
+// One block of 1024 lanes, each owning B/1024 consecutive buckets.  f(b) = ceil(cnt[b] / D):
+//   f_out[b] = f(b) (optional), off_out[b] = exclusive scan of f, off_out[B] = total, *max_out = max cnt (optional)
+__global__ void __launch_bounds__(1024) bucket_scan_kernel(const uint32_t* cnt, uint32_t B, uint32_t D, uint32_t* f_out,
+                                                           uint32_t* off_out, uint32_t* max_out) {
     __shared__ uint32_t lds[1024];
-    __shared__ uint32_t carry_s, max_s;
-    if (threadIdx.x == 0) { carry_s = 0; max_s = 0; }
+    __shared__ uint32_t max_s;
+    if (threadIdx.x == 0) max_s = 0;
     __syncthreads();
-    (void)total_entries_last_count;
-    // total entries = offsets[last] + counts[last]
-    const uint32_t total = offsets[(size_t)B * G - 1] + counts[(size_t)B * G - 1];
-    for (uint32_t base = 0; base < B; base += 1024) {
-        const uint32_t b = base + threadIdx.x;
-        uint32_t s = 0, cn = 0;
-        if (b < B) {
-            const uint32_t st = offsets[(size_t)b * G];
-            const uint32_t en = (b + 1 < B) ? offsets[(size_t)(b + 1) * G] : total;
-            cn = en - st;
-            start[b] = st;
-            cnt[b] = cn;
-            s = (cn + L - 1) / L;
-            atomicMax(&max_s, cn);
-        }
-        uint32_t tot;
-        const uint32_t ex = block_exclusive_scan(s, lds, &tot);
-        const uint32_t carry = carry_s;
-        if (b < B) slot_off[b] = ex + carry;
-        __syncthreads();
-        if (threadIdx.x == 0) carry_s = carry + tot;
-        __syncthreads();
+    const uint32_t per = (B + 1023) / 1024;
+    const uint32_t lo = threadIdx.x * per, hi = lo + per < B ? lo + per : B;
+    uint32_t s = 0, mx = 0;
+    for (uint32_t b = lo; b < hi; b++) {
+        const uint32_t c = cnt[b];
+        s += (c + D - 1) / D;
+        mx = c > mx ? c : mx;
+    }
+    atomicMax(&max_s, mx);
+    uint32_t total;
+    uint32_t run = block_exclusive_scan(s, lds, &total);
+    for (uint32_t b = lo; b < hi; b++) {
+        const uint32_t f = (cnt[b] + D - 1) / D;
+        if (f_out) f_out[b] = f;
+        off_out[b] = run;
+        run += f;
     }
     if (threadIdx.x == 0) {
-        slot_off[B] = carry_s;
-        info[0] = total;
-        info[1] = max_s;
-        info[2] = carry_s;
+        off_out[B] = total;
+        if (max_out) *max_out = max_s;
     }
-}
-
-// next merge level: cnt_out = ceil(cnt_in / F), off_out = exclusive scan.  One block.
-__global__ void __launch_bounds__(1024) merge_plan_kernel(const uint32_t* cnt_in, uint32_t B, uint32_t F, uint32_t* cnt_out,
-                                                          uint32_t* off_out) {
-    __shared__ uint32_t lds[1024];
-    __shared__ uint32_t carry_s;
-    if (threadIdx.x == 0) carry_s = 0;
-    __syncthreads();
-    for (uint32_t base = 0; base < B; base += 1024) {
-        const uint32_t b = base + threadIdx.x;
-        uint32_t s = 0;
-        if (b < B) {
-            s = (cnt_in[b] + F - 1) / F;
-            cnt_out[b] = s;
-        }
-        uint32_t tot;
-        const uint32_t ex = block_exclusive_scan(s, lds, &tot);
-        const uint32_t carry = carry_s;
-        if (b < B) off_out[b] = ex + carry;
-        __syncthreads();
-        if (threadIdx.x == 0) carry_s = carry + tot;
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) off_out[B] = carry_s;
 }
 
 // largest b with off[b] <= t, over the B + 1 entry monotone array off (off[B] = total)
@@ -385,141 +322,257 @@ static void xyzz_to_jacobian_host(uint64_t out[12], const uint64_t in[16]) {
 
 static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
-static int exclusive_scan_u32(zkhip_ctx* ctx, const uint32_t* in, uint32_t* out, size_t n, uint32_t* tile_sums) {
-    const size_t tiles = (n + SCAN_TILE - 1) / SCAN_TILE;
-    hipLaunchKernelGGL(scan_tile_sums_kernel, dim3((unsigned)tiles), dim3(SCAN_THREADS), 0, ctx->stream, in, n, tile_sums);
-    hipLaunchKernelGGL(scan_single_block_kernel, dim3(1), dim3(1024), 0, ctx->stream, tile_sums, tiles, (uint32_t*)nullptr);
-    hipLaunchKernelGGL(scan_apply_kernel, dim3((unsigned)tiles), dim3(SCAN_THREADS), 0, ctx->stream, in, n, tile_sums, out);
-    ZK_HIP(ctx, hipGetLastError());
-    return ZKHIP_OK;
+static uint32_t env_u32(const char* name, uint32_t dflt) {
+    const char* v = getenv(name);
+    return v && *v ? (uint32_t)atoi(v) : dflt;
 }
+// entries folded by one accumulate lane / partial sums folded by one merge lane (tunable for experiments)
+static const uint32_t SLOT_L = env_u32("ZKHIP_SLOT_L", 32);
+static const uint32_t MERGE_F = env_u32("ZKHIP_MERGE_F", 16);
 
-int msm_run(zkhip_ctx* ctx, const MsmTables& tb, size_t first, const fe* d_scalars, size_t n, uint64_t out_jacobian[12]) {
-    memset(out_jacobian, 0, 96);
-    if (n == 0) return ZKHIP_OK;
-    ZK_CHECK(ctx, first + n <= tb.n, "msm: range [%zu, %zu) exceeds the %zu registered bases", first, first + n, tb.n);
-    ZK_CHECK(ctx, n <= ((size_t)1 << ENTRY_IDX_BITS), "msm: n=%zu exceeds 2^26", n);
-    const uint32_t c = tb.c, W = tb.W, B = 1u << (c - 1);
-    const uint32_t L = 32, F = 16;
+// Buffers of one in-flight MSM.  A workspace is bound to a stream; several workspaces let the latency-bound tail of
+// one MSM (merge, reduce, host fold) overlap the accumulate phase of the next.
+struct MsmWorkspace {
+    hipStream_t stream = nullptr;
+    unsigned char* base = nullptr;
+    size_t bytes = 0;
+    uint32_t* h_info = nullptr;        // pinned: {total slots, max bucket size}
+    uint64_t* h_sums = nullptr;        // pinned block sums (XYZZ)
+    size_t h_sums_cap = 0;
+    // per-call state
+    size_t n = 0, first = 0;
+    const fe* d_scalars = nullptr;
+    uint32_t G = 0;
+    size_t n_red_blocks = 0;
+    uint32_t *counts, *entries, *start, *cnt, *offA, *cntA, *offB, *cntB, *info;
+    g1_xyzz *itemsA, *itemsB, *bsums;
+};
+
+static int ws_prepare(zkhip_ctx* ctx, MsmWorkspace& ws, const MsmTables& tb, size_t n) {
+    const uint32_t B = 1u << (tb.c - 1), W = tb.W;
     uint32_t G = (uint32_t)std::min<size_t>((size_t)ctx->num_cus, (n + HIST_THREADS - 1) / HIST_THREADS);
     if (G < 1) G = 1;
-    const size_t chunk = (n + G - 1) / G;
-    const size_t E_max = n * W;
-    const size_t T1_max = E_max / L + B + 1;
-
-    // scratch layout
+    ws.G = G;
+    const size_t E_max = n * W, T1_max = E_max / SLOT_L + B + 1;
+    ws.n_red_blocks = (B + 511) / 512;
     size_t off = 0;
     auto take = [&](size_t bytes) {
         const size_t o = off;
         off = align_up(off + bytes, 256);
         return o;
     };
-    const size_t o_counts = take((size_t)B * G * 4), o_offsets = take((size_t)B * G * 4);
-    const size_t o_tiles = take((((size_t)B * G + SCAN_TILE - 1) / SCAN_TILE + 1) * 4);
-    const size_t o_entries = take(E_max * 4);
-    const size_t o_start = take((size_t)B * 4), o_cnt = take((size_t)B * 4);
-    const size_t o_offA = take(((size_t)B + 1) * 4), o_cntA = take((size_t)B * 4);
-    const size_t o_offB = take(((size_t)B + 1) * 4), o_cntB = take((size_t)B * 4);
-    const size_t o_info = take(64);
-    const size_t o_itemsA = take(T1_max * sizeof(g1_xyzz));
-    const size_t o_itemsB = take((T1_max / F + B + 1) * sizeof(g1_xyzz));
-    const size_t n_red_blocks = (B + REDUCE_THREADS - 1) / REDUCE_THREADS;
-    const size_t o_bsums = take(n_red_blocks * sizeof(g1_xyzz));
-    int rc = ensure_scratch(ctx, off);
+    const size_t o_counts = take((size_t)B * G * 4), o_entries = take(E_max * 4), o_start = take(((size_t)B + 1) * 4),
+                 o_cnt = take((size_t)B * 4), o_offA = take(((size_t)B + 1) * 4), o_cntA = take((size_t)B * 4),
+                 o_offB = take(((size_t)B + 1) * 4), o_cntB = take((size_t)B * 4), o_info = take(64),
+                 o_itemsA = take(T1_max * sizeof(g1_xyzz)), o_itemsB = take((T1_max / MERGE_F + B + 1) * sizeof(g1_xyzz)),
+                 o_bsums = take(ws.n_red_blocks * sizeof(g1_xyzz));
+    if (off > ws.bytes) {
+        if (ws.base) {
+            ZK_HIP(ctx, hipStreamSynchronize(ws.stream));
+            ZK_HIP(ctx, hipFree(ws.base));
+            ws.base = nullptr;
+            ws.bytes = 0;
+        }
+        ZK_HIP(ctx, hipMalloc((void**)&ws.base, off));
+        ws.bytes = off;
+    }
+    if (!ws.h_info) ZK_HIP(ctx, hipHostMalloc((void**)&ws.h_info, 64));
+    if (ws.h_sums_cap < ws.n_red_blocks) {
+        if (ws.h_sums) ZK_HIP(ctx, hipHostFree(ws.h_sums));
+        ZK_HIP(ctx, hipHostMalloc((void**)&ws.h_sums, ws.n_red_blocks * sizeof(g1_xyzz)));
+        ws.h_sums_cap = ws.n_red_blocks;
+    }
+    unsigned char* p = ws.base;
+    ws.counts = (uint32_t*)(p + o_counts);
+    ws.entries = (uint32_t*)(p + o_entries);
+    ws.start = (uint32_t*)(p + o_start);
+    ws.cnt = (uint32_t*)(p + o_cnt);
+    ws.offA = (uint32_t*)(p + o_offA);
+    ws.cntA = (uint32_t*)(p + o_cntA);
+    ws.offB = (uint32_t*)(p + o_offB);
+    ws.cntB = (uint32_t*)(p + o_cntB);
+    ws.info = (uint32_t*)(p + o_info);
+    ws.itemsA = (g1_xyzz*)(p + o_itemsA);
+    ws.itemsB = (g1_xyzz*)(p + o_itemsB);
+    ws.bsums = (g1_xyzz*)(p + o_bsums);
+    return ZKHIP_OK;
+}
+
+// phase 1: recode, count, scan, scatter; asynchronous readback of {slots, max bucket size}
+static int msm_phase1(zkhip_ctx* ctx, MsmWorkspace& ws, const MsmTables& tb, size_t first, const fe* d_scalars, size_t n) {
+    int rc = ws_prepare(ctx, ws, tb, n);
     if (rc) return rc;
-    unsigned char* base = (unsigned char*)ctx->scratch;
-    uint32_t* counts = (uint32_t*)(base + o_counts);
-    uint32_t* offsets = (uint32_t*)(base + o_offsets);
-    uint32_t* tiles = (uint32_t*)(base + o_tiles);
-    uint32_t* entries = (uint32_t*)(base + o_entries);
-    uint32_t* start = (uint32_t*)(base + o_start);
-    uint32_t* cnt = (uint32_t*)(base + o_cnt);
-    uint32_t* offA = (uint32_t*)(base + o_offA);
-    uint32_t* cntA = (uint32_t*)(base + o_cntA);
-    uint32_t* offB = (uint32_t*)(base + o_offB);
-    uint32_t* cntB = (uint32_t*)(base + o_cntB);
-    uint32_t* info = (uint32_t*)(base + o_info);
-    g1_xyzz* itemsA = (g1_xyzz*)(base + o_itemsA);
-    g1_xyzz* itemsB = (g1_xyzz*)(base + o_itemsB);
-    g1_xyzz* bsums = (g1_xyzz*)(base + o_bsums);
-
+    ws.n = n;
+    ws.first = first;
+    ws.d_scalars = d_scalars;
+    const uint32_t c = tb.c, W = tb.W, B = 1u << (c - 1), G = ws.G;
+    const size_t chunk = (n + G - 1) / G;
     const size_t lds_hist = (size_t)B * 4;
-    {
-        TimedRegion tr(ctx, "msm_sort");
-        hipLaunchKernelGGL(digits_hist_kernel, dim3(G), dim3(HIST_THREADS), lds_hist, ctx->stream, d_scalars, n, chunk, c, W,
-                           counts);
-        ZK_HIP(ctx, hipGetLastError());
-        rc = exclusive_scan_u32(ctx, counts, offsets, (size_t)B * G, tiles);
-        if (rc) return rc;
-        hipLaunchKernelGGL(bucket_plan_kernel, dim3(1), dim3(1024), 0, ctx->stream, offsets, G, B, 0u, counts, L, start, cnt,
-                           offA, info);
-        hipLaunchKernelGGL(scatter_kernel, dim3(G), dim3(HIST_THREADS), lds_hist, ctx->stream, d_scalars, n, chunk, c, W,
-                           offsets, entries);
-        ZK_HIP(ctx, hipGetLastError());
-    }
-    uint32_t h_info[3];
-    ZK_HIP(ctx, hipMemcpyAsync(h_info, info, sizeof h_info, hipMemcpyDeviceToHost, ctx->stream));
-    ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    const uint32_t total_entries = h_info[0], max_cnt = h_info[1], total_slots = h_info[2];
-    if (total_entries == 0) return ZKHIP_OK;   // every scalar is zero
+    hipStream_t st = ws.stream;
+    hipLaunchKernelGGL(digits_hist_kernel, dim3(G), dim3(HIST_THREADS), lds_hist, st, d_scalars, n, chunk, c, W, ws.counts);
+    hipLaunchKernelGGL(column_scan_kernel, dim3((B + 255) / 256), dim3(256), 0, st, ws.counts, G, B, ws.cnt);
+    // start[b] = exclusive scan of cnt (entries), then slots per bucket and their scan; info = {total slots, max cnt}
+    hipLaunchKernelGGL(bucket_scan_kernel, dim3(1), dim3(1024), 0, st, ws.cnt, B, 1u, (uint32_t*)nullptr, ws.start,
+                       ws.info + 1);
+    hipLaunchKernelGGL(bucket_scan_kernel, dim3(1), dim3(1024), 0, st, ws.cnt, B, SLOT_L, ws.cntA, ws.offA,
+                       (uint32_t*)nullptr);
+    hipLaunchKernelGGL(scatter_kernel, dim3(G), dim3(HIST_THREADS), lds_hist, st, d_scalars, n, chunk, c, W, ws.counts,
+                       ws.start, ws.entries);
+    ZK_HIP(ctx, hipGetLastError());
+    ZK_HIP(ctx, hipMemcpyAsync(ws.h_info, ws.offA + B, 4, hipMemcpyDeviceToHost, st));
+    ZK_HIP(ctx, hipMemcpyAsync(ws.h_info + 1, ws.info + 1, 4, hipMemcpyDeviceToHost, st));
+    return ZKHIP_OK;
+}
 
+// phase 2: waits for phase 1's readback, then accumulate, merge levels, reduce; asynchronous readback of block sums
+static int msm_phase2(zkhip_ctx* ctx, MsmWorkspace& ws, const MsmTables& tb, bool timed) {
+    hipStream_t st = ws.stream;
+    ZK_HIP(ctx, hipStreamSynchronize(st));
+    const uint32_t total_slots = ws.h_info[0], max_cnt = ws.h_info[1];
+    const uint32_t B = 1u << (tb.c - 1);
+    if (total_slots == 0) {   // every scalar is zero
+        ws.n_red_blocks = 0;
+        return ZKHIP_OK;
+    }
     {
-        TimedRegion tr(ctx, "msm_accumulate");
-        hipLaunchKernelGGL(accumulate_kernel, dim3((total_slots + 255) / 256), dim3(256), 0, ctx->stream, entries, start, cnt,
-                           offA, B, L, tb.d_tables, tb.n, first, itemsA);
+        TimedRegion tr(ctx, timed ? "msm_accumulate" : nullptr, st);
+        hipLaunchKernelGGL(accumulate_kernel, dim3((total_slots + 255) / 256), dim3(256), 0, st, ws.entries, ws.start, ws.cnt,
+                           ws.offA, B, SLOT_L, tb.d_tables, tb.n, ws.first, ws.itemsA);
         ZK_HIP(ctx, hipGetLastError());
     }
-    // slot partial sums -> one item per bucket
-    g1_xyzz *cur_items = itemsA, *nxt_items = itemsB;
-    uint32_t *cur_off = offA, *cur_cnt = cntA, *nxt_off = offB, *nxt_cnt = cntB;
+    g1_xyzz *cur_items = ws.itemsA, *nxt_items = ws.itemsB;
+    uint32_t *cur_off = ws.offA, *cur_cnt = ws.cntA, *nxt_off = ws.offB, *nxt_cnt = ws.cntB;
     {
-        TimedRegion tr(ctx, "msm_merge");
-        // cntA = slots per bucket
-        hipLaunchKernelGGL(merge_plan_kernel, dim3(1), dim3(1024), 0, ctx->stream, cnt, B, L, cntA, offA);
-        uint32_t level_max = (max_cnt + L - 1) / L;
-        uint32_t level_total = total_slots;
+        TimedRegion tr(ctx, timed ? "msm_merge" : nullptr, st);
+        uint32_t level_max = (max_cnt + SLOT_L - 1) / SLOT_L, level_total = total_slots;
         while (level_max > 1) {
-            hipLaunchKernelGGL(merge_plan_kernel, dim3(1), dim3(1024), 0, ctx->stream, cur_cnt, B, F, nxt_cnt, nxt_off);
-            const uint32_t bound = level_total / F + B + 1;
-            hipLaunchKernelGGL(merge_kernel, dim3((bound + 255) / 256), dim3(256), 0, ctx->stream, cur_items, cur_off, cur_cnt,
-                               nxt_off, B, F, nxt_items);
+            hipLaunchKernelGGL(bucket_scan_kernel, dim3(1), dim3(1024), 0, st, cur_cnt, B, MERGE_F, nxt_cnt, nxt_off,
+                               (uint32_t*)nullptr);
+            const uint32_t bound = level_total / MERGE_F + B + 1;
+            hipLaunchKernelGGL(merge_kernel, dim3((bound + 255) / 256), dim3(256), 0, st, cur_items, cur_off, cur_cnt, nxt_off,
+                               B, MERGE_F, nxt_items);
             ZK_HIP(ctx, hipGetLastError());
             std::swap(cur_items, nxt_items);
             std::swap(cur_off, nxt_off);
             std::swap(cur_cnt, nxt_cnt);
-            level_max = (level_max + F - 1) / F;
+            level_max = (level_max + MERGE_F - 1) / MERGE_F;
             level_total = bound;
         }
     }
     {
-        TimedRegion tr(ctx, "msm_reduce");
-        hipLaunchKernelGGL(bucket_reduce_kernel, dim3((unsigned)n_red_blocks), dim3(REDUCE_THREADS),
-                           (REDUCE_THREADS / 2) * sizeof(g1_xyzz), ctx->stream, cur_items, cur_off, cur_cnt, B, bsums);
+        TimedRegion tr(ctx, timed ? "msm_reduce" : nullptr, st);
+        hipLaunchKernelGGL(bucket_reduce_kernel, dim3((unsigned)ws.n_red_blocks), dim3(REDUCE_THREADS),
+                           (REDUCE_THREADS / 2) * sizeof(g1_xyzz), st, cur_items, cur_off, cur_cnt, B, ws.bsums);
         ZK_HIP(ctx, hipGetLastError());
     }
-    std::vector<uint64_t> h_sums(n_red_blocks * 16);
-    ZK_HIP(ctx, hipMemcpyAsync(h_sums.data(), bsums, n_red_blocks * sizeof(g1_xyzz), hipMemcpyDeviceToHost, ctx->stream));
-    ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ZK_HIP(ctx, hipMemcpyAsync(ws.h_sums, ws.bsums, ws.n_red_blocks * sizeof(g1_xyzz), hipMemcpyDeviceToHost, st));
+    return ZKHIP_OK;
+}
+
+// phase 3: waits for the block sums and folds them on the host
+static int msm_phase3(zkhip_ctx* ctx, MsmWorkspace& ws, uint64_t out_jacobian[12]) {
+    ZK_HIP(ctx, hipStreamSynchronize(ws.stream));
     uint64_t acc[12], jac[12];
     memset(acc, 0, sizeof acc);
-    for (size_t i = 0; i < n_red_blocks; i++) {
-        xyzz_to_jacobian_host(jac, &h_sums[16 * i]);
+    for (size_t i = 0; i < ws.n_red_blocks; i++) {
+        xyzz_to_jacobian_host(jac, ws.h_sums + 16 * i);
         h_g1_add(acc, acc, jac);
     }
     memcpy(out_jacobian, acc, 96);
     return ZKHIP_OK;
 }
 
-static std::map<zkhip_ctx*, std::map<uint32_t, MsmTables>>& registry() {
-    static std::map<zkhip_ctx*, std::map<uint32_t, MsmTables>> r;
+constexpr int MSM_PIPE = 3;
+struct MsmState {
+    std::map<uint32_t, MsmTables> tables;
+    MsmWorkspace ws[MSM_PIPE];
+    hipEvent_t ev_in = nullptr, ev_out[MSM_PIPE] = {nullptr, nullptr, nullptr};
+    hipStream_t batch_streams[MSM_PIPE] = {nullptr, nullptr, nullptr};
+};
+static std::map<zkhip_ctx*, MsmState>& registry() {
+    static std::map<zkhip_ctx*, MsmState> r;
     return r;
+}
+
+static int check_args(zkhip_ctx* ctx, const MsmTables& tb, size_t first, size_t n) {
+    ZK_CHECK(ctx, first + n <= tb.n, "msm: range [%zu, %zu) exceeds the %zu registered bases", first, first + n, tb.n);
+    ZK_CHECK(ctx, n <= ((size_t)1 << ENTRY_IDX_BITS), "msm: n=%zu exceeds 2^26", n);
+    return ZKHIP_OK;
+}
+
+int msm_run(zkhip_ctx* ctx, MsmState& stt, const MsmTables& tb, size_t first, const fe* d_scalars, size_t n,
+            uint64_t out_jacobian[12]) {
+    memset(out_jacobian, 0, 96);
+    if (n == 0) return ZKHIP_OK;
+    int rc = check_args(ctx, tb, first, n);
+    if (rc) return rc;
+    MsmWorkspace& ws = stt.ws[0];
+    ws.stream = ctx->stream;
+    {
+        TimedRegion tr(ctx, "msm_sort");
+        rc = msm_phase1(ctx, ws, tb, first, d_scalars, n);
+    }
+    if (!rc) rc = msm_phase2(ctx, ws, tb, true);
+    if (!rc) rc = msm_phase3(ctx, ws, out_jacobian);
+    return rc;
+}
+
+// Batch: up to MSM_PIPE MSMs in flight on internal streams, so one MSM's tail overlaps the next one's accumulate phase.
+int msm_run_batch(zkhip_ctx* ctx, MsmState& stt, const MsmTables& tb, const uint64_t* const* d_scalars, size_t batch, size_t n,
+                  uint64_t* out) {
+    memset(out, 0, batch * 96);
+    if (n == 0 || batch == 0) return ZKHIP_OK;
+    int rc = check_args(ctx, tb, 0, n);
+    if (rc) return rc;
+    if (!stt.ev_in) {
+        ZK_HIP(ctx, hipEventCreateWithFlags(&stt.ev_in, hipEventDisableTiming));
+        for (int i = 0; i < MSM_PIPE; i++) ZK_HIP(ctx, hipEventCreateWithFlags(&stt.ev_out[i], hipEventDisableTiming));
+    }
+    MsmWorkspace* pipe[MSM_PIPE];
+    for (int i = 0; i < MSM_PIPE; i++) {
+        if (!stt.batch_streams[i]) ZK_HIP(ctx, hipStreamCreateWithFlags(&stt.batch_streams[i], hipStreamNonBlocking));
+        stt.ws[i].stream = stt.batch_streams[i];   // slot 0 is rebound to the caller's stream by single MSMs
+        pipe[i] = &stt.ws[i];
+    }
+    ZK_HIP(ctx, hipEventRecord(stt.ev_in, ctx->stream));
+    for (int i = 0; i < MSM_PIPE; i++) ZK_HIP(ctx, hipStreamWaitEvent(pipe[i]->stream, stt.ev_in, 0));
+    // software pipeline: phase1(j + 2), phase2(j + 1), phase3(j)
+    for (size_t j = 0; j < batch + 2; j++) {
+        if (j < batch) {
+            rc = msm_phase1(ctx, *pipe[j % MSM_PIPE], tb, 0, (const fe*)d_scalars[j], n);
+            if (rc) return rc;
+        }
+        if (j >= 1 && j - 1 < batch) {
+            rc = msm_phase2(ctx, *pipe[(j - 1) % MSM_PIPE], tb, false);
+            if (rc) return rc;
+        }
+        if (j >= 2 && j - 2 < batch) {
+            rc = msm_phase3(ctx, *pipe[(j - 2) % MSM_PIPE], out + 12 * (j - 2));
+            if (rc) return rc;
+        }
+    }
+    for (int i = 0; i < MSM_PIPE; i++) {
+        ZK_HIP(ctx, hipEventRecord(stt.ev_out[i], pipe[i]->stream));
+        ZK_HIP(ctx, hipStreamWaitEvent(ctx->stream, stt.ev_out[i], 0));
+    }
+    return ZKHIP_OK;
 }
 
 void msm_drop_ctx(zkhip_ctx* ctx) {
     auto it = registry().find(ctx);
     if (it == registry().end()) return;
-    for (auto& kv : it->second)
+    MsmState& st = it->second;
+    for (auto& kv : st.tables)
         if (kv.second.d_tables) (void)hipFree(kv.second.d_tables);
+    for (int i = 0; i < MSM_PIPE; i++) {
+        MsmWorkspace& w = st.ws[i];
+        if (w.base) (void)hipFree(w.base);
+        if (w.h_info) (void)hipHostFree(w.h_info);
+        if (w.h_sums) (void)hipHostFree(w.h_sums);
+        if (st.batch_streams[i]) (void)hipStreamDestroy(st.batch_streams[i]);
+        if (st.ev_out[i]) (void)hipEventDestroy(st.ev_out[i]);
+    }
+    if (st.ev_in) (void)hipEventDestroy(st.ev_in);
     registry().erase(it);
 }
 
@@ -561,14 +614,14 @@ int zkhip_register_bases(zkhip_ctx* ctx, const uint64_t* affine_xy, size_t n, ui
         return set_error(ctx, ZKHIP_ERR_HIP, "register_bases failed: %s", hipGetErrorString(e));
     }
     const uint32_t id = ctx->next_bases_id++;
-    registry()[ctx][id] = tb;
+    registry()[ctx].tables[id] = tb;
     *out_id = id;
     return ZKHIP_OK;
 }
 
 int zkhip_release_bases(zkhip_ctx* ctx, uint32_t bases_id) {
     if (!ctx) return ZKHIP_ERR_INVALID;
-    auto& m = registry()[ctx];
+    auto& m = registry()[ctx].tables;
     auto it = m.find(bases_id);
     ZK_CHECK(ctx, it != m.end(), "release_bases: unknown id %u", bases_id);
     ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -580,23 +633,24 @@ int zkhip_release_bases(zkhip_ctx* ctx, uint32_t bases_id) {
 int zkhip_msm_range_dev(zkhip_ctx* ctx, uint32_t bases_id, size_t first, const uint64_t* d_scalars, size_t n,
                         uint64_t out_jacobian[12]) {
     if (!ctx || !out_jacobian) return ZKHIP_ERR_INVALID;
-    auto& m = registry()[ctx];
-    auto it = m.find(bases_id);
-    ZK_CHECK(ctx, it != m.end(), "msm: unknown bases id %u", bases_id);
+    MsmState& stt = registry()[ctx];
+    auto it = stt.tables.find(bases_id);
+    ZK_CHECK(ctx, it != stt.tables.end(), "msm: unknown bases id %u", bases_id);
     ZK_CHECK(ctx, d_scalars || n == 0, "msm: null scalars");
     ZK_HIP(ctx, hipSetDevice(ctx->device));
-    return msm_run(ctx, it->second, first, (const fe*)d_scalars, n, out_jacobian);
+    return msm_run(ctx, stt, it->second, first, (const fe*)d_scalars, n, out_jacobian);
 }
 
 int zkhip_msm_batch_dev(zkhip_ctx* ctx, uint32_t bases_id, const uint64_t* const* d_scalars, size_t batch, size_t n,
                         uint64_t* out_jacobian) {
     if (!ctx) return ZKHIP_ERR_INVALID;
     ZK_CHECK(ctx, (d_scalars && out_jacobian) || batch == 0, "msm_batch: null pointer");
-    for (size_t b = 0; b < batch; b++) {
-        int rc = zkhip_msm_range_dev(ctx, bases_id, 0, d_scalars[b], n, out_jacobian + 12 * b);
-        if (rc) return rc;
-    }
-    return ZKHIP_OK;
+    MsmState& stt = registry()[ctx];
+    auto it = stt.tables.find(bases_id);
+    ZK_CHECK(ctx, it != stt.tables.end(), "msm: unknown bases id %u", bases_id);
+    for (size_t b = 0; b < batch; b++) ZK_CHECK(ctx, d_scalars[b] || n == 0, "msm_batch: null scalars");
+    ZK_HIP(ctx, hipSetDevice(ctx->device));
+    return msm_run_batch(ctx, stt, it->second, d_scalars, batch, n, out_jacobian);
 }
 
 int zkhip_msm(zkhip_ctx* ctx, uint32_t bases_id, const uint64_t* scalars, size_t n, uint64_t out_jacobian[12]) {

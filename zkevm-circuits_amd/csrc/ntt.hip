@@ -17,7 +17,7 @@ namespace zkhip {
 
 constexpr int NTT_THREADS = 256;
 constexpr int TILE_LOG = 11;
-constexpr int TILE = 1 << TILE_LOG;
+
 
 struct NttPassArgs {
     const fe* in;
