@@ -179,8 +179,7 @@ int zkhip_evaluate_h(zkhip_domain* dom, const zkhip_evalh_desc* desc, uint64_t* 
 
 /* Kernel timing hook: average duration in microseconds of the launches of the named kernel family issued on
  * this context since the last zkhip_timing_reset (measured with HIP events on the launch stream).
- * families: "ntt", "msm_sort", "msm_accumulate", "msm_merge", "msm_reduce", "evalh_gates", "evalh_lookup",
- * "evalh_perm".  A family brackets every launch of its stage in one call (e.g. the passes of one NTT). */
+ * families: "ntt", "msm_sort", "msm_accumulate", "msm_merge", "msm_reduce", "evalh".  A family brackets every launch of its stage in one call (e.g. the passes of one NTT). */
 int zkhip_timing_enable(zkhip_ctx* ctx, int on);
 int zkhip_timing_reset(zkhip_ctx* ctx);
 int zkhip_timing_get(zkhip_ctx* ctx, const char* family, double* avg_us, uint64_t* launches);

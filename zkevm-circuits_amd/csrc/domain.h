@@ -10,6 +10,7 @@ struct zkhip_domain {
     uint64_t g_coset[4], g_coset_inv[4], ifft_divisor[4], extended_ifft_divisor[4];
     std::vector<uint64_t> t_evaluations;   // 2^(extended_k - k) inverted values, Montgomery limbs
     void* d_t_evaluations = nullptr;
+    void* d_xpoints = nullptr;             // zeta * extended_omega^idx per extended row (built on first use by evaluate_h)
     zkhip::NttPlan *plan_fwd = nullptr, *plan_inv = nullptr, *plan_ext_fwd = nullptr, *plan_ext_inv = nullptr;
 };
 

@@ -91,6 +91,7 @@ int zkhip_domain_create(zkhip_ctx* ctx, uint32_t j, uint32_t k, zkhip_domain** o
 void zkhip_domain_destroy(zkhip_domain* dom) {
     if (!dom) return;
     if (dom->d_t_evaluations) (void)hipFree(dom->d_t_evaluations);
+    if (dom->d_xpoints) (void)hipFree(dom->d_xpoints);
     delete dom;   // NTT plans are owned by the context
 }
 

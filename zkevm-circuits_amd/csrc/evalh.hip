@@ -1,17 +1,21 @@
 // `plonk::evaluation::Evaluator::evaluate_h` on gfx950: quotient numerator over the extended coset.
 //
-// One lane per extended row.  Custom gates and each lookup's compressed-expression graph arrive as the
-// serialised `GraphEvaluator`; the host lowers a graph to a register-machine program:
-//   * only calculations reachable from the result are emitted, in just-in-time order, so a value is computed
-//     right before its first use instead of all "parts" being alive until the final Horner;
-//   * `Store` of a column / challenge is never materialised: users read the source directly;
-//   * `Horner(start, parts, factor)` becomes one multiply-add per part on an accumulator that lives in
-//     registers for the root calculation;
-//   * values get slots by liveness; the slots with the densest use live in LDS ([slot][lane], 32 B each), the
-//     rest spill to a [slot][row] buffer in HBM (coalesced 32 B per lane).
-// The program is wave-uniform, so decode runs on the scalar unit and every branch is a scalar branch; column
-// reads are (row + rotation * 2^(ext_k - k)) mod 2^ext_k, i.e. coalesced 32-byte loads per lane.
-// Permutation and lookup argument terms are fixed-function code following the upstream formulas.
+// One lane per extended row, ONE kernel launch for the whole function.  The host fuses custom gates, the
+// permutation argument and every lookup argument into a single register-machine program:
+//   * each serialised `GraphEvaluator` is lowered just-in-time: only calculations reachable from its result are
+//     emitted, each right before its first use; `Store` of a column / challenge is never materialised (users read the
+//     source); `Horner(start, parts, factor)` becomes one multiply-add per part;
+//   * the running value `values[idx] = values[idx] * y + term` of upstream's row loops lives in a register
+//     accumulator for the whole program, so the output is written once instead of once per argument;
+//   * permutation and lookup terms are emitted as instructions following upstream's formulas; their cosets, l0,
+//     l_last, l_active_row and the row's point zeta * extended_omega^idx join the unified column table;
+//   * values get slots by liveness; the slots with the densest use live in LDS ([slot][lane], 32 B), the rest spill
+//     to a [slot][row] buffer in HBM.  The launch reserves only the LDS the program needs, so that three 256-lane
+//     workgroups share a CU.
+// Every instruction is r = (a * b | a) (+ c | - c | nothing): the interpreter holds one multiplier instance.  The
+// program is wave-uniform: decode runs on the scalar unit, every branch is a scalar branch, column reads are
+// (row + rotation * 2^(ext_k - k)) mod 2^ext_k, i.e. 32 contiguous bytes per lane.
+// Results equal upstream's bit for bit: field arithmetic is exact, only the order of independent operations differs.
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
@@ -23,42 +27,32 @@ namespace zkhip {
 
 constexpr int EV_THREADS = 256;
 
-enum DevOp : uint32_t { D_ADD = 0, D_SUB, D_MUL, D_SQR, D_DBL, D_NEG, D_MOV, D_MULADD };
-enum DevKind : uint32_t { K_CONST = 0, K_SLOT, K_COL, K_SCALAR, K_ACC, K_ZERO, K_PREV };
+// instruction word 0: bit 0 = multiply a * b, bit 1 = add c, bit 2 = subtract c, bits 8.. = destination
+constexpr uint32_t F_MUL = 1, F_ADD = 2, F_SUB = 4;
+enum DevKind : uint32_t { K_CONST = 0, K_SLOT, K_COL, K_SCALAR, K_ACC, K_ZERO };
 constexpr uint32_t DST_ACC = 0xffffffu;
+constexpr uint32_t W_ZERO = K_ZERO << 28, W_ACC = K_ACC << 28;
 
-// scalar table layout: [0] beta [1] gamma [2] theta [3] y [4..] challenges
-constexpr uint32_t SC_BETA = 0, SC_GAMMA = 1, SC_THETA = 2, SC_Y = 3, SC_CHALLENGE0 = 4;
+// scalar table layout
+constexpr uint32_t SC_BETA = 0, SC_GAMMA = 1, SC_THETA = 2, SC_Y = 3, SC_ONE = 4, SC_CHALLENGE0 = 5;
 
 struct InterpArgs {
     const uint32_t* prog;       // 4 words per instruction
     uint32_t n_instr;
-    uint32_t result;            // operand word of the graph's value
+    uint32_t result;            // operand word of the final value
     const fe* consts;
     const fe* scalars;
-    const fe* const* cols;      // unified column table: fixed | advice | instance (extended cosets)
+    const fe* const* cols;      // unified column table (extended cosets)
     const int32_t* rots;
     uint32_t lds_slots;
     fe* spill;                  // [slot - lds_slots][size]
     uint32_t log_size;          // extended_k
     uint32_t rot_scale;         // 2^(extended_k - k)
-    fe* out;                    // values[], updated in place
-    // lookup mode (mode = 1)
-    uint32_t mode;
-    const fe* product;
-    const fe* permuted_input;
-    const fe* permuted_table;
-    const fe* l0;
-    const fe* l_last;
-    const fe* l_active;
+    fe* out;
 };
 
-ZK_DEV uint32_t rot_row(uint32_t idx, int32_t rot, uint32_t rot_scale, uint32_t mask) {
-    return (uint32_t)((int32_t)idx + rot * (int32_t)rot_scale) & mask;
-}
-
-__device__ __forceinline__ fe ev_fetch(const InterpArgs& a, uint32_t word, const fe* lds, const fe& acc, const fe& prev,
-                                       uint32_t idx, uint32_t mask) {
+__device__ __forceinline__ fe ev_fetch(const InterpArgs& a, uint32_t word, const fe* lds, const fe& acc, uint32_t idx,
+                                       uint32_t mask) {
     const uint32_t kind = word >> 28, pl = word & 0x0fffffffu;
     switch (kind) {
         case K_CONST: return load_fe(a.consts + pl);
@@ -68,11 +62,10 @@ __device__ __forceinline__ fe ev_fetch(const InterpArgs& a, uint32_t word, const
         case K_COL: {
             const fe* col = a.cols[pl >> 12];
             const int32_t rot = a.rots[pl & 0xfff];
-            return load_fe(col + rot_row(idx, rot, a.rot_scale, mask));
+            return load_fe(col + ((uint32_t)((int32_t)idx + rot * (int32_t)a.rot_scale) & mask));
         }
         case K_SCALAR: return load_fe(a.scalars + pl);
         case K_ACC: return acc;
-        case K_PREV: return prev;
         default: return Fr::zero();
     }
 }
@@ -83,119 +76,39 @@ __global__ void __launch_bounds__(EV_THREADS) evalh_interp_kernel(const InterpAr
     const uint32_t idx = blockIdx.x * EV_THREADS + threadIdx.x;
     const uint32_t mask = (1u << a.log_size) - 1;
     if (idx > mask) return;   // domains smaller than one workgroup
-    const fe prev = load_fe(a.out + idx);
-    const fe pv = (a.mode == 0) ? prev : Fr::zero();   // `previous_value` of GraphEvaluator::evaluate
-    fe acc = pv;
+    fe acc = Fr::zero();
     for (uint32_t pc = 0; pc < a.n_instr; pc++) {
         const uint32_t w0 = __builtin_amdgcn_readfirstlane(a.prog[4 * pc]);
         const uint32_t wa = __builtin_amdgcn_readfirstlane(a.prog[4 * pc + 1]);
         const uint32_t wb = __builtin_amdgcn_readfirstlane(a.prog[4 * pc + 2]);
         const uint32_t wc = __builtin_amdgcn_readfirstlane(a.prog[4 * pc + 3]);
-        const uint32_t op = w0 & 0xff, dst = w0 >> 8;
-        const fe x = ev_fetch(a, wa, lds, acc, pv, idx, mask);
-        fe r;
-        switch (op) {
-            case D_ADD: r = Fr::add(x, ev_fetch(a, wb, lds, acc, pv, idx, mask)); break;
-            case D_SUB: r = Fr::sub(x, ev_fetch(a, wb, lds, acc, pv, idx, mask)); break;
-            case D_MUL: r = Fr::mul(x, ev_fetch(a, wb, lds, acc, pv, idx, mask)); break;
-            case D_SQR: r = Fr::sqr(x); break;
-            case D_DBL: r = Fr::dbl(x); break;
-            case D_NEG: r = Fr::neg(x); break;
-            case D_MOV: r = x; break;
-            default: {   // D_MULADD: x * b + c
-                const fe y = ev_fetch(a, wb, lds, acc, pv, idx, mask);
-                r = Fr::add(Fr::mul(x, y), ev_fetch(a, wc, lds, acc, pv, idx, mask));
-                break;
-            }
+        const uint32_t dst = w0 >> 8;
+        fe t = ev_fetch(a, wa, lds, acc, idx, mask);
+        if (w0 & F_MUL) t = Fr::mul(t, ev_fetch(a, wb, lds, acc, idx, mask));
+        if (w0 & (F_ADD | F_SUB)) {
+            const fe c = ev_fetch(a, wc, lds, acc, idx, mask);
+            t = (w0 & F_ADD) ? Fr::add(t, c) : Fr::sub(t, c);
         }
-        if (dst == DST_ACC) acc = r;
-        else if (dst < a.lds_slots) lds[dst * EV_THREADS + threadIdx.x] = r;
-        else store_fe(a.spill + ((size_t)(dst - a.lds_slots) << a.log_size) + idx, r);
+        if (dst == DST_ACC) acc = t;
+        else if (dst < a.lds_slots) lds[dst * EV_THREADS + threadIdx.x] = t;
+        else store_fe(a.spill + ((size_t)(dst - a.lds_slots) << a.log_size) + idx, t);
     }
-    const fe value = ev_fetch(a, a.result, lds, acc, pv, idx, mask);
-    if (a.mode == 0) {
-        store_fe(a.out + idx, value);
-        return;
-    }
-    // lookup argument terms; `value` = (theta-compressed input + beta) * (theta-compressed table + gamma)
-    const fe y = load_fe(a.scalars + SC_Y), beta = load_fe(a.scalars + SC_BETA), gamma = load_fe(a.scalars + SC_GAMMA);
-    const uint32_t r_next = rot_row(idx, 1, a.rot_scale, mask), r_prev = rot_row(idx, -1, a.rot_scale, mask);
-    const fe z = load_fe(a.product + idx), z_next = load_fe(a.product + r_next);
-    const fe ai = load_fe(a.permuted_input + idx), ai_prev = load_fe(a.permuted_input + r_prev);
-    const fe si = load_fe(a.permuted_table + idx);
-    const fe l0 = load_fe(a.l0 + idx), l_last = load_fe(a.l_last + idx), l_active = load_fe(a.l_active + idx);
-    const fe a_minus_s = Fr::sub(ai, si);
-    fe v = prev;
-    v = Fr::add(Fr::mul(v, y), Fr::mul(Fr::sub(Fr::one(), z), l0));
-    v = Fr::add(Fr::mul(v, y), Fr::mul(Fr::sub(Fr::sqr(z), z), l_last));
-    {
-        const fe left = Fr::mul(Fr::mul(z_next, Fr::add(ai, beta)), Fr::add(si, gamma));
-        const fe right = Fr::mul(z, value);
-        v = Fr::add(Fr::mul(v, y), Fr::mul(Fr::sub(left, right), l_active));
-    }
-    v = Fr::add(Fr::mul(v, y), Fr::mul(a_minus_s, l0));
-    v = Fr::add(Fr::mul(v, y), Fr::mul(Fr::mul(a_minus_s, Fr::sub(ai, ai_prev)), l_active));
-    store_fe(a.out + idx, v);
+    store_fe(a.out + idx, ev_fetch(a, a.result, lds, acc, idx, mask));
 }
 
-struct PermArgs {
-    fe* out;
-    const fe* const* z;          // [nsets] permutation product cosets
-    const fe* const* sigma;      // [ncols]
-    const fe* const* colptr;     // [ncols] column cosets in permutation order
-    uint32_t nsets, ncols, chunk;
-    int32_t last_rot;
-    const fe* l0;
-    const fe* l_last;
-    const fe* l_active;
-    const fe* scalars;
-    const fe* om_lo;             // extended_omega^i, i < 2^h
-    const fe* om_hi;             // extended_omega^(i 2^h)
-    uint32_t om_h;
-    uint32_t log_size, rot_scale;
-};
-
-__global__ void __launch_bounds__(EV_THREADS) evalh_perm_kernel(const PermArgs a) {
-    const uint32_t idx = blockIdx.x * EV_THREADS + threadIdx.x;
-    const uint32_t mask = (1u << a.log_size) - 1;
-    if (idx > mask) return;
-    const fe y = load_fe(a.scalars + SC_Y), beta = load_fe(a.scalars + SC_BETA), gamma = load_fe(a.scalars + SC_GAMMA);
-    const fe l0 = load_fe(a.l0 + idx), l_last = load_fe(a.l_last + idx), l_active = load_fe(a.l_active + idx);
-    const uint32_t r_next = rot_row(idx, 1, a.rot_scale, mask), r_last = rot_row(idx, a.last_rot, a.rot_scale, mask);
-    fe v = load_fe(a.out + idx);
-    {
-        const fe z0 = load_fe(a.z[0] + idx);
-        v = Fr::add(Fr::mul(v, y), Fr::mul(Fr::sub(Fr::one(), z0), l0));
-        const fe zl = load_fe(a.z[a.nsets - 1] + idx);
-        v = Fr::add(Fr::mul(v, y), Fr::mul(Fr::sub(Fr::sqr(zl), zl), l_last));
-    }
-    for (uint32_t s = 1; s < a.nsets; s++) {
-        const fe d = Fr::sub(load_fe(a.z[s] + idx), load_fe(a.z[s - 1] + r_last));
-        v = Fr::add(Fr::mul(v, y), Fr::mul(d, l0));
-    }
-    // current_delta = beta * zeta * extended_omega^idx, then * DELTA per column (carried across sets)
-    fe om = load_fe(a.om_lo + (idx & ((1u << a.om_h) - 1)));
-    if (idx >> a.om_h) om = Fr::mul(om, load_fe(a.om_hi + (idx >> a.om_h)));
-    fe zeta, delta;
+// x[idx] = zeta * extended_omega^idx: the point of extended row idx
+__global__ void __launch_bounds__(256) xpoints_kernel(fe* x, const fe* om_lo, const fe* om_hi, uint32_t h, uint32_t size) {
+    const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= size) return;
+    fe zeta;
 #pragma unroll
-    for (int i = 0; i < 8; i++) { zeta.l[i] = FrParams::ZETA[i]; delta.l[i] = FrParams::DELTA[i]; }
-    fe current_delta = Fr::mul(Fr::mul(beta, zeta), om);
-    for (uint32_t s = 0; s < a.nsets; s++) {
-        const uint32_t c0 = s * a.chunk, c1 = c0 + a.chunk < a.ncols ? c0 + a.chunk : a.ncols;
-        fe left = load_fe(a.z[s] + r_next), right = load_fe(a.z[s] + idx);
-        for (uint32_t c = c0; c < c1; c++) {
-            const fe val = load_fe(a.colptr[c] + idx);
-            const fe sg = load_fe(a.sigma[c] + idx);
-            left = Fr::mul(left, Fr::add(Fr::add(val, Fr::mul(beta, sg)), gamma));
-            right = Fr::mul(right, Fr::add(Fr::add(val, current_delta), gamma));
-            current_delta = Fr::mul(current_delta, delta);
-        }
-        v = Fr::add(Fr::mul(v, y), Fr::mul(Fr::sub(left, right), l_active));
-    }
-    store_fe(a.out + idx, v);
+    for (int i = 0; i < 8; i++) zeta.l[i] = FrParams::ZETA[i];
+    fe om = load_fe(om_lo + (idx & ((1u << h) - 1)));
+    if (idx >> h) om = Fr::mul(om, load_fe(om_hi + (idx >> h)));
+    store_fe(x + idx, Fr::mul(om, zeta));
 }
 
-// ---- host-side lowering of a GraphEvaluator ---------------------------------------------------------
+// ---- host-side program construction ------------------------------------------------------------------
 struct VS {
     uint32_t kind, a, b;
 };
@@ -204,12 +117,7 @@ struct Calc {
     VS src[2];
     VS start, factor;
     std::vector<VS> parts;
-};
-struct Program {
-    std::vector<uint32_t> words;   // 4 per instruction
-    uint32_t result = 0;
-    uint32_t n_slots = 0;          // total slots (LDS + spill)
-    uint32_t lds_slots = 1;        // slots kept in LDS
+    uint32_t acc_dst = 0;
 };
 
 static bool parse_graph(const zkhip_graph* g, std::vector<Calc>& out, std::string& err) {
@@ -254,66 +162,96 @@ static bool parse_graph(const zkhip_graph* g, std::vector<Calc>& out, std::strin
     return true;
 }
 
+// The fused program under construction: instruction words with virtual destination ids, the merged constant and
+// rotation tables.
+struct Builder {
+    std::vector<uint32_t> words;
+    std::vector<uint64_t> consts;      // 4 limbs each
+    std::vector<int32_t> rots;
+    uint32_t n_virtual = 0;
+
+    uint32_t rot(int32_t r) {
+        for (size_t i = 0; i < rots.size(); i++)
+            if (rots[i] == r) return (uint32_t)i;
+        rots.push_back(r);
+        return (uint32_t)rots.size() - 1;
+    }
+    uint32_t col(uint32_t c, int32_t r) { return (K_COL << 28) | (c << 12) | rot(r); }
+    static uint32_t scalar(uint32_t i) { return (K_SCALAR << 28) | i; }
+    static uint32_t slot(uint32_t v) { return (K_SLOT << 28) | v; }
+    uint32_t fresh() { return n_virtual++; }
+    void emit(uint32_t flags, uint32_t dst, uint32_t a, uint32_t b = W_ZERO, uint32_t c = W_ZERO) {
+        words.push_back(flags | (dst << 8));
+        words.push_back(a);
+        words.push_back(b);
+        words.push_back(c);
+    }
+    // value-returning helpers (destination = fresh virtual value)
+    uint32_t mul(uint32_t a, uint32_t b) { const uint32_t d = fresh(); emit(F_MUL, d, a, b); return slot(d); }
+    uint32_t add(uint32_t a, uint32_t c) { const uint32_t d = fresh(); emit(F_ADD, d, a, W_ZERO, c); return slot(d); }
+    uint32_t sub(uint32_t a, uint32_t c) { const uint32_t d = fresh(); emit(F_SUB, d, a, W_ZERO, c); return slot(d); }
+    uint32_t mul_add(uint32_t a, uint32_t b, uint32_t c) { const uint32_t d = fresh(); emit(F_MUL | F_ADD, d, a, b, c); return slot(d); }
+    uint32_t mul_sub(uint32_t a, uint32_t b, uint32_t c) { const uint32_t d = fresh(); emit(F_MUL | F_SUB, d, a, b, c); return slot(d); }
+    // values[idx] = values[idx] * y + term
+    void fold(uint32_t term) { emit(F_MUL | F_ADD, DST_ACC, W_ACC, scalar(SC_Y), term); }
+};
+
+// Lowers one GraphEvaluator into the builder.  `is_gates`: the root Horner accumulates into the running value.
 struct Lowering {
+    Builder& b;
     const zkhip_graph* g;
     const zkhip_evalh_desc* desc;
+    bool is_gates;
     std::vector<Calc> calcs;
-    std::vector<uint32_t> val;      // operand word per calculation once emitted (virtual slot ids in K_SLOT payload)
+    std::vector<uint32_t> val;
     std::vector<uint8_t> done;
-    std::vector<uint32_t> words;    // instruction stream with virtual slots
-    uint32_t n_virtual = 0;
+    uint32_t const_base = 0;
     uint32_t root = 0;
     std::string err;
+
+    Lowering(Builder& b_, const zkhip_graph* g_, const zkhip_evalh_desc* d_, bool gates) : b(b_), g(g_), desc(d_), is_gates(gates) {}
 
     bool operand(const VS& v, uint32_t& word) {
         switch (v.kind) {
             case 0:
                 if (v.a >= g->num_constants) { err = "constant index out of range"; return false; }
-                word = (K_CONST << 28) | v.a;
+                word = (K_CONST << 28) | (const_base + v.a);
                 return true;
             case 1:
                 if (v.a >= calcs.size() || !done[v.a]) { err = "intermediate used before definition"; return false; }
                 word = val[v.a];
                 return true;
             case 2: case 3: case 4: {
-                uint32_t col;
-                if (v.kind == 2) { if (v.a >= desc->num_fixed) { err = "fixed column out of range"; return false; } col = v.a; }
-                else if (v.kind == 3) { if (v.a >= desc->num_advice) { err = "advice column out of range"; return false; } col = desc->num_fixed + v.a; }
-                else { if (v.a >= desc->num_instance) { err = "instance column out of range"; return false; } col = desc->num_fixed + desc->num_advice + v.a; }
+                uint32_t c;
+                if (v.kind == 2) { if (v.a >= desc->num_fixed) { err = "fixed column out of range"; return false; } c = v.a; }
+                else if (v.kind == 3) { if (v.a >= desc->num_advice) { err = "advice column out of range"; return false; } c = desc->num_fixed + v.a; }
+                else { if (v.a >= desc->num_instance) { err = "instance column out of range"; return false; } c = desc->num_fixed + desc->num_advice + v.a; }
                 if (v.b >= g->num_rotations) { err = "rotation index out of range"; return false; }
-                if (col >= (1u << 16) || v.b >= (1u << 12)) { err = "too many columns or rotations"; return false; }
-                word = (K_COL << 28) | (col << 12) | v.b;
+                word = b.col(c, g->rotations[v.b]);
                 return true;
             }
             case 5:
                 if (v.a >= desc->num_challenges) { err = "challenge index out of range"; return false; }
-                word = (K_SCALAR << 28) | (SC_CHALLENGE0 + v.a);
+                word = Builder::scalar(SC_CHALLENGE0 + v.a);
                 return true;
-            case 6: word = (K_SCALAR << 28) | SC_BETA; return true;
-            case 7: word = (K_SCALAR << 28) | SC_GAMMA; return true;
-            case 8: word = (K_SCALAR << 28) | SC_THETA; return true;
-            case 9: word = (K_SCALAR << 28) | SC_Y; return true;
-            case 10: word = (K_PREV << 28); return true;
+            case 6: word = Builder::scalar(SC_BETA); return true;
+            case 7: word = Builder::scalar(SC_GAMMA); return true;
+            case 8: word = Builder::scalar(SC_THETA); return true;
+            case 9: word = Builder::scalar(SC_Y); return true;
+            case 10: word = is_gates ? W_ACC : W_ZERO; return true;   // previous_value: values[idx] for gates, ZERO for lookups
             default: err = "unknown ValueSource kind"; return false;
         }
     }
-    void emit(uint32_t op, uint32_t dst, uint32_t a, uint32_t b = K_ZERO << 28, uint32_t c = K_ZERO << 28) {
-        words.push_back(op | (dst << 8));
-        words.push_back(a);
-        words.push_back(b);
-        words.push_back(c);
-    }
-    // iterative post-order: make calculation `t` available
+
+    // iterative post-order: make calculation `t_root` available
     bool schedule(uint32_t t_root) {
         struct Frame { uint32_t t; uint32_t stage; };
         std::vector<Frame> st;
         st.push_back({t_root, 0});
         while (!st.empty()) {
-            Frame& f = st.back();
-            const uint32_t t = f.t;
+            const uint32_t t = st.back().t;
             if (done[t]) { st.pop_back(); continue; }
             Calc& c = calcs[t];
-            // collect intermediate dependencies in evaluation order
             auto dep = [&](const VS& v) -> bool {
                 if (v.kind == 1 && v.a < calcs.size() && !done[v.a]) {
                     if (v.a >= t) { err = "calculation depends on a later one"; return true; }
@@ -328,41 +266,40 @@ struct Lowering {
                 for (int k = 0; k < ns && !pushed; k++) pushed = dep(c.src[k]);
                 if (!err.empty()) return false;
                 if (pushed) continue;
-                uint32_t a, b = K_ZERO << 28;
-                if (!operand(c.src[0], a)) return false;
-                if (ns == 2 && !operand(c.src[1], b)) return false;
-                if (c.op == 7) {   // Store: alias the source
-                    val[t] = a;
-                } else {
-                    const uint32_t dst = n_virtual++;
-                    static const uint32_t map[6] = {D_ADD, D_SUB, D_MUL, D_SQR, D_DBL, D_NEG};
-                    emit(map[c.op], dst, a, b);
-                    val[t] = (K_SLOT << 28) | dst;
+                uint32_t x, y = W_ZERO;
+                if (!operand(c.src[0], x)) return false;
+                if (ns == 2 && !operand(c.src[1], y)) return false;
+                switch (c.op) {
+                    case 0: val[t] = b.add(x, y); break;
+                    case 1: val[t] = b.sub(x, y); break;
+                    case 2: val[t] = b.mul(x, y); break;
+                    case 3: val[t] = b.mul(x, x); break;
+                    case 4: val[t] = b.add(x, x); break;
+                    case 5: val[t] = b.sub(W_ZERO, x); break;
+                    default: val[t] = x; break;   // Store: alias the source
                 }
                 done[t] = 1;
                 st.pop_back();
             } else {
-                // Horner: stage 0 = start/factor deps, then one part at a time
-                const bool is_root = (t == root);
-                if (f.stage == 0) {
+                // Horner: stage 0 = start / factor dependencies, then one part at a time
+                const bool to_acc = is_gates && t == root;
+                if (st.back().stage == 0) {
                     if (dep(c.start) || dep(c.factor)) { if (!err.empty()) return false; continue; }
                     uint32_t s;
                     if (!operand(c.start, s)) return false;
-                    const uint32_t dst = is_root ? DST_ACC : n_virtual++;
-                    c.src[0].kind = dst;   // remember the accumulator (reusing the unused src slot)
-                    if (!(is_root && c.start.kind == 10)) emit(D_MOV, dst, s);   // the root accumulator starts as previous_value
-                    f.stage = 1;
+                    c.acc_dst = to_acc ? DST_ACC : b.fresh();
+                    if (!(to_acc && s == W_ACC)) b.emit(0, c.acc_dst, s);   // the running value already holds previous_value
+                    st.back().stage = 1;
                 }
-                const uint32_t dst = c.src[0].kind;
-                const uint32_t accw = (dst == DST_ACC) ? (K_ACC << 28) : ((K_SLOT << 28) | dst);
+                const uint32_t accw = (c.acc_dst == DST_ACC) ? W_ACC : Builder::slot(c.acc_dst);
                 bool pushed = false;
-                while (f.stage - 1 < c.parts.size()) {
-                    const VS& p = c.parts[f.stage - 1];
+                while (st.back().stage - 1 < c.parts.size()) {
+                    const VS& p = c.parts[st.back().stage - 1];
                     if (dep(p)) { pushed = true; break; }
                     uint32_t pw, fw;
                     if (!operand(p, pw) || !operand(c.factor, fw)) return false;
-                    emit(D_MULADD, dst, accw, fw, pw);
-                    st.back().stage++;   // `f` may dangle after push_back; index through st.back()
+                    b.emit(F_MUL | F_ADD, c.acc_dst, accw, fw, pw);
+                    st.back().stage++;
                 }
                 if (!err.empty()) return false;
                 if (pushed) continue;
@@ -373,12 +310,23 @@ struct Lowering {
         }
         return true;
     }
+
+    // returns the operand word of the graph's value (W_ACC for a gates graph rooted in a Horner)
+    bool run(uint32_t& result) {
+        if (!parse_graph(g, calcs, err)) return false;
+        const_base = (uint32_t)(b.consts.size() / 4);
+        if (g->num_constants) b.consts.insert(b.consts.end(), g->constants, g->constants + (size_t)g->num_constants * 4);
+        if (calcs.empty()) { result = W_ZERO; return true; }
+        val.assign(calcs.size(), 0);
+        done.assign(calcs.size(), 0);
+        root = (uint32_t)calcs.size() - 1;
+        if (!schedule(root)) return false;
+        result = val[root];
+        return true;
+    }
 };
 
-// liveness-based slot assignment; the `lds_slots` slots with the smallest average gap between accesses stay on chip
-// lds_budget: LDS slots the caller is willing to give one lane.  Returns through lds_slots_out the number actually
-// used (the peak number of simultaneously live values when that is smaller), so the launch reserves no more LDS than
-// the program needs and more workgroups fit on a CU.
+// Liveness-based slot assignment.  lds_budget: LDS slots one lane may use; the program gets min(peak, budget).
 static void assign_slots(std::vector<uint32_t>& words, uint32_t& result, uint32_t n_virtual, uint32_t lds_budget,
                          uint32_t& lds_slots_out, uint32_t& n_slots_out) {
     const size_t ni = words.size() / 4;
@@ -395,7 +343,6 @@ static void assign_slots(std::vector<uint32_t>& words, uint32_t& result, uint32_
         if (dst != DST_ACC) touch(dst, (uint32_t)pc);
     }
     if ((result >> 28) == K_SLOT) touch(result & 0x0fffffffu, (uint32_t)ni);
-    // gap metric; sort candidates for demotion by decreasing gap
     std::vector<uint32_t> order(n_virtual);
     for (uint32_t v = 0; v < n_virtual; v++) order[v] = v;
     auto gap = [&](uint32_t v) { return (double)(last[v] - first[v] + 1) / (double)std::max(1u, uses[v]); };
@@ -413,7 +360,7 @@ static void assign_slots(std::vector<uint32_t>& words, uint32_t& result, uint32_
     const uint32_t lds_slots = std::max(1u, std::min(peak, lds_budget));
     lds_slots_out = lds_slots;
     if (peak > lds_slots) {
-        // smallest prefix of `order` whose demotion brings the on-chip pressure within budget
+        // smallest prefix of `order` (largest access gaps first) whose demotion fits the rest on chip
         size_t lo = 0, hi = n_virtual;
         while (lo < hi) {
             const size_t mid = (lo + hi) / 2;
@@ -425,14 +372,13 @@ static void assign_slots(std::vector<uint32_t>& words, uint32_t& result, uint32_
         std::fill(spilled.begin(), spilled.end(), 0);
         for (size_t i = 0; i < lo; i++) spilled[order[i]] = 1;
     }
-    // linear scan within each class
     std::vector<uint32_t> phys(n_virtual, 0);
-    std::vector<std::vector<uint32_t>> expire(ni + 2);
+    std::vector<std::vector<uint32_t>> expire(ni + 2), begin(ni + 2);
     for (uint32_t v = 0; v < n_virtual; v++)
-        if (first[v] != UINT32_MAX) expire[last[v] + 1].push_back(v);
-    std::vector<std::vector<uint32_t>> begin(ni + 2);
-    for (uint32_t v = 0; v < n_virtual; v++)
-        if (first[v] != UINT32_MAX) begin[first[v]].push_back(v);
+        if (first[v] != UINT32_MAX) {
+            expire[last[v] + 1].push_back(v);
+            begin[first[v]].push_back(v);
+        }
     std::vector<uint32_t> free_lds, free_sp;
     uint32_t next_lds = 0, next_sp = 0;
     for (size_t pc = 0; pc <= ni; pc++) {
@@ -459,45 +405,6 @@ static void assign_slots(std::vector<uint32_t>& words, uint32_t& result, uint32_
     n_slots_out = lds_slots + next_sp;
 }
 
-static int lower_graph(zkhip_ctx* ctx, const zkhip_graph* g, const zkhip_evalh_desc* desc, uint32_t lds_budget, Program& out) {
-    Lowering lw;
-    lw.g = g;
-    lw.desc = desc;
-    if (!parse_graph(g, lw.calcs, lw.err)) return set_error(ctx, ZKHIP_ERR_INVALID, "evaluate_h: %s", lw.err.c_str());
-    if (lw.calcs.empty()) {
-        out.result = K_ZERO << 28;
-        out.lds_slots = 1;
-        return ZKHIP_OK;
-    }
-    lw.val.assign(lw.calcs.size(), 0);
-    lw.done.assign(lw.calcs.size(), 0);
-    lw.root = (uint32_t)lw.calcs.size() - 1;
-    if (!lw.schedule(lw.root)) return set_error(ctx, ZKHIP_ERR_INVALID, "evaluate_h: %s", lw.err.c_str());
-    out.words.swap(lw.words);
-    out.result = lw.val[lw.root];
-    ZK_CHECK(ctx, lw.n_virtual < DST_ACC, "evaluate_h: program too large");
-    uint32_t lds_slots = 1;
-    assign_slots(out.words, out.result, lw.n_virtual, lds_budget, lds_slots, out.n_slots);
-    out.lds_slots = lds_slots;
-    if (getenv("ZKHIP_DEBUG")) {
-        size_t nmul = 0, ncol = 0, nspill = 0;
-        for (size_t pc = 0; pc < out.words.size() / 4; pc++) {
-            const uint32_t op = out.words[4 * pc] & 0xff;
-            if (op == D_MUL || op == D_SQR || op == D_MULADD) nmul++;
-            for (int k = 1; k <= 3; k++) {
-                const uint32_t w = out.words[4 * pc + k];
-                if ((w >> 28) == K_COL) ncol++;
-                if ((w >> 28) == K_SLOT && (w & 0x0fffffffu) >= lds_slots) nspill++;
-            }
-            const uint32_t dst = out.words[4 * pc] >> 8;
-            if (dst != DST_ACC && dst >= lds_slots) nspill++;
-        }
-        fprintf(stderr, "[zkhip] graph: %u calculations -> %zu instructions (%zu multiplications, %zu column reads, %zu spill accesses), %u virtual values, %u slots (%u in LDS)\n",
-                g->num_calculations, out.words.size() / 4, nmul, ncol, nspill, lw.n_virtual, out.n_slots, lds_slots);
-    }
-    return ZKHIP_OK;
-}
-
 // ---- device buffer bookkeeping for one call -----------------------------------------------------------
 struct Arena {
     zkhip_ctx* ctx;
@@ -515,11 +422,15 @@ struct Arena {
         void* d;
         int rc = alloc(count * sizeof(T), &d);
         if (rc) return rc;
-        ZK_HIP(ctx, hipMemcpyAsync(d, host, count * sizeof(T), hipMemcpyHostToDevice, ctx->stream));
+        if (count) ZK_HIP(ctx, hipMemcpyAsync(d, host, count * sizeof(T), hipMemcpyHostToDevice, ctx->stream));
         *out = (T*)d;
         return ZKHIP_OK;
     }
 };
+
+static bool graph_arrays_ok(const zkhip_graph* g) {
+    return (g->constants || !g->num_constants) && (g->rotations || !g->num_rotations) && (g->calc_words || !g->num_calc_words);
+}
 
 }  // namespace zkhip
 
@@ -584,33 +495,171 @@ extern "C" int zkhip_evaluate_h(zkhip_domain* dom, const zkhip_evalh_desc* desc,
         return ZKHIP_OK;
     };
 
-    // unified column table: fixed | advice | instance
-    const uint32_t ncols = desc->num_fixed + desc->num_advice + desc->num_instance;
-    std::vector<const fe*> cols(ncols ? ncols : 1, nullptr);
+    // ---- unified column table: fixed | advice | instance | l0 l_last l_active | X | perm z | perm sigma | lookups ----
+    std::vector<const fe*> cols;
+    auto push = [&](const uint64_t* p, bool ext_in) -> int {
+        const fe* d;
+        int r = resolve(p, ext_in, &d);
+        if (r) return r;
+        cols.push_back(d);
+        return ZKHIP_OK;
+    };
     for (uint32_t i = 0; i < desc->num_fixed; i++)
-        if ((rc = resolve(desc->fixed_cosets[i], true, &cols[i]))) return rc;
+        if ((rc = push(desc->fixed_cosets[i], true))) return rc;
     for (uint32_t i = 0; i < desc->num_advice; i++)
-        if ((rc = resolve(desc->advice[i], !coeff, &cols[desc->num_fixed + i]))) return rc;
+        if ((rc = push(desc->advice[i], !coeff))) return rc;
     for (uint32_t i = 0; i < desc->num_instance; i++)
-        if ((rc = resolve(desc->instance[i], !coeff, &cols[desc->num_fixed + desc->num_advice + i]))) return rc;
-    const fe** d_cols;
-    if ((rc = ar.upload(cols.data(), cols.size(), &d_cols))) return rc;
-    const fe *d_l0, *d_l_last, *d_l_active;
-    if ((rc = resolve(desc->l0, true, &d_l0))) return rc;
-    if ((rc = resolve(desc->l_last, true, &d_l_last))) return rc;
-    if ((rc = resolve(desc->l_active_row, true, &d_l_active))) return rc;
+        if ((rc = push(desc->instance[i], !coeff))) return rc;
+    const uint32_t c_l0 = (uint32_t)cols.size();
+    if ((rc = push(desc->l0, true)) || (rc = push(desc->l_last, true)) || (rc = push(desc->l_active_row, true))) return rc;
+    const uint32_t c_last = c_l0 + 1, c_active = c_l0 + 2;
 
-    // scalar table
-    std::vector<uint64_t> scal((SC_CHALLENGE0 + desc->num_challenges) * 4);
+    Builder b;
+    const uint32_t ONE = Builder::scalar(SC_ONE), BETA = Builder::scalar(SC_BETA), GAMMA = Builder::scalar(SC_GAMMA);
+    // ---- 1. custom gates -----------------------------------------------------------------------------
+    if (desc->custom_gates) {
+        const zkhip_graph* g = desc->custom_gates;
+        ZK_CHECK(ctx, graph_arrays_ok(g), "evaluate_h: graph arrays missing");
+        Lowering lw(b, g, desc, true);
+        uint32_t res;
+        if (!lw.run(res)) return set_error(ctx, ZKHIP_ERR_INVALID, "evaluate_h: %s", lw.err.c_str());
+        if (res != W_ACC) b.emit(0, DST_ACC, res);   // a gates graph whose value is not the running Horner
+    }
+
+    // ---- 2. permutation argument ---------------------------------------------------------------------
+    std::vector<uint64_t> extra_scalars;   // after the challenges: beta * delta^c per permutation column
+    const uint32_t sc_perm0 = SC_CHALLENGE0 + desc->num_challenges;
+    if (desc->num_perm_sets) {
+        if (!dom->d_xpoints) {
+            ZK_HIP(ctx, hipMalloc(&dom->d_xpoints, size * 32));
+            hipLaunchKernelGGL(xpoints_kernel, dim3((unsigned)((size + 255) / 256)), dim3(256), 0, ctx->stream,
+                               (fe*)dom->d_xpoints, (const fe*)dom->plan_ext_fwd->d_lo, (const fe*)dom->plan_ext_fwd->d_hi,
+                               dom->plan_ext_fwd->h, (uint32_t)size);
+            ZK_HIP(ctx, hipGetLastError());
+        }
+        const uint32_t c_x = (uint32_t)cols.size();
+        cols.push_back((const fe*)dom->d_xpoints);
+        const uint32_t c_z0 = (uint32_t)cols.size();
+        for (uint32_t s = 0; s < desc->num_perm_sets; s++)
+            if ((rc = push(desc->perm_product_cosets[s], true))) return rc;
+        const uint32_t c_sigma0 = (uint32_t)cols.size();
+        std::vector<uint32_t> pcol(desc->num_perm_columns);
+        for (uint32_t c = 0; c < desc->num_perm_columns; c++) {
+            if ((rc = push(desc->perm_sigma_cosets[c], true))) return rc;
+            const uint32_t kind = desc->perm_column_kind[c], ci = desc->perm_column_index[c];
+            if (kind == 2) { ZK_CHECK(ctx, ci < desc->num_fixed, "evaluate_h: permutation fixed column out of range"); pcol[c] = ci; }
+            else if (kind == 3) { ZK_CHECK(ctx, ci < desc->num_advice, "evaluate_h: permutation advice column out of range"); pcol[c] = desc->num_fixed + ci; }
+            else if (kind == 4) { ZK_CHECK(ctx, ci < desc->num_instance, "evaluate_h: permutation instance column out of range"); pcol[c] = desc->num_fixed + desc->num_advice + ci; }
+            else return set_error(ctx, ZKHIP_ERR_INVALID, "evaluate_h: permutation column kind %u", kind);
+        }
+        // current_delta of column c on row idx = beta * zeta * extended_omega^idx * delta^c = (beta * delta^c) * X[idx]
+        uint64_t cur[4], delta[4];
+        memcpy(delta, FrParams::DELTA, 32);
+        memcpy(cur, desc->beta, 32);
+        for (uint32_t c = 0; c < desc->num_perm_columns; c++) {
+            extra_scalars.insert(extra_scalars.end(), cur, cur + 4);
+            h_mul(HFR, cur, cur, delta);
+        }
+        const int32_t last_rot = -((int32_t)desc->blinding_factors + 1);
+        const uint32_t nsets = desc->num_perm_sets;
+        // l_0(X) * (1 - z_0(X))
+        b.fold(b.mul(b.sub(ONE, b.col(c_z0, 0)), b.col(c_l0, 0)));
+        // l_last(X) * (z_l(X)^2 - z_l(X))
+        {
+            const uint32_t zl = b.col(c_z0 + nsets - 1, 0);
+            b.fold(b.mul(b.mul_sub(zl, zl, zl), b.col(c_last, 0)));
+        }
+        // l_0(X) * (z_i(X) - z_{i-1}(omega^last X))
+        for (uint32_t s = 1; s < nsets; s++)
+            b.fold(b.mul(b.sub(b.col(c_z0 + s, 0), b.col(c_z0 + s - 1, last_rot)), b.col(c_l0, 0)));
+        // l_active(X) * (z_i(omega X) prod (p + beta s_j + gamma) - z_i(X) prod (p + delta^j beta X + gamma))
+        for (uint32_t s = 0; s < nsets; s++) {
+            const uint32_t c0 = s * desc->perm_chunk_len, c1 = std::min(c0 + desc->perm_chunk_len, desc->num_perm_columns);
+            uint32_t left = b.col(c_z0 + s, 1), right = b.col(c_z0 + s, 0);
+            for (uint32_t c = c0; c < c1; c++) {
+                const uint32_t val = b.col(pcol[c], 0);
+                left = b.mul(left, b.add(b.mul_add(BETA, b.col(c_sigma0 + c, 0), val), GAMMA));
+                right = b.mul(right, b.add(b.mul_add(b.col(c_x, 0), Builder::scalar(sc_perm0 + c), val), GAMMA));
+            }
+            b.fold(b.mul(b.sub(left, right), b.col(c_active, 0)));
+        }
+    }
+
+    // ---- 3. lookup arguments -------------------------------------------------------------------------
+    for (uint32_t i = 0; i < desc->num_lookups; i++) {
+        const zkhip_lookup& lk = desc->lookups[i];
+        const zkhip_graph* g = &lk.graph;
+        ZK_CHECK(ctx, graph_arrays_ok(g), "evaluate_h: graph arrays missing");
+        const uint32_t c_z = (uint32_t)cols.size();
+        if ((rc = push(lk.product, !coeff)) || (rc = push(lk.permuted_input, !coeff)) || (rc = push(lk.permuted_table, !coeff)))
+            return rc;
+        const uint32_t c_a = c_z + 1, c_s = c_z + 2;
+        Lowering lw(b, g, desc, false);
+        uint32_t table_value;
+        if (!lw.run(table_value)) return set_error(ctx, ZKHIP_ERR_INVALID, "evaluate_h: %s", lw.err.c_str());
+        const uint32_t Z = b.col(c_z, 0), A = b.col(c_a, 0), S = b.col(c_s, 0);
+        const uint32_t a_minus_s = b.sub(A, S);
+        // l_0(X) * (1 - z(X))
+        b.fold(b.mul(b.sub(ONE, Z), b.col(c_l0, 0)));
+        // l_last(X) * (z(X)^2 - z(X))
+        b.fold(b.mul(b.mul_sub(Z, Z, Z), b.col(c_last, 0)));
+        // l_active(X) * (z(omega X) (a'(X) + beta) (s'(X) + gamma) - z(X) * table_value)
+        {
+            const uint32_t left = b.mul(b.mul(b.col(c_z, 1), b.add(A, BETA)), b.add(S, GAMMA));
+            const uint32_t diff = b.sub(left, b.mul(Z, table_value));
+            b.fold(b.mul(diff, b.col(c_active, 0)));
+        }
+        // l_0(X) * (a'(X) - s'(X))
+        b.fold(b.mul(a_minus_s, b.col(c_l0, 0)));
+        // l_active(X) * (a'(X) - s'(X)) * (a'(X) - a'(omega^-1 X))
+        b.fold(b.mul(b.mul(a_minus_s, b.sub(A, b.col(c_a, -1))), b.col(c_active, 0)));
+    }
+    ZK_CHECK(ctx, cols.size() < (1u << 16) && b.rots.size() < (1u << 12), "evaluate_h: too many columns or rotations");
+    ZK_CHECK(ctx, b.n_virtual < DST_ACC, "evaluate_h: program too large");
+
+    // ---- slots, tables, launch -----------------------------------------------------------------------
+    // LDS budget per lane: 6 slots of 32 B keep three 256-lane workgroups on a CU (the register file allows three)
+    const char* env_slots = getenv("ZKHIP_EVALH_LDS_SLOTS");
+    const uint32_t lds_budget = env_slots && *env_slots ? (uint32_t)atoi(env_slots) : 6;
+    uint32_t result = W_ACC, lds_slots = 1, n_slots = 1;
+    assign_slots(b.words, result, b.n_virtual, lds_budget, lds_slots, n_slots);
+    if (getenv("ZKHIP_DEBUG")) {
+        size_t nmul = 0, ncol = 0, nspill = 0;
+        for (size_t pc = 0; pc < b.words.size() / 4; pc++) {
+            if (b.words[4 * pc] & F_MUL) nmul++;
+            for (int q = 1; q <= 3; q++) {
+                const uint32_t w = b.words[4 * pc + q];
+                if ((w >> 28) == K_COL) ncol++;
+                if ((w >> 28) == K_SLOT && (w & 0x0fffffffu) >= lds_slots) nspill++;
+            }
+            const uint32_t dst = b.words[4 * pc] >> 8;
+            if (dst != DST_ACC && dst >= lds_slots) nspill++;
+        }
+        fprintf(stderr, "[zkhip] evaluate_h program: %zu instructions (%zu multiplications, %zu column reads, %zu spill accesses), "
+                        "%zu columns, %zu rotations, %u values -> %u slots (%u in LDS)\n",
+                b.words.size() / 4, nmul, ncol, nspill, cols.size(), b.rots.size(), b.n_virtual, n_slots, lds_slots);
+    }
+
+    std::vector<uint64_t> scal((size_t)(SC_CHALLENGE0 + desc->num_challenges) * 4);
     memcpy(&scal[4 * SC_BETA], desc->beta, 32);
     memcpy(&scal[4 * SC_GAMMA], desc->gamma, 32);
     memcpy(&scal[4 * SC_THETA], desc->theta, 32);
     memcpy(&scal[4 * SC_Y], desc->y, 32);
+    memcpy(&scal[4 * SC_ONE], HFR.r, 32);
     if (desc->num_challenges) memcpy(&scal[4 * SC_CHALLENGE0], desc->challenges, (size_t)desc->num_challenges * 32);
-    fe* d_scal;
-    if ((rc = ar.upload((const fe*)scal.data(), scal.size() / 4, &d_scal))) return rc;
+    scal.insert(scal.end(), extra_scalars.begin(), extra_scalars.end());
 
-    // output buffer
+    InterpArgs a;
+    memset(&a, 0, sizeof a);
+    uint32_t* d_prog;
+    fe *d_scal, *d_consts;
+    int32_t* d_rots;
+    const fe** d_cols;
+    if ((rc = ar.upload(b.words.data(), b.words.size(), &d_prog))) return rc;
+    if ((rc = ar.upload((const fe*)scal.data(), scal.size() / 4, &d_scal))) return rc;
+    if ((rc = ar.upload((const fe*)b.consts.data(), b.consts.size() / 4, &d_consts))) return rc;
+    if ((rc = ar.upload(b.rots.data(), b.rots.size(), &d_rots))) return rc;
+    if ((rc = ar.upload(cols.data(), cols.size(), &d_cols))) return rc;
     fe* d_out;
     if (host) {
         void* p;
@@ -619,122 +668,31 @@ extern "C" int zkhip_evaluate_h(zkhip_domain* dom, const zkhip_evalh_desc* desc,
     } else {
         d_out = (fe*)out;
     }
-    ZK_HIP(ctx, hipMemsetAsync(d_out, 0, size * 32, ctx->stream));
-
-    // LDS budget per lane: 6 slots of 32 B keep three 256-lane workgroups on a CU (the register file allows three)
-    const char* env_slots = getenv("ZKHIP_EVALH_LDS_SLOTS");
-    const uint32_t lds_budget = env_slots && *env_slots ? (uint32_t)atoi(env_slots) : 6;
-    const dim3 grid((unsigned)((size + EV_THREADS - 1) / EV_THREADS));
+    a.prog = d_prog;
+    a.n_instr = (uint32_t)(b.words.size() / 4);
+    a.result = result;
+    a.consts = d_consts;
+    a.scalars = d_scal;
+    a.cols = d_cols;
+    a.rots = d_rots;
+    a.lds_slots = lds_slots;
+    if (n_slots > lds_slots) {
+        void* sp;
+        if ((rc = ar.alloc((size_t)(n_slots - lds_slots) * size * 32, &sp))) return rc;
+        a.spill = (fe*)sp;
+    }
+    a.log_size = ek;
+    a.rot_scale = 1u << (ek - k);
+    a.out = d_out;
+    const size_t lds_bytes = (size_t)lds_slots * EV_THREADS * sizeof(fe);
     ZK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(evalh_interp_kernel),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-
-    auto run_graph = [&](const zkhip_graph* g, uint32_t mode, const fe* prod, const fe* pin, const fe* ptab,
-                         const char* family) -> int {
-        ZK_CHECK(ctx, (g->constants || !g->num_constants) && (g->rotations || !g->num_rotations) &&
-                          (g->calc_words || !g->num_calc_words),
-                 "evaluate_h: graph arrays missing");
-        Program prog;
-        int r = lower_graph(ctx, g, desc, lds_budget, prog);
-        if (r) return r;
-        const uint32_t lds_slots = prog.lds_slots;
-        const size_t lds_bytes = (size_t)lds_slots * EV_THREADS * sizeof(fe);
-        InterpArgs a;
-        memset(&a, 0, sizeof a);
-        uint32_t* d_prog;
-        if ((r = ar.upload(prog.words.data(), prog.words.size(), &d_prog))) return r;
-        fe* d_consts;
-        if ((r = ar.upload((const fe*)g->constants, g->num_constants, &d_consts))) return r;
-        int32_t* d_rots;
-        if ((r = ar.upload(g->rotations, g->num_rotations, &d_rots))) return r;
-        a.prog = d_prog;
-        a.n_instr = (uint32_t)(prog.words.size() / 4);
-        a.result = prog.result;
-        a.consts = d_consts;
-        a.scalars = d_scal;
-        a.cols = d_cols;
-        a.rots = d_rots;
-        a.lds_slots = lds_slots;
-        if (prog.n_slots > lds_slots) {
-            void* sp;
-            if ((r = ar.alloc((size_t)(prog.n_slots - lds_slots) * size * 32, &sp))) return r;
-            a.spill = (fe*)sp;
-        }
-        a.log_size = ek;
-        a.rot_scale = 1u << (ek - k);
-        a.out = d_out;
-        a.mode = mode;
-        a.product = prod;
-        a.permuted_input = pin;
-        a.permuted_table = ptab;
-        a.l0 = d_l0;
-        a.l_last = d_l_last;
-        a.l_active = d_l_active;
-        TimedRegion tr(ctx, family);
-        hipLaunchKernelGGL(evalh_interp_kernel, grid, dim3(EV_THREADS), lds_bytes, ctx->stream, a);
-        ZK_HIP(ctx, hipGetLastError());
-        return ZKHIP_OK;
-    };
-
-    // 1. custom gates
-    if (desc->custom_gates) {
-        rc = run_graph(desc->custom_gates, 0, nullptr, nullptr, nullptr, "evalh_gates");
-        if (rc) return rc;
-    }
-
-    // 2. permutation argument
-    if (desc->num_perm_sets) {
-        std::vector<const fe*> z(desc->num_perm_sets), sigma(desc->num_perm_columns), colp(desc->num_perm_columns);
-        for (uint32_t s = 0; s < desc->num_perm_sets; s++)
-            if ((rc = resolve(desc->perm_product_cosets[s], true, &z[s]))) return rc;
-        for (uint32_t c = 0; c < desc->num_perm_columns; c++) {
-            if ((rc = resolve(desc->perm_sigma_cosets[c], true, &sigma[c]))) return rc;
-            const uint32_t kind = desc->perm_column_kind[c], ci = desc->perm_column_index[c];
-            uint32_t u;
-            if (kind == 2) { ZK_CHECK(ctx, ci < desc->num_fixed, "evaluate_h: permutation fixed column out of range"); u = ci; }
-            else if (kind == 3) { ZK_CHECK(ctx, ci < desc->num_advice, "evaluate_h: permutation advice column out of range"); u = desc->num_fixed + ci; }
-            else if (kind == 4) { ZK_CHECK(ctx, ci < desc->num_instance, "evaluate_h: permutation instance column out of range"); u = desc->num_fixed + desc->num_advice + ci; }
-            else return set_error(ctx, ZKHIP_ERR_INVALID, "evaluate_h: permutation column kind %u", kind);
-            colp[c] = cols[u];
-        }
-        PermArgs pa;
-        memset(&pa, 0, sizeof pa);
-        const fe **d_z, **d_sigma, **d_colp;
-        if ((rc = ar.upload(z.data(), z.size(), &d_z))) return rc;
-        if ((rc = ar.upload(sigma.data(), sigma.size(), &d_sigma))) return rc;
-        if ((rc = ar.upload(colp.data(), colp.size(), &d_colp))) return rc;
-        pa.out = d_out;
-        pa.z = d_z;
-        pa.sigma = d_sigma;
-        pa.colptr = d_colp;
-        pa.nsets = desc->num_perm_sets;
-        pa.ncols = desc->num_perm_columns;
-        pa.chunk = desc->perm_chunk_len;
-        pa.last_rot = -((int32_t)desc->blinding_factors + 1);
-        pa.l0 = d_l0;
-        pa.l_last = d_l_last;
-        pa.l_active = d_l_active;
-        pa.scalars = d_scal;
-        pa.om_lo = (const fe*)dom->plan_ext_fwd->d_lo;
-        pa.om_hi = (const fe*)dom->plan_ext_fwd->d_hi;
-        pa.om_h = dom->plan_ext_fwd->h;
-        pa.log_size = ek;
-        pa.rot_scale = 1u << (ek - k);
-        TimedRegion tr(ctx, "evalh_perm");
-        hipLaunchKernelGGL(evalh_perm_kernel, grid, dim3(EV_THREADS), 0, ctx->stream, pa);
+    {
+        TimedRegion tr(ctx, "evalh");
+        hipLaunchKernelGGL(evalh_interp_kernel, dim3((unsigned)((size + EV_THREADS - 1) / EV_THREADS)), dim3(EV_THREADS),
+                           lds_bytes, ctx->stream, a);
         ZK_HIP(ctx, hipGetLastError());
     }
-
-    // 3. lookups, one at a time (their three cosets only live for the duration of their pass)
-    for (uint32_t i = 0; i < desc->num_lookups; i++) {
-        const zkhip_lookup& lk = desc->lookups[i];
-        const fe *prod, *pin, *ptab;
-        if ((rc = resolve(lk.product, !coeff, &prod))) return rc;
-        if ((rc = resolve(lk.permuted_input, !coeff, &pin))) return rc;
-        if ((rc = resolve(lk.permuted_table, !coeff, &ptab))) return rc;
-        rc = run_graph(&lk.graph, 1, prod, pin, ptab, "evalh_lookup");
-        if (rc) return rc;
-    }
-
     if (host) ZK_HIP(ctx, hipMemcpyAsync(out, d_out, size * 32, hipMemcpyDeviceToHost, ctx->stream));
     ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return ZKHIP_OK;
