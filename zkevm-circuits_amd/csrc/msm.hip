@@ -11,11 +11,16 @@
 //                           "digit 1" of witness-like scalars never touch a contended global atomic)
 //   2. scan               : exclusive scan of the [bucket][block] count matrix -> scatter offsets
 //   3. scatter            : the same blocks place (point, window, sign) entries with LDS-private cursors
-//   4. accumulate         : one lane per (bucket, slot of <= L entries): gathers table points, XYZZ mixed adds
-//   5. merge              : per bucket, the slot partial sums are folded F at a time until one remains
-//   6. reduce             : every lane multiplies its bucket sum by its weight (b + 1) and a block tree-sum in
-//                           LDS folds 512 buckets; the <= 64 block sums are added on the host
+//   4. accumulate         : one lane per (bucket, slot): a bucket of cnt entries is split into ceil(cnt / L) slots of
+//                           equal share; L is planned per MSM so that the slots fill a whole number of rounds of
+//                           the chip.  Each lane gathers its table points and folds them with XYZZ mixed additions
+//   5. merge              : per bucket, two lanes fold the slot sums and join by a shuffle (heavy buckets of skewed
+//                           scalars first pass through serial pre-levels of 16 sums per lane)
+//   6. reduce             : sum (b + 1) S_b without scalar multiplications: per wave of 64 buckets a suffix scan by
+//                           shuffles gives sum P_i and sum i P_i in 12 additions; a second level does the same for
+//                           the 512 wave sums and the host joins the 24 leftover points
 #include <algorithm>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include "common.h"
@@ -118,75 +123,185 @@ __global__ void __launch_bounds__(HIST_THREADS) scatter_kernel(const fe* scalars
     }
 }
 
-// ---- scans -----------------------------------------------------------------------------------------
-__device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t* lds /*[blockDim]*/, uint32_t* total) {
-    const uint32_t tid = threadIdx.x, nt = blockDim.x;
-    lds[tid] = v;
-    __syncthreads();
-    for (uint32_t off = 1; off < nt; off <<= 1) {
-        uint32_t t = (tid >= off) ? lds[tid - off] : 0;
-        __syncthreads();
-        lds[tid] += t;
-        __syncthreads();
+// ---- scans and the slot plan ------------------------------------------------------------------------
+// A bucket of cnt entries is folded by f = ceil(cnt / L) lanes ("slots") of near-equal share.  The accumulate phase
+// takes rounds * L additions per SIMD, where rounds = ceil(total slots / one slot per lane of the chip): L is picked
+// per MSM from a ladder of candidates (2.5 % apart) so that the slots just fill a whole number of rounds.
+constexpr uint32_t L_MAX = 256;
+constexpr uint32_t PLAN_STRIDE = 128;   // words per block in the plan statistics: [0] max cnt, [1] entries, [2 + i] slots(L_i)
+enum { INFO_SLOTS = 0, INFO_MAXCNT = 1, INFO_L = 2, INFO_ENTRIES = 3 };
+ZK_DEV uint32_t next_slot_len(uint32_t L) { return L + (L < 40 ? 1 : L / 40); }
+
+__device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+    return v;
+}
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
+    for (int d = 32; d >= 1; d >>= 1) {
+        const uint32_t o = __shfl_xor(v, d, 64);
+        v = o > v ? o : v;
     }
-    const uint32_t incl = lds[tid];
-    if (total) *total = lds[nt - 1];
-    __syncthreads();
-    return incl - v;
+    return v;
 }
 
-// counts[g][b] -> exclusive prefix over g (in place), cnt[b] = bucket size.  One lane per bucket, coalesced over b.
-__global__ void __launch_bounds__(256) column_scan_kernel(uint32_t* counts /*[G][B]*/, uint32_t G, uint32_t B, uint32_t* cnt) {
+// counts[g][b] -> exclusive prefix over g (in place), cnt[b] = bucket size; one lane per bucket, coalesced over b.
+// Each block also leaves its share of the plan statistics in plan[blockIdx.x][*].
+__global__ void __launch_bounds__(256) column_scan_kernel(uint32_t* counts /*[G][B]*/, uint32_t G, uint32_t B, uint32_t* cnt,
+                                                          uint32_t l_min, uint32_t* plan) {
+    __shared__ uint32_t sh[PLAN_STRIDE];
+    for (uint32_t i = threadIdx.x; i < PLAN_STRIDE; i += 256) sh[i] = 0;
+    __syncthreads();
     const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= B) return;
     uint32_t run = 0;
-    uint32_t g = 0;
-    for (; g + 8 <= G; g += 8) {
-        uint32_t v[8];
+    if (b < B) {
+        uint32_t g = 0;
+        for (; g + 8 <= G; g += 8) {
+            uint32_t v[8];
 #pragma unroll
-        for (int k = 0; k < 8; k++) v[k] = counts[(size_t)(g + k) * B + b];
+            for (int k = 0; k < 8; k++) v[k] = counts[(size_t)(g + k) * B + b];
 #pragma unroll
-        for (int k = 0; k < 8; k++) {
-            counts[(size_t)(g + k) * B + b] = run;
-            run += v[k];
+            for (int k = 0; k < 8; k++) {
+                counts[(size_t)(g + k) * B + b] = run;
+                run += v[k];
+            }
+        }
+        for (; g < G; g++) {
+            const uint32_t v = counts[(size_t)g * B + b];
+            counts[(size_t)g * B + b] = run;
+            run += v;
+        }
+        cnt[b] = run;
+    }
+    // statistics: lane i < 2 folds max / sum, lane 2 + i the slots of ladder step i, over the block's 256 bucket sizes
+    __shared__ uint32_t cv[256];
+    cv[threadIdx.x] = run;
+    __syncthreads();
+    if (threadIdx.x < PLAN_STRIDE) {
+        uint32_t L = l_min;
+        for (uint32_t i = 2; i < threadIdx.x && L <= L_MAX; i++) L = next_slot_len(L);
+        uint32_t acc = 0;
+        if (threadIdx.x == 0) {
+            for (int k = 0; k < 256; k++) acc = cv[k] > acc ? cv[k] : acc;
+        } else if (threadIdx.x == 1) {
+            for (int k = 0; k < 256; k++) acc += cv[k];
+        } else if (L <= L_MAX) {
+            // ceil(c / L) = floor((c + L - 1) * ceil(2^32 / L) / 2^32), exact while (c + L) * L < 2^32
+            const uint32_t magic = (uint32_t)((0x100000000ull + L - 1) / L);
+            for (int k = 0; k < 256; k++) acc += __umulhi(cv[k] + L - 1, magic);
+        }
+        sh[threadIdx.x] = acc;
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < PLAN_STRIDE; i += 256) plan[(size_t)blockIdx.x * PLAN_STRIDE + i] = sh[i];
+}
+
+// One block of 1024 lanes (B a power of two, B <= 32768).
+//   D != 0 : f(b) = ceil(cnt[b] / D)
+//   D == 0 : folds the plan statistics of `plan_blocks` blocks, picks the slot length L (info[INFO_L]) that minimises
+//            rounds * L for `round_lanes` lanes per round, and uses f(b) = ceil(cnt[b] / L);
+//            also writes start_out = exclusive scan of cnt, info[INFO_MAXCNT], info[INFO_ENTRIES]
+//   f_out[b] = f(b), off_out[b] = exclusive scan of f, off_out[B] = info[INFO_SLOTS] = total
+__global__ void __launch_bounds__(1024) bucket_scan_kernel(const uint32_t* cnt, uint32_t B, uint32_t D, uint32_t* f_out,
+                                                           uint32_t* off_out, uint32_t* start_out, const uint32_t* plan,
+                                                           uint32_t plan_blocks, uint32_t l_min, uint32_t round_lanes,
+                                                           uint32_t force_L, uint32_t* info) {
+    __shared__ uint32_t wsum[2][16];
+    __shared__ uint32_t best;
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if (D == 0) {
+        if (tid == 0) best = 0xffffffffu;
+        __syncthreads();
+        __shared__ uint32_t stat[PLAN_STRIDE];
+        if (tid < PLAN_STRIDE) stat[tid] = 0;
+        __syncthreads();
+        {
+            const uint32_t col = tid & (PLAN_STRIDE - 1);
+            uint32_t v = 0;
+#pragma unroll 4
+            for (uint32_t k = tid / PLAN_STRIDE; k < plan_blocks; k += 1024 / PLAN_STRIDE) {
+                const uint32_t x = plan[(size_t)k * PLAN_STRIDE + col];
+                v = col == 0 ? (x > v ? x : v) : v + x;
+            }
+            if (col == 0) atomicMax(&stat[0], v);
+            else atomicAdd(&stat[col], v);
+        }
+        __syncthreads();
+        if (tid < PLAN_STRIDE) {
+            const uint32_t v = stat[tid];
+            if (tid == 0) info[INFO_MAXCNT] = v;
+            if (tid == 1) info[INFO_ENTRIES] = v;
+            if (tid >= 2) {
+                // candidate index tid - 2: recompute its L
+                uint32_t L = l_min;
+                for (uint32_t i = 2; i < tid && L <= L_MAX; i++) L = next_slot_len(L);
+                if (L <= L_MAX) {
+                    const uint32_t rounds = v == 0 ? 1 : (v + round_lanes - 1) / round_lanes;
+                    // in 1/16 of a mixed addition per SIMD: the accumulate rounds, the partly filled last round
+                    // (about 0.7 L, measured) and the merge of v / B partial sums per bucket; ties go to the longer slot
+                    uint64_t cost = (uint64_t)rounds * L * 16 + (uint64_t)L * 11 + (uint64_t)(v / B) * 8;
+                    if (cost >= (1u << 20)) cost = (1u << 20) - 1;
+                    atomicMin(&best, ((uint32_t)cost << 12) | (L_MAX + 1 - L));
+                }
+            }
+        }
+        __syncthreads();
+        D = force_L ? force_L : (L_MAX + 1 - (best & 0xfff));
+        if (tid == 0) info[INFO_L] = D;
+    }
+    // wave wv owns rows r < per of 64 consecutive buckets each (coalesced); prefix sums stay in registers
+    const uint32_t per = B >= 1024 ? B / 1024 : 1;
+    const uint32_t base = wv * per * 64 + lane;
+    uint32_t offf[32], offc[32];
+    uint32_t carry_f = 0, carry_c = 0;
+#pragma unroll
+    for (uint32_t r = 0; r < 32; r++) {
+        offf[r] = offc[r] = 0;
+        if (r < per) {
+            const uint32_t idx = base + r * 64;
+            const uint32_t c = idx < B ? cnt[idx] : 0;
+            const uint32_t f = (c + D - 1) / D;
+            if (idx < B) f_out[idx] = f;
+            uint32_t inf = f, inc = c;
+            for (int d = 1; d < 64; d <<= 1) {
+                const uint32_t tf = __shfl_up(inf, d, 64), tc = __shfl_up(inc, d, 64);
+                if ((int)lane >= d) {
+                    inf += tf;
+                    inc += tc;
+                }
+            }
+            offf[r] = carry_f + inf - f;
+            offc[r] = carry_c + inc - c;
+            carry_f += __shfl(inf, 63, 64);
+            carry_c += __shfl(inc, 63, 64);
         }
     }
-    for (; g < G; g++) {
-        const uint32_t v = counts[(size_t)g * B + b];
-        counts[(size_t)g * B + b] = run;
-        run += v;
+    if (lane == 0) {
+        wsum[0][wv] = carry_f;
+        wsum[1][wv] = carry_c;
     }
-    cnt[b] = run;
-}
-
-// One block of 1024 lanes, each owning B/1024 consecutive buckets.  f(b) = ceil(cnt[b] / D):
-//   f_out[b] = f(b) (optional), off_out[b] = exclusive scan of f, off_out[B] = total, *max_out = max cnt (optional)
-__global__ void __launch_bounds__(1024) bucket_scan_kernel(const uint32_t* cnt, uint32_t B, uint32_t D, uint32_t* f_out,
-                                                           uint32_t* off_out, uint32_t* max_out) {
-    __shared__ uint32_t lds[1024];
-    __shared__ uint32_t max_s;
-    if (threadIdx.x == 0) max_s = 0;
     __syncthreads();
-    const uint32_t per = (B + 1023) / 1024;
-    const uint32_t lo = threadIdx.x * per, hi = lo + per < B ? lo + per : B;
-    uint32_t s = 0, mx = 0;
-    for (uint32_t b = lo; b < hi; b++) {
-        const uint32_t c = cnt[b];
-        s += (c + D - 1) / D;
-        mx = c > mx ? c : mx;
+    uint32_t bs = 0, be = 0, total = 0;
+    for (uint32_t k = 0; k < 16; k++) {
+        const uint32_t a = wsum[0][k];
+        if (k < wv) {
+            bs += a;
+            be += wsum[1][k];
+        }
+        total += a;
     }
-    atomicMax(&max_s, mx);
-    uint32_t total;
-    uint32_t run = block_exclusive_scan(s, lds, &total);
-    for (uint32_t b = lo; b < hi; b++) {
-        const uint32_t f = (cnt[b] + D - 1) / D;
-        if (f_out) f_out[b] = f;
-        off_out[b] = run;
-        run += f;
+#pragma unroll
+    for (uint32_t r = 0; r < 32; r++) {
+        if (r < per) {
+            const uint32_t idx = base + r * 64;
+            if (idx < B) {
+                off_out[idx] = bs + offf[r];
+                if (start_out) start_out[idx] = be + offc[r];
+            }
+        }
     }
-    if (threadIdx.x == 0) {
+    if (tid == 0) {
         off_out[B] = total;
-        if (max_out) *max_out = max_s;
+        if (info) info[INFO_SLOTS] = total;
     }
 }
 
@@ -202,17 +317,17 @@ ZK_DEV uint32_t find_bucket(const uint32_t* off, uint32_t B, uint32_t t) {
 }
 
 // ---- accumulate ------------------------------------------------------------------------------------
+// lane t = slot s of bucket b: folds entries [s * cnt / f, (s + 1) * cnt / f) of the bucket, f = slots of the bucket
 __global__ void __launch_bounds__(256) accumulate_kernel(const uint32_t* entries, const uint32_t* start, const uint32_t* cnt,
-                                                         const uint32_t* slot_off, uint32_t B, uint32_t L,
+                                                         const uint32_t* slot_off, const uint32_t* slot_cnt, uint32_t B,
                                                          const g1_affine* tables, size_t table_stride, size_t first,
                                                          g1_xyzz* items) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= slot_off[B]) return;
     const uint32_t b = find_bucket(slot_off, B, t);
-    const uint32_t s = t - slot_off[b];
-    const uint32_t lo = start[b] + s * L;
-    const uint32_t end = start[b] + cnt[b];
-    const uint32_t hi = lo + L < end ? lo + L : end;
+    const uint32_t s = t - slot_off[b], f = slot_cnt[b], c = cnt[b];
+    const uint32_t lo = start[b] + (uint32_t)((uint64_t)s * c / f);
+    const uint32_t hi = start[b] + (uint32_t)((uint64_t)(s + 1) * c / f);
     g1_xyzz acc = xyzz_identity();
     uint32_t e = entries[lo];
     g1_affine p = load_affine(tables + (size_t)((e >> ENTRY_IDX_BITS) & 31) * table_stride + first + (e & ENTRY_IDX_MASK));
@@ -229,7 +344,20 @@ __global__ void __launch_bounds__(256) accumulate_kernel(const uint32_t* entries
     store_xyzz(items + t, acc);
 }
 
-// one lane folds up to F consecutive items of one bucket
+// ---- merge -----------------------------------------------------------------------------------------
+__device__ __forceinline__ g1_xyzz shfl_xyzz(const g1_xyzz& v, int src_lane) {
+    g1_xyzz o;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        o.x.l[i] = __shfl(v.x.l[i], src_lane, 64);
+        o.y.l[i] = __shfl(v.y.l[i], src_lane, 64);
+        o.zz.l[i] = __shfl(v.zz.l[i], src_lane, 64);
+        o.zzz.l[i] = __shfl(v.zzz.l[i], src_lane, 64);
+    }
+    return o;
+}
+
+// pre-level for very heavy buckets: one lane folds up to F consecutive items of one bucket
 __global__ void __launch_bounds__(256) merge_kernel(const g1_xyzz* in, const uint32_t* off_in, const uint32_t* cnt_in,
                                                     const uint32_t* off_out, uint32_t B, uint32_t F, g1_xyzz* out) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -244,34 +372,84 @@ __global__ void __launch_bounds__(256) merge_kernel(const g1_xyzz* in, const uin
     store_xyzz(out + t, acc);
 }
 
-// ---- reduce ----------------------------------------------------------------------------------------
-constexpr int REDUCE_THREADS = 512;
-// weight * p by double-and-add from the top bit
-ZK_DEV g1_xyzz xyzz_mul_small(const g1_xyzz& p, uint32_t k) {
+// final level: MERGE_P neighbouring lanes share one bucket; lane r folds items r, r + P, ... and a shuffle tree joins
+// the P partial sums.  out[b] = bucket sum (identity for an empty bucket).
+constexpr int MERGE_P = 2;
+__global__ void __launch_bounds__(256) merge_final_kernel(const g1_xyzz* in, const uint32_t* off_in, const uint32_t* cnt_in,
+                                                          uint32_t B, g1_xyzz* out) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t b = t / MERGE_P, r = t % MERGE_P;
+    const uint32_t lane = threadIdx.x & 63;
     g1_xyzz acc = xyzz_identity();
-    if (k == 0 || xyzz_is_identity(p)) return acc;
-    const int top = 31 - __builtin_clz(k);
-    for (int bit = top; bit >= 0; bit--) {
-        acc = xyzz_double(acc);
-        if ((k >> bit) & 1) acc = xyzz_add(acc, p);
+    if (b < B) {
+        const uint32_t c = cnt_in[b], base = off_in[b];
+        if (r < c) {
+            acc = load_xyzz(in + base + r);
+            for (uint32_t i = r + MERGE_P; i < c; i += MERGE_P) acc = xyzz_add(acc, load_xyzz(in + base + i));
+        }
     }
-    return acc;
+    for (int d = MERGE_P / 2; d >= 1; d >>= 1) {
+        const g1_xyzz o = shfl_xyzz(acc, (int)(lane ^ d));
+        acc = xyzz_add(acc, o);
+    }
+    if (b < B && r == 0) store_xyzz(out + b, acc);
 }
 
-__global__ void __launch_bounds__(REDUCE_THREADS) bucket_reduce_kernel(const g1_xyzz* items, const uint32_t* off,
-                                                                       const uint32_t* cnt, uint32_t B, g1_xyzz* block_sums) {
-    extern __shared__ __align__(16) unsigned char smem[];
-    g1_xyzz* sh = reinterpret_cast<g1_xyzz*>(smem);
-    const uint32_t b = blockIdx.x * REDUCE_THREADS + threadIdx.x;
-    g1_xyzz v = xyzz_identity();
-    if (b < B && cnt[b]) v = xyzz_mul_small(load_xyzz(items + off[b]), b + 1);
-    for (uint32_t half = REDUCE_THREADS / 2; half >= 1; half >>= 1) {
-        if (threadIdx.x >= half && threadIdx.x < 2 * half) sh[threadIdx.x - half] = v;
-        __syncthreads();
-        if (threadIdx.x < half) v = xyzz_add(v, sh[threadIdx.x]);
-        __syncthreads();
+// ---- reduce ----------------------------------------------------------------------------------------
+// sum over b of (b + 1) * S_b.  Within a wave of 64 consecutive points P_0..P_63 a suffix scan T_i = sum_{k >= i} P_k
+// gives A = T_0 = sum P_i and V = sum_{i >= 1} T_i = sum i * P_i in 12 point additions, with no scalar multiplication.
+// Level 1 does this for every 64 buckets, level 2 for the A's of 64 waves; the host joins the <= 24 leftovers.
+__device__ __forceinline__ void wave_weighted_sum(g1_xyzz p, uint32_t lane, g1_xyzz& a_out, g1_xyzz& v_out) {
+    for (int d = 1; d < 64; d <<= 1) {
+        g1_xyzz o = shfl_xyzz(p, (int)((lane + d) & 63));
+        if (lane + d >= 64) o = xyzz_identity();
+        p = xyzz_add(p, o);
     }
-    if (threadIdx.x == 0) store_xyzz(block_sums + blockIdx.x, v);
+    a_out = shfl_xyzz(p, 0);
+    g1_xyzz v = lane >= 1 ? p : xyzz_identity();
+    for (int d = 32; d >= 1; d >>= 1) {
+        const g1_xyzz o = shfl_xyzz(v, (int)(lane ^ d));
+        v = xyzz_add(v, o);
+    }
+    v_out = v;
+}
+__device__ __forceinline__ g1_xyzz wave_sum_xyzz(g1_xyzz v, uint32_t lane) {
+    for (int d = 32; d >= 1; d >>= 1) {
+        const g1_xyzz o = shfl_xyzz(v, (int)(lane ^ d));
+        v = xyzz_add(v, o);
+    }
+    return v;
+}
+
+// level 1: sums[b] for b < B (B a multiple of 64) -> a1[j], v1[j] for wave j = b / 64
+__global__ void __launch_bounds__(256) reduce_level1_kernel(const g1_xyzz* sums, uint32_t B, g1_xyzz* a1, g1_xyzz* v1) {
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x, lane = threadIdx.x & 63;
+    g1_xyzz p = b < B ? load_xyzz(sums + b) : xyzz_identity();
+    g1_xyzz a, v;
+    wave_weighted_sum(p, lane, a, v);
+    if (lane == 0) {
+        store_xyzz(a1 + (b >> 6), a);
+        store_xyzz(v1 + (b >> 6), v);
+    }
+}
+// level 2 (16 blocks of one wave, J <= 512): blocks h < 8 take a1[64 h + lane] -> out[h] = sum, out[8 + h] = sum of
+// lane * a1[64 h + lane]; blocks 8 + h take v1[64 h + lane] -> out[16 + h] = sum.
+__global__ void __launch_bounds__(64) reduce_level2_kernel(const g1_xyzz* a1, const g1_xyzz* v1, uint32_t J, g1_xyzz* out) {
+    const uint32_t lane = threadIdx.x, h = blockIdx.x & 7;
+    const uint32_t j = h * 64 + lane;
+    if (blockIdx.x < 8) {
+        g1_xyzz p = j < J ? load_xyzz(a1 + j) : xyzz_identity();
+        g1_xyzz a, v;
+        wave_weighted_sum(p, lane, a, v);
+        if (lane == 0) {
+            store_xyzz(out + h, a);
+            store_xyzz(out + 8 + h, v);
+        }
+    } else {
+        g1_xyzz p = j < J ? load_xyzz(v1 + j) : xyzz_identity();
+        p = wave_sum_xyzz(p, lane);
+        if (lane == 0) store_xyzz(out + 16 + h, p);
+    }
 }
 
 // out[i] = (first + i) * P for an affine point P: the synthetic SRS of the benchmark and the parity tests
@@ -326,9 +504,10 @@ static uint32_t env_u32(const char* name, uint32_t dflt) {
     const char* v = getenv(name);
     return v && *v ? (uint32_t)atoi(v) : dflt;
 }
-// entries folded by one accumulate lane / partial sums folded by one merge lane (tunable for experiments)
-static const uint32_t SLOT_L = env_u32("ZKHIP_SLOT_L", 32);
-static const uint32_t MERGE_F = env_u32("ZKHIP_MERGE_F", 16);
+// experiments: force the slot length (0 = planned per MSM) / items folded per lane in a merge pre-level
+static const uint32_t FORCE_L = env_u32("ZKHIP_SLOT_L", 0);
+static const uint32_t MERGE_F = 16;
+constexpr uint32_t MERGE_DIRECT_MAX = 32;   // the final merge level takes buckets of up to this many partial sums
 
 // Buffers of one in-flight MSM.  A workspace is bound to a stream; several workspaces let the latency-bound tail of
 // one MSM (merge, reduce, host fold) overlap the accumulate phase of the next.
@@ -336,25 +515,30 @@ struct MsmWorkspace {
     hipStream_t stream = nullptr;
     unsigned char* base = nullptr;
     size_t bytes = 0;
-    uint32_t* h_info = nullptr;        // pinned: {total slots, max bucket size}
-    uint64_t* h_sums = nullptr;        // pinned block sums (XYZZ)
-    size_t h_sums_cap = 0;
+    uint32_t* h_info = nullptr;        // pinned copy of info[0..3]
+    uint64_t* h_sums = nullptr;        // pinned: the 24 leftover sums of the reduce (XYZZ)
     // per-call state
     size_t n = 0, first = 0;
     const fe* d_scalars = nullptr;
-    uint32_t G = 0;
-    size_t n_red_blocks = 0;
-    uint32_t *counts, *entries, *start, *cnt, *offA, *cntA, *offB, *cntB, *info;
-    g1_xyzz *itemsA, *itemsB, *bsums;
+    uint32_t G = 0, l_min = 0, plan_blocks = 0;
+    bool nonzero = false;
+    uint32_t *counts, *entries, *start, *cnt, *offA, *cntA, *offB, *cntB, *info, *plan;
+    g1_xyzz *itemsA, *itemsB, *sums, *a1, *v1, *out2;
 };
+constexpr size_t REDUCE_OUT = 24;
 
 static int ws_prepare(zkhip_ctx* ctx, MsmWorkspace& ws, const MsmTables& tb, size_t n) {
     const uint32_t B = 1u << (tb.c - 1), W = tb.W;
     uint32_t G = (uint32_t)std::min<size_t>((size_t)ctx->num_cus, (n + HIST_THREADS - 1) / HIST_THREADS);
     if (G < 1) G = 1;
     ws.G = G;
-    const size_t E_max = n * W, T1_max = E_max / SLOT_L + B + 1;
-    ws.n_red_blocks = (B + 511) / 512;
+    const size_t E_max = n * W, round_lanes = (size_t)ctx->num_cus * 256;
+    // shortest slot the plan may pick: keeps the partial-sum buffers within E_max / l_min + B items
+    ws.l_min = (uint32_t)std::min<size_t>(64, std::max<size_t>(8, E_max / (8 * round_lanes)));
+    if (FORCE_L) ws.l_min = std::min(ws.l_min, FORCE_L);
+    ws.plan_blocks = (B + 255) / 256;
+    const size_t T1_max = E_max / ws.l_min + B + 1;
+    const size_t J = (B + 63) / 64;
     size_t off = 0;
     auto take = [&](size_t bytes) {
         const size_t o = off;
@@ -364,8 +548,10 @@ static int ws_prepare(zkhip_ctx* ctx, MsmWorkspace& ws, const MsmTables& tb, siz
     const size_t o_counts = take((size_t)B * G * 4), o_entries = take(E_max * 4), o_start = take(((size_t)B + 1) * 4),
                  o_cnt = take((size_t)B * 4), o_offA = take(((size_t)B + 1) * 4), o_cntA = take((size_t)B * 4),
                  o_offB = take(((size_t)B + 1) * 4), o_cntB = take((size_t)B * 4), o_info = take(64),
-                 o_itemsA = take(T1_max * sizeof(g1_xyzz)), o_itemsB = take((T1_max / MERGE_F + B + 1) * sizeof(g1_xyzz)),
-                 o_bsums = take(ws.n_red_blocks * sizeof(g1_xyzz));
+                 o_plan = take((size_t)ws.plan_blocks * PLAN_STRIDE * 4), o_itemsA = take(T1_max * sizeof(g1_xyzz)),
+                 o_itemsB = take((T1_max / MERGE_F + B + 1) * sizeof(g1_xyzz)), o_sums = take((size_t)B * sizeof(g1_xyzz)),
+                 o_a1 = take((J + 4) * sizeof(g1_xyzz)), o_v1 = take((J + 4) * sizeof(g1_xyzz)),
+                 o_out2 = take(REDUCE_OUT * sizeof(g1_xyzz));
     if (off > ws.bytes) {
         if (ws.base) {
             ZK_HIP(ctx, hipStreamSynchronize(ws.stream));
@@ -377,11 +563,7 @@ static int ws_prepare(zkhip_ctx* ctx, MsmWorkspace& ws, const MsmTables& tb, siz
         ws.bytes = off;
     }
     if (!ws.h_info) ZK_HIP(ctx, hipHostMalloc((void**)&ws.h_info, 64));
-    if (ws.h_sums_cap < ws.n_red_blocks) {
-        if (ws.h_sums) ZK_HIP(ctx, hipHostFree(ws.h_sums));
-        ZK_HIP(ctx, hipHostMalloc((void**)&ws.h_sums, ws.n_red_blocks * sizeof(g1_xyzz)));
-        ws.h_sums_cap = ws.n_red_blocks;
-    }
+    if (!ws.h_sums) ZK_HIP(ctx, hipHostMalloc((void**)&ws.h_sums, REDUCE_OUT * sizeof(g1_xyzz)));
     unsigned char* p = ws.base;
     ws.counts = (uint32_t*)(p + o_counts);
     ws.entries = (uint32_t*)(p + o_entries);
@@ -392,13 +574,17 @@ static int ws_prepare(zkhip_ctx* ctx, MsmWorkspace& ws, const MsmTables& tb, siz
     ws.offB = (uint32_t*)(p + o_offB);
     ws.cntB = (uint32_t*)(p + o_cntB);
     ws.info = (uint32_t*)(p + o_info);
+    ws.plan = (uint32_t*)(p + o_plan);
     ws.itemsA = (g1_xyzz*)(p + o_itemsA);
     ws.itemsB = (g1_xyzz*)(p + o_itemsB);
-    ws.bsums = (g1_xyzz*)(p + o_bsums);
+    ws.sums = (g1_xyzz*)(p + o_sums);
+    ws.a1 = (g1_xyzz*)(p + o_a1);
+    ws.v1 = (g1_xyzz*)(p + o_v1);
+    ws.out2 = (g1_xyzz*)(p + o_out2);
     return ZKHIP_OK;
 }
 
-// phase 1: recode, count, scan, scatter; asynchronous readback of {slots, max bucket size}
+// phase 1: recode, count, scan and plan, scatter; asynchronous readback of {slots, max bucket size, slot length}
 static int msm_phase1(zkhip_ctx* ctx, MsmWorkspace& ws, const MsmTables& tb, size_t first, const fe* d_scalars, size_t n) {
     int rc = ws_prepare(ctx, ws, tb, n);
     if (rc) return rc;
@@ -410,44 +596,42 @@ static int msm_phase1(zkhip_ctx* ctx, MsmWorkspace& ws, const MsmTables& tb, siz
     const size_t lds_hist = (size_t)B * 4;
     hipStream_t st = ws.stream;
     hipLaunchKernelGGL(digits_hist_kernel, dim3(G), dim3(HIST_THREADS), lds_hist, st, d_scalars, n, chunk, c, W, ws.counts);
-    hipLaunchKernelGGL(column_scan_kernel, dim3((B + 255) / 256), dim3(256), 0, st, ws.counts, G, B, ws.cnt);
-    // start[b] = exclusive scan of cnt (entries), then slots per bucket and their scan; info = {total slots, max cnt}
-    hipLaunchKernelGGL(bucket_scan_kernel, dim3(1), dim3(1024), 0, st, ws.cnt, B, 1u, (uint32_t*)nullptr, ws.start,
-                       ws.info + 1);
-    hipLaunchKernelGGL(bucket_scan_kernel, dim3(1), dim3(1024), 0, st, ws.cnt, B, SLOT_L, ws.cntA, ws.offA,
-                       (uint32_t*)nullptr);
+    hipLaunchKernelGGL(column_scan_kernel, dim3(ws.plan_blocks), dim3(256), 0, st, ws.counts, G, B, ws.cnt, ws.l_min, ws.plan);
+    hipLaunchKernelGGL(bucket_scan_kernel, dim3(1), dim3(1024), 0, st, ws.cnt, B, 0u, ws.cntA, ws.offA, ws.start, ws.plan,
+                       ws.plan_blocks, ws.l_min, (uint32_t)ctx->num_cus * 256u, FORCE_L, ws.info);
     hipLaunchKernelGGL(scatter_kernel, dim3(G), dim3(HIST_THREADS), lds_hist, st, d_scalars, n, chunk, c, W, ws.counts,
                        ws.start, ws.entries);
     ZK_HIP(ctx, hipGetLastError());
-    ZK_HIP(ctx, hipMemcpyAsync(ws.h_info, ws.offA + B, 4, hipMemcpyDeviceToHost, st));
-    ZK_HIP(ctx, hipMemcpyAsync(ws.h_info + 1, ws.info + 1, 4, hipMemcpyDeviceToHost, st));
+    ZK_HIP(ctx, hipMemcpyAsync(ws.h_info, ws.info, 16, hipMemcpyDeviceToHost, st));
     return ZKHIP_OK;
 }
 
-// phase 2: waits for phase 1's readback, then accumulate, merge levels, reduce; asynchronous readback of block sums
+// phase 2: waits for phase 1's readback, then accumulate, merge, reduce; asynchronous readback of the leftover sums
 static int msm_phase2(zkhip_ctx* ctx, MsmWorkspace& ws, const MsmTables& tb, bool timed) {
     hipStream_t st = ws.stream;
     ZK_HIP(ctx, hipStreamSynchronize(st));
-    const uint32_t total_slots = ws.h_info[0], max_cnt = ws.h_info[1];
+    const uint32_t total_slots = ws.h_info[INFO_SLOTS], max_cnt = ws.h_info[INFO_MAXCNT], L = ws.h_info[INFO_L];
     const uint32_t B = 1u << (tb.c - 1);
-    if (total_slots == 0) {   // every scalar is zero
-        ws.n_red_blocks = 0;
-        return ZKHIP_OK;
-    }
+    ws.nonzero = total_slots != 0;
+    static const bool debug = getenv("ZKHIP_DEBUG") != nullptr;
+    if (debug)
+        fprintf(stderr, "[zkhip] msm n=%zu: slots=%u max_cnt=%u L=%u entries=%u\n", ws.n, total_slots, max_cnt, L,
+                ws.h_info[INFO_ENTRIES]);
+    if (!ws.nonzero) return ZKHIP_OK;   // every scalar is zero
     {
         TimedRegion tr(ctx, timed ? "msm_accumulate" : nullptr, st);
         hipLaunchKernelGGL(accumulate_kernel, dim3((total_slots + 255) / 256), dim3(256), 0, st, ws.entries, ws.start, ws.cnt,
-                           ws.offA, B, SLOT_L, tb.d_tables, tb.n, ws.first, ws.itemsA);
+                           ws.offA, ws.cntA, B, tb.d_tables, tb.n, ws.first, ws.itemsA);
         ZK_HIP(ctx, hipGetLastError());
     }
     g1_xyzz *cur_items = ws.itemsA, *nxt_items = ws.itemsB;
     uint32_t *cur_off = ws.offA, *cur_cnt = ws.cntA, *nxt_off = ws.offB, *nxt_cnt = ws.cntB;
     {
         TimedRegion tr(ctx, timed ? "msm_merge" : nullptr, st);
-        uint32_t level_max = (max_cnt + SLOT_L - 1) / SLOT_L, level_total = total_slots;
-        while (level_max > 1) {
+        uint32_t level_max = (max_cnt + L - 1) / L, level_total = total_slots;
+        while (level_max > MERGE_DIRECT_MAX) {
             hipLaunchKernelGGL(bucket_scan_kernel, dim3(1), dim3(1024), 0, st, cur_cnt, B, MERGE_F, nxt_cnt, nxt_off,
-                               (uint32_t*)nullptr);
+                               (uint32_t*)nullptr, (const uint32_t*)nullptr, 0u, 0u, 0u, 0u, (uint32_t*)nullptr);
             const uint32_t bound = level_total / MERGE_F + B + 1;
             hipLaunchKernelGGL(merge_kernel, dim3((bound + 255) / 256), dim3(256), 0, st, cur_items, cur_off, cur_cnt, nxt_off,
                                B, MERGE_F, nxt_items);
@@ -458,25 +642,47 @@ static int msm_phase2(zkhip_ctx* ctx, MsmWorkspace& ws, const MsmTables& tb, boo
             level_max = (level_max + MERGE_F - 1) / MERGE_F;
             level_total = bound;
         }
+        hipLaunchKernelGGL(merge_final_kernel, dim3((B * MERGE_P + 255) / 256), dim3(256), 0, st, cur_items, cur_off, cur_cnt, B,
+                           ws.sums);
+        ZK_HIP(ctx, hipGetLastError());
     }
     {
         TimedRegion tr(ctx, timed ? "msm_reduce" : nullptr, st);
-        hipLaunchKernelGGL(bucket_reduce_kernel, dim3((unsigned)ws.n_red_blocks), dim3(REDUCE_THREADS),
-                           (REDUCE_THREADS / 2) * sizeof(g1_xyzz), st, cur_items, cur_off, cur_cnt, B, ws.bsums);
+        const uint32_t blocks1 = (B + 255) / 256, J = blocks1 * 4;
+        hipLaunchKernelGGL(reduce_level1_kernel, dim3(blocks1), dim3(256), 0, st, ws.sums, B, ws.a1, ws.v1);
+        hipLaunchKernelGGL(reduce_level2_kernel, dim3(16), dim3(64), 0, st, ws.a1, ws.v1, J, ws.out2);
         ZK_HIP(ctx, hipGetLastError());
     }
-    ZK_HIP(ctx, hipMemcpyAsync(ws.h_sums, ws.bsums, ws.n_red_blocks * sizeof(g1_xyzz), hipMemcpyDeviceToHost, st));
+    ZK_HIP(ctx, hipMemcpyAsync(ws.h_sums, ws.out2, REDUCE_OUT * sizeof(g1_xyzz), hipMemcpyDeviceToHost, st));
     return ZKHIP_OK;
 }
 
-// phase 3: waits for the block sums and folds them on the host
+// phase 3: waits for the leftover sums of the reduce and joins them on the host.  With a_h, v_h, s_h (h < 8) the three
+// groups of level 2:  result = sum s_h + sum a_h + 64 * (sum v_h + 64 * sum h * a_h)
 static int msm_phase3(zkhip_ctx* ctx, MsmWorkspace& ws, uint64_t out_jacobian[12]) {
     ZK_HIP(ctx, hipStreamSynchronize(ws.stream));
-    uint64_t acc[12], jac[12];
-    memset(acc, 0, sizeof acc);
-    for (size_t i = 0; i < ws.n_red_blocks; i++) {
-        xyzz_to_jacobian_host(jac, ws.h_sums + 16 * i);
-        h_g1_add(acc, acc, jac);
+    memset(out_jacobian, 0, 96);
+    if (!ws.nonzero) return ZKHIP_OK;
+    uint64_t a[8][12], t[12], run[12], ha[12], acc[12];
+    memset(run, 0, sizeof run);
+    memset(ha, 0, sizeof ha);
+    for (int h = 0; h < 8; h++) xyzz_to_jacobian_host(a[h], ws.h_sums + 16 * h);
+    for (int h = 7; h >= 1; h--) {   // sum h * a_h by running sums
+        h_g1_add(run, run, a[h]);
+        h_g1_add(ha, ha, run);
+    }
+    h_g1_add(run, run, a[0]);        // run = sum a_h
+    for (int k = 0; k < 6; k++) h_g1_double(ha, ha);
+    for (int h = 0; h < 8; h++) {
+        xyzz_to_jacobian_host(t, ws.h_sums + 16 * (8 + h));
+        h_g1_add(ha, ha, t);
+    }
+    for (int k = 0; k < 6; k++) h_g1_double(ha, ha);
+    memcpy(acc, ha, sizeof acc);
+    h_g1_add(acc, acc, run);
+    for (int h = 0; h < 8; h++) {
+        xyzz_to_jacobian_host(t, ws.h_sums + 16 * (16 + h));
+        h_g1_add(acc, acc, t);
     }
     memcpy(out_jacobian, acc, 96);
     return ZKHIP_OK;
@@ -581,8 +787,6 @@ int msm_init(zkhip_ctx* ctx) {
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
     ZK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(scatter_kernel),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
-    ZK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(bucket_reduce_kernel),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
     return ZKHIP_OK;
 }
 
