@@ -34,6 +34,12 @@ __global__ void __launch_bounds__(256) probe(uint64_t* out, uint32_t seed) {
                 dacc[u] = __builtin_fma(dacc[u], 1.0000001, 0.5);
             } else if (KIND == 6) {  // 32-bit add
                 acc[u] = (uint32_t)acc[u] + b;
+            } else if (KIND == 8) {  // v_mad_i64_i32
+                acc[u] = (uint64_t)((int64_t)(int32_t)acc[u] * (int64_t)(int32_t)b + (int64_t)acc[u]);
+            } else if (KIND == 9) {  // v_ashrrev_i64
+                acc[u] = (uint64_t)((int64_t)acc[u] >> (b & 31)) ^ a;
+            } else if (KIND == 10) {  // v_lshl_add_u64
+                acc[u] = (acc[u] << 1) + (((uint64_t)b << 32) | a);
             } else if (KIND == 7) {  // v_mad_u64_u32 with carry-out consumed (mad + addc)
                 uint64_t r = (uint64_t)(uint32_t)acc[u] * (uint64_t)b;
                 uint64_t s = r + acc[u];
@@ -76,6 +82,9 @@ int main() {
     run<5>("v_fma_f64", d, blocks);
     run<6>("v_add_u32", d, blocks);
     run<7>("mad_u64 + carry fold", d, blocks);
+    run<8>("v_mad_i64_i32", d, blocks);
+    run<9>("v_ashrrev_i64 (+xor)", d, blocks);
+    run<10>("v_lshl_add_u64", d, blocks);
     CK(hipFree(d));
     return 0;
 }

@@ -1,0 +1,163 @@
+// XYZZ bucket accumulation on the lazy signed-digit arithmetic of wide.cuh (the MSM accumulate kernel's inner loop).
+//
+// Coordinates live in the 2^261 Montgomery domain (the MSM tables are stored in it; see msm.hip).  A mixed addition
+// is 8 mul + 2 sqr, seven digit-wise subtractions and two carry normalisations; nothing is reduced modulo p.
+// Digit-magnitude bookkeeping (see wide.cuh): acc.x, acc.y, acc.zz, acc.zzz are normalised; every subtraction below
+// takes two normalised values, so its result is a valid mul / sqr operand; x3 (four terms) and y3 are normalised
+// before they are stored.  Value bookkeeping: with |x| < 3.3 p, |y| < 1.2 p at entry, P and Rr stay below 4.3 p and
+// 2.3 p, all products land in (-0.15 p, 1.15 p), and x3, y3 satisfy the entry bounds again.
+#pragma once
+#include "curve.cuh"
+#include "wide.cuh"
+
+namespace zkhip {
+
+struct g1_xyzz_w {
+    fw x, y, zz, zzz;
+    bool inf;   // identity (coordinates unspecified)
+};
+
+// 2 * (x, y), an affine point that is not the identity; y may be a lazy negation
+__device__ __forceinline__ void xyzz_w_double_affine(g1_xyzz_w& acc, const fw& x, const fw& y) {
+    const fw yn = FqW::norm(y);
+    const fw u = FqW::norm(FqW::dbl(yn));
+    const fw v = FqW::sqr(u);
+    const fw w = FqW::mul(u, v);
+    const fw s = FqW::mul(x, v);
+    const fw x2 = FqW::sqr(x);
+    const fw m = FqW::norm(FqW::add(FqW::dbl(x2), x2));
+    const fw x3 = FqW::norm(FqW::sub(FqW::sqr(m), FqW::dbl(s)));
+    acc.y = FqW::norm(FqW::sub(FqW::mul(m, FqW::sub(s, x3)), FqW::mul(w, yn)));
+    acc.x = x3;
+    acc.zz = v;
+    acc.zzz = w;
+    acc.inf = false;
+}
+
+// acc += (qx, +-qy); q is in the packed in-memory form (identity = all zero words)
+__device__ __forceinline__ void xyzz_w_add_affine(g1_xyzz_w& acc, const g1_affine& q, bool negate) {
+    uint32_t any = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) any |= q.x.l[i] | q.y.l[i];
+    if (any == 0) return;
+    const fw qx = FqW::from_fe(q.x);
+    const fw qy = FqW::cneg(FqW::from_fe(q.y), negate);
+    if (acc.inf) {
+        acc.x = qx;
+        acc.y = FqW::norm(qy);
+        acc.zz = FqW::one();
+        acc.zzz = FqW::one();
+        acc.inf = false;
+        return;
+    }
+    const fw u2 = FqW::mul(qx, acc.zz);
+    const fw s2 = FqW::mul(qy, acc.zzz);
+    const fw p = FqW::sub(u2, acc.x);
+    const fw r = FqW::sub(s2, acc.y);
+    if (FqW::maybe_zero(p)) {          // almost never taken: the exact test costs a full canonicalisation
+        if (FqW::is_zero(p)) {
+            if (FqW::is_zero(r)) xyzz_w_double_affine(acc, qx, qy);
+            else acc.inf = true;
+            return;
+        }
+    }
+    const fw pp = FqW::sqr(p);
+    const fw ppp = FqW::mul(p, pp);
+    const fw qq = FqW::mul(acc.x, pp);
+    const fw x3 = FqW::norm(FqW::sub(FqW::sub(FqW::sqr(r), ppp), FqW::dbl(qq)));
+    acc.y = FqW::norm(FqW::sub(FqW::mul(r, FqW::sub(qq, x3)), FqW::mul(acc.y, ppp)));
+    acc.x = x3;
+    acc.zz = FqW::mul(acc.zz, pp);
+    acc.zzz = FqW::mul(acc.zzz, ppp);
+}
+
+// 2 * a (a not the identity)
+__device__ __forceinline__ g1_xyzz_w xyzz_w_double(const g1_xyzz_w& a) {
+    g1_xyzz_w o;
+    const fw u = FqW::norm(FqW::dbl(a.y));
+    const fw v = FqW::sqr(u);
+    const fw w = FqW::mul(u, v);
+    const fw s = FqW::mul(a.x, v);
+    const fw x2 = FqW::sqr(a.x);
+    const fw m = FqW::norm(FqW::add(FqW::dbl(x2), x2));
+    o.x = FqW::norm(FqW::sub(FqW::sqr(m), FqW::dbl(s)));
+    o.y = FqW::norm(FqW::sub(FqW::mul(m, FqW::sub(s, o.x)), FqW::mul(w, a.y)));
+    o.zz = FqW::mul(v, a.zz);
+    o.zzz = FqW::mul(w, a.zzz);
+    o.inf = false;
+    return o;
+}
+
+// a + b, both with normalised coordinates
+__device__ __forceinline__ g1_xyzz_w xyzz_w_add(const g1_xyzz_w& a, const g1_xyzz_w& b) {
+    if (a.inf) return b;
+    if (b.inf) return a;
+    const fw u1 = FqW::mul(a.x, b.zz);
+    const fw u2 = FqW::mul(b.x, a.zz);
+    const fw s1 = FqW::mul(a.y, b.zzz);
+    const fw s2 = FqW::mul(b.y, a.zzz);
+    const fw p = FqW::sub(u2, u1);
+    const fw r = FqW::sub(s2, s1);
+    if (FqW::maybe_zero(p)) {
+        if (FqW::is_zero(p)) {
+            if (FqW::is_zero(r)) return xyzz_w_double(a);
+            g1_xyzz_w o = a;
+            o.inf = true;
+            return o;
+        }
+    }
+    g1_xyzz_w o;
+    const fw pp = FqW::sqr(p);
+    const fw ppp = FqW::mul(p, pp);
+    const fw qq = FqW::mul(u1, pp);
+    o.x = FqW::norm(FqW::sub(FqW::sub(FqW::sqr(r), ppp), FqW::dbl(qq)));
+    o.y = FqW::norm(FqW::sub(FqW::mul(r, FqW::sub(qq, o.x)), FqW::mul(s1, ppp)));
+    o.zz = FqW::mul(FqW::mul(a.zz, b.zz), pp);
+    o.zzz = FqW::mul(FqW::mul(a.zzz, b.zzz), ppp);
+    o.inf = false;
+    return o;
+}
+
+__device__ __forceinline__ g1_xyzz_w xyzz_w_identity() {
+    g1_xyzz_w o;
+    o.x = o.y = o.zz = o.zzz = FqW::zero();
+    o.inf = true;
+    return o;
+}
+
+// Packed XYZZ in memory (canonical residues, identity: zz = 0), coordinates in the 2^261 domain.
+__device__ __forceinline__ g1_xyzz_w xyzz_w_load(const g1_xyzz* p) {
+    const g1_xyzz v = load_xyzz(p);
+    g1_xyzz_w o;
+    o.inf = Fq::is_zero(v.zz);
+    o.x = FqW::from_fe(v.x);
+    o.y = FqW::from_fe(v.y);
+    o.zz = FqW::from_fe(v.zz);
+    o.zzz = FqW::from_fe(v.zzz);
+    return o;
+}
+__device__ __forceinline__ g1_xyzz xyzz_w_pack(const g1_xyzz_w& a) {
+    if (a.inf) return xyzz_identity();
+    g1_xyzz o;
+    o.x = FqW::to_fe(a.x);
+    o.y = FqW::to_fe(a.y);
+    o.zz = FqW::to_fe(a.zz);
+    o.zzz = FqW::to_fe(a.zzz);
+    return o;
+}
+__device__ __forceinline__ void xyzz_w_store(g1_xyzz* p, const g1_xyzz_w& a) { store_xyzz(p, xyzz_w_pack(a)); }
+
+__device__ __forceinline__ g1_xyzz_w xyzz_w_shfl(const g1_xyzz_w& v, int src_lane) {
+    g1_xyzz_w o;
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+        o.x.d[i] = __shfl(v.x.d[i], src_lane, 64);
+        o.y.d[i] = __shfl(v.y.d[i], src_lane, 64);
+        o.zz.d[i] = __shfl(v.zz.d[i], src_lane, 64);
+        o.zzz.d[i] = __shfl(v.zzz.d[i], src_lane, 64);
+    }
+    o.inf = __shfl((int)v.inf, src_lane, 64) != 0;
+    return o;
+}
+
+}  // namespace zkhip

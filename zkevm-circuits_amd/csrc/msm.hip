@@ -1,7 +1,8 @@
 // Pippenger bucket MSM over BN254 G1 for gfx950 (`arithmetic::best_multiexp`).
 //
 // Registration (once per SRS): for window width c and W = ceil(255 / c) windows the library stores the
-// affine tables T_w[i] = 2^(c w) * G_i for every w.  With 288 GB of HBM the W-fold copy is cheap (k = 19:
+// affine tables T_w[i] = 2^(c w) * G_i for every w (coordinates in the 2^261 Montgomery domain of the accumulate
+// kernel's lazy arithmetic, csrc/wide.cuh).  With 288 GB of HBM the W-fold copy is cheap (k = 19:
 // 512 MiB) and it collapses all windows into ONE set of 2^(c-1) signed-digit buckets: no per-window bucket
 // sets, no doubling ladder at the end, 16x less bucket-reduction work.
 //
@@ -25,6 +26,7 @@
 #include <cstring>
 #include "common.h"
 #include "curve.cuh"
+#include "curve_wide.cuh"
 
 using namespace zkhip;
 
@@ -48,6 +50,20 @@ __global__ void __launch_bounds__(256) table_next_kernel(const g1_affine* prev, 
     g1_xyzz acc = xyzz_from_affine(p);
     for (uint32_t k = 0; k < c; k++) acc = xyzz_double(acc);
     store_affine(next + i, xyzz_to_affine(acc));
+}
+
+// R = 2^256 Montgomery coordinates -> the 2^261 domain of the accumulate kernel's arithmetic (x * 32 mod q); the
+// identity (0, 0) maps to itself
+__global__ void __launch_bounds__(256) table_widen_kernel(g1_affine* pts, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    fe k;
+#pragma unroll
+    for (int j = 0; j < 8; j++) k.l[j] = FqParams::TWO5[j];
+    g1_affine p = load_affine(pts + i);
+    p.x = Fq::mul(p.x, k);
+    p.y = Fq::mul(p.y, k);
+    store_affine(pts + i, p);
 }
 
 // ---- digits ----------------------------------------------------------------------------------------
@@ -328,35 +344,24 @@ __global__ void __launch_bounds__(256) accumulate_kernel(const uint32_t* entries
     const uint32_t s = t - slot_off[b], f = slot_cnt[b], c = cnt[b];
     const uint32_t lo = start[b] + (uint32_t)((uint64_t)s * c / f);
     const uint32_t hi = start[b] + (uint32_t)((uint64_t)(s + 1) * c / f);
-    g1_xyzz acc = xyzz_identity();
+    g1_xyzz_w acc;
+    acc.inf = true;
+    acc.x = acc.y = acc.zz = acc.zzz = FqW::zero();
     uint32_t e = entries[lo];
     g1_affine p = load_affine(tables + (size_t)((e >> ENTRY_IDX_BITS) & 31) * table_stride + first + (e & ENTRY_IDX_MASK));
     for (uint32_t k = lo; k < hi; k++) {
         const uint32_t ecur = e;
-        g1_affine q = p;
+        const g1_affine q = p;
         if (k + 1 < hi) {   // prefetch the next point while this one is added
             e = entries[k + 1];
             p = load_affine(tables + (size_t)((e >> ENTRY_IDX_BITS) & 31) * table_stride + first + (e & ENTRY_IDX_MASK));
         }
-        if (ecur & 0x80000000u) q.y = Fq::neg(q.y);
-        xyzz_add_affine(acc, q);
+        xyzz_w_add_affine(acc, q, (ecur & 0x80000000u) != 0);
     }
-    store_xyzz(items + t, acc);
+    xyzz_w_store(items + t, acc);
 }
 
 // ---- merge -----------------------------------------------------------------------------------------
-__device__ __forceinline__ g1_xyzz shfl_xyzz(const g1_xyzz& v, int src_lane) {
-    g1_xyzz o;
-#pragma unroll
-    for (int i = 0; i < 8; i++) {
-        o.x.l[i] = __shfl(v.x.l[i], src_lane, 64);
-        o.y.l[i] = __shfl(v.y.l[i], src_lane, 64);
-        o.zz.l[i] = __shfl(v.zz.l[i], src_lane, 64);
-        o.zzz.l[i] = __shfl(v.zzz.l[i], src_lane, 64);
-    }
-    return o;
-}
-
 // pre-level for very heavy buckets: one lane folds up to F consecutive items of one bucket
 __global__ void __launch_bounds__(256) merge_kernel(const g1_xyzz* in, const uint32_t* off_in, const uint32_t* cnt_in,
                                                     const uint32_t* off_out, uint32_t B, uint32_t F, g1_xyzz* out) {
@@ -367,9 +372,9 @@ __global__ void __launch_bounds__(256) merge_kernel(const g1_xyzz* in, const uin
     const uint32_t lo = off_in[b] + j * F;
     const uint32_t end = off_in[b] + cnt_in[b];
     const uint32_t hi = lo + F < end ? lo + F : end;
-    g1_xyzz acc = load_xyzz(in + lo);
-    for (uint32_t k = lo + 1; k < hi; k++) acc = xyzz_add(acc, load_xyzz(in + k));
-    store_xyzz(out + t, acc);
+    g1_xyzz_w acc = xyzz_w_load(in + lo);
+    for (uint32_t k = lo + 1; k < hi; k++) acc = xyzz_w_add(acc, xyzz_w_load(in + k));
+    xyzz_w_store(out + t, acc);
 }
 
 // final level: MERGE_P neighbouring lanes share one bucket; lane r folds items r, r + P, ... and a shuffle tree joins
@@ -380,43 +385,44 @@ __global__ void __launch_bounds__(256) merge_final_kernel(const g1_xyzz* in, con
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t b = t / MERGE_P, r = t % MERGE_P;
     const uint32_t lane = threadIdx.x & 63;
-    g1_xyzz acc = xyzz_identity();
+    g1_xyzz_w acc = xyzz_w_identity();
     if (b < B) {
         const uint32_t c = cnt_in[b], base = off_in[b];
         if (r < c) {
-            acc = load_xyzz(in + base + r);
-            for (uint32_t i = r + MERGE_P; i < c; i += MERGE_P) acc = xyzz_add(acc, load_xyzz(in + base + i));
+            acc = xyzz_w_load(in + base + r);
+            for (uint32_t i = r + MERGE_P; i < c; i += MERGE_P) acc = xyzz_w_add(acc, xyzz_w_load(in + base + i));
         }
     }
     for (int d = MERGE_P / 2; d >= 1; d >>= 1) {
-        const g1_xyzz o = shfl_xyzz(acc, (int)(lane ^ d));
-        acc = xyzz_add(acc, o);
+        const g1_xyzz_w o = xyzz_w_shfl(acc, (int)(lane ^ d));
+        acc = xyzz_w_add(acc, o);
     }
-    if (b < B && r == 0) store_xyzz(out + b, acc);
+    if (b < B && r == 0) xyzz_w_store(out + b, acc);
 }
 
 // ---- reduce ----------------------------------------------------------------------------------------
 // sum over b of (b + 1) * S_b.  Within a wave of 64 consecutive points P_0..P_63 a suffix scan T_i = sum_{k >= i} P_k
 // gives A = T_0 = sum P_i and V = sum_{i >= 1} T_i = sum i * P_i in 12 point additions, with no scalar multiplication.
 // Level 1 does this for every 64 buckets, level 2 for the A's of 64 waves; the host joins the <= 24 leftovers.
-__device__ __forceinline__ void wave_weighted_sum(g1_xyzz p, uint32_t lane, g1_xyzz& a_out, g1_xyzz& v_out) {
+__device__ __forceinline__ void wave_weighted_sum(g1_xyzz_w p, uint32_t lane, g1_xyzz_w& a_out, g1_xyzz_w& v_out) {
     for (int d = 1; d < 64; d <<= 1) {
-        g1_xyzz o = shfl_xyzz(p, (int)((lane + d) & 63));
-        if (lane + d >= 64) o = xyzz_identity();
-        p = xyzz_add(p, o);
+        g1_xyzz_w o = xyzz_w_shfl(p, (int)((lane + d) & 63));
+        if (lane + d >= 64) o.inf = true;
+        p = xyzz_w_add(p, o);
     }
-    a_out = shfl_xyzz(p, 0);
-    g1_xyzz v = lane >= 1 ? p : xyzz_identity();
+    a_out = xyzz_w_shfl(p, 0);
+    g1_xyzz_w v = p;
+    if (lane == 0) v.inf = true;
     for (int d = 32; d >= 1; d >>= 1) {
-        const g1_xyzz o = shfl_xyzz(v, (int)(lane ^ d));
-        v = xyzz_add(v, o);
+        const g1_xyzz_w o = xyzz_w_shfl(v, (int)(lane ^ d));
+        v = xyzz_w_add(v, o);
     }
     v_out = v;
 }
-__device__ __forceinline__ g1_xyzz wave_sum_xyzz(g1_xyzz v, uint32_t lane) {
+__device__ __forceinline__ g1_xyzz_w wave_sum_xyzz(g1_xyzz_w v, uint32_t lane) {
     for (int d = 32; d >= 1; d >>= 1) {
-        const g1_xyzz o = shfl_xyzz(v, (int)(lane ^ d));
-        v = xyzz_add(v, o);
+        const g1_xyzz_w o = xyzz_w_shfl(v, (int)(lane ^ d));
+        v = xyzz_w_add(v, o);
     }
     return v;
 }
@@ -424,12 +430,12 @@ __device__ __forceinline__ g1_xyzz wave_sum_xyzz(g1_xyzz v, uint32_t lane) {
 // level 1: sums[b] for b < B (B a multiple of 64) -> a1[j], v1[j] for wave j = b / 64
 __global__ void __launch_bounds__(256) reduce_level1_kernel(const g1_xyzz* sums, uint32_t B, g1_xyzz* a1, g1_xyzz* v1) {
     const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x, lane = threadIdx.x & 63;
-    g1_xyzz p = b < B ? load_xyzz(sums + b) : xyzz_identity();
-    g1_xyzz a, v;
+    g1_xyzz_w p = b < B ? xyzz_w_load(sums + b) : xyzz_w_identity();
+    g1_xyzz_w a, v;
     wave_weighted_sum(p, lane, a, v);
     if (lane == 0) {
-        store_xyzz(a1 + (b >> 6), a);
-        store_xyzz(v1 + (b >> 6), v);
+        xyzz_w_store(a1 + (b >> 6), a);
+        xyzz_w_store(v1 + (b >> 6), v);
     }
 }
 // level 2 (16 blocks of one wave, J <= 512): blocks h < 8 take a1[64 h + lane] -> out[h] = sum, out[8 + h] = sum of
@@ -438,17 +444,17 @@ __global__ void __launch_bounds__(64) reduce_level2_kernel(const g1_xyzz* a1, co
     const uint32_t lane = threadIdx.x, h = blockIdx.x & 7;
     const uint32_t j = h * 64 + lane;
     if (blockIdx.x < 8) {
-        g1_xyzz p = j < J ? load_xyzz(a1 + j) : xyzz_identity();
-        g1_xyzz a, v;
+        g1_xyzz_w p = j < J ? xyzz_w_load(a1 + j) : xyzz_w_identity();
+        g1_xyzz_w a, v;
         wave_weighted_sum(p, lane, a, v);
         if (lane == 0) {
-            store_xyzz(out + h, a);
-            store_xyzz(out + 8 + h, v);
+            xyzz_w_store(out + h, a);
+            xyzz_w_store(out + 8 + h, v);
         }
     } else {
-        g1_xyzz p = j < J ? load_xyzz(v1 + j) : xyzz_identity();
+        g1_xyzz_w p = j < J ? xyzz_w_load(v1 + j) : xyzz_w_identity();
         p = wave_sum_xyzz(p, lane);
-        if (lane == 0) store_xyzz(out + 16 + h, p);
+        if (lane == 0) xyzz_w_store(out + 16 + h, p);
     }
 }
 
@@ -481,7 +487,19 @@ static uint32_t log2_ceil(size_t n) {
     return l;
 }
 
-static void xyzz_to_jacobian_host(uint64_t out[12], const uint64_t in[16]) {
+// in: XYZZ with coordinates x * 2^261 (the kernels' domain); out: Jacobian with coordinates in the 2^256 domain
+static void xyzz_to_jacobian_host(uint64_t out[12], const uint64_t in_wide[16]) {
+    struct Inv32 {
+        uint64_t v[4];
+        Inv32() {
+            uint64_t k32[4];
+            h_from_u64(HFQ, k32, 32);
+            h_inv(HFQ, v, k32);
+        }
+    };
+    static const Inv32 inv32;
+    uint64_t in[16];
+    for (int k = 0; k < 4; k++) h_mul(HFQ, in + 4 * k, in_wide + 4 * k, inv32.v);
     const uint64_t *X = in, *Y = in + 4, *ZZ = in + 8, *ZZZ = in + 12;
     if (h_is_zero(ZZ)) {
         memset(out, 0, 96);
@@ -810,6 +828,9 @@ int zkhip_register_bases(zkhip_ctx* ctx, const uint64_t* affine_xy, size_t n, ui
         for (uint32_t w = 1; w < tb.W; w++)
             hipLaunchKernelGGL(table_next_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream,
                                tb.d_tables + (size_t)(w - 1) * n, tb.d_tables + (size_t)w * n, n, tb.c);
+        const size_t total = (size_t)tb.W * n;
+        hipLaunchKernelGGL(table_widen_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, tb.d_tables,
+                           total);
         e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);

@@ -1,0 +1,219 @@
+// Lazy signed-digit arithmetic for BN254 Fr / Fq inside kernels ("wide" form).
+//
+// A value is nine signed 32-bit digits of weight 2^(29 i); the represented integer is only fixed modulo p and
+// may be negative or exceed p.  add / sub / neg work digit by digit with no carries and no comparison against
+// p.  mul is a Montgomery multiplication with R' = 2^261 (all nine digits retired), computed with signed
+// 64-bit multiply-adds (v_mad_i64_i32) in 64-bit columns:
+//
+//     mul(a, b) = (a b + m p) / 2^261,   0 <= m < 2^261   =>   a b / 2^261 <= result < a b / 2^261 + p
+//
+// Because 2^261 / p > 147, a product of operands of a few p in magnitude lands back in (-p/10, 1.1 p): the
+// multiplications themselves keep every value small and no modular reduction is ever executed between
+// operations.  What callers must keep track of is the digit magnitude:
+//
+//     "normalised"  digits 0..7 in [0, 2^29), digit 8 signed and small       (mul, sqr, norm, from_fe results)
+//     "lazy"        sums / differences of normalised values, |digit| < 2^31
+//
+//   mul / sqr operands: the column sums need  9 |a_i| |b_j| + 9 * 2^58 < 2^63, so a difference of two normalised
+//   values (|digit| < 2^29) is a valid operand next to another such difference or a normalised value; a sum of two
+//   normalised values (|digit| < 2^30) is valid next to a normalised value only.  Anything larger goes through
+//   norm() first (25 instructions, against ~24 for ONE packed modular addition).
+//
+// Elements enter with from_fe (the packed in-memory form, any Montgomery domain: wide form does not care what
+// the residue means) and leave with to_fe, which produces the canonical packed residue in [0, p).
+// A value x kept as x 2^261 in wide form is obtained from the in-memory x 2^256 by one packed multiplication
+// with FP::TWO5, and returns to x 2^256 through mul(v, r256()).
+#pragma once
+#include "field.cuh"
+
+namespace zkhip {
+
+struct fw {
+    int32_t d[9];
+};
+
+template <class FP>
+struct Wide {
+    ZK_DEV static fw zero() {
+        fw o;
+#pragma unroll
+        for (int i = 0; i < 9; i++) o.d[i] = 0;
+        return o;
+    }
+    // packed 256-bit value (< 2^256) -> normalised digits
+    ZK_DEV static fw from_fe(const fe& a) {
+        const d29 u = unpack29(a);
+        fw o;
+#pragma unroll
+        for (int i = 0; i < 9; i++) o.d[i] = (int32_t)u.d[i];
+        return o;
+    }
+    ZK_DEV static fw from_words(const uint32_t w[8]) {
+        fe t;
+#pragma unroll
+        for (int i = 0; i < 8; i++) t.l[i] = w[i];
+        return from_fe(t);
+    }
+    ZK_DEV static fw one() { return from_words(FP::TWO5); }    // 1 in the 2^261 Montgomery domain
+    ZK_DEV static fw r256() { return from_words(FP::ONE); }    // 2^256 mod p as an integer: mul(x 2^261, r256) = x 2^256
+
+    ZK_DEV static fw add(const fw& a, const fw& b) {
+        fw o;
+#pragma unroll
+        for (int i = 0; i < 9; i++) o.d[i] = a.d[i] + b.d[i];
+        return o;
+    }
+    ZK_DEV static fw sub(const fw& a, const fw& b) {
+        fw o;
+#pragma unroll
+        for (int i = 0; i < 9; i++) o.d[i] = a.d[i] - b.d[i];
+        return o;
+    }
+    ZK_DEV static fw neg(const fw& a) {
+        fw o;
+#pragma unroll
+        for (int i = 0; i < 9; i++) o.d[i] = -a.d[i];
+        return o;
+    }
+    ZK_DEV static fw dbl(const fw& a) {
+        fw o;
+#pragma unroll
+        for (int i = 0; i < 9; i++) o.d[i] = a.d[i] << 1;
+        return o;
+    }
+    // negate when flag is set
+    ZK_DEV static fw cneg(const fw& a, bool flag) {
+        const int32_t m = flag ? -1 : 0;
+        fw o;
+#pragma unroll
+        for (int i = 0; i < 9; i++) o.d[i] = (a.d[i] ^ m) - m;
+        return o;
+    }
+    // carry propagation: digits 0..7 into [0, 2^29), the rest of the value into the signed top digit
+    ZK_DEV static fw norm(const fw& a) {
+        fw o;
+        int32_t c = 0;
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const int32_t t = a.d[i] + c;
+            o.d[i] = t & (int32_t)M29;
+            c = t >> 29;
+        }
+        o.d[8] = a.d[8] + c;
+        return o;
+    }
+
+    // Montgomery reduction by 2^261 of 17 signed product columns; normalised result
+    ZK_DEV static fw reduce(int64_t col[18]) {
+#pragma unroll
+        for (int k = 0; k < 9; k++) {
+            const int32_t m = (int32_t)(((uint32_t)col[k] * FP::INV29) & M29);
+#pragma unroll
+            for (int j = 0; j < 9; j++) col[k + j] += (int64_t)m * (int32_t)FP::P29[j];
+            col[k + 1] += col[k] >> 29;
+        }
+        fw o;
+#pragma unroll
+        for (int k = 9; k < 17; k++) {
+            o.d[k - 9] = (int32_t)((uint32_t)col[k] & M29);
+            col[k + 1] += col[k] >> 29;
+        }
+        o.d[8] = (int32_t)col[17];
+        return o;
+    }
+    ZK_DEV static fw mul(const fw& a, const fw& b) {
+        int64_t col[18];
+#pragma unroll
+        for (int k = 0; k < 18; k++) col[k] = 0;
+#pragma unroll
+        for (int i = 0; i < 9; i++)
+#pragma unroll
+            for (int j = 0; j < 9; j++) col[i + j] += (int64_t)a.d[i] * b.d[j];
+        return reduce(col);
+    }
+    // operand digits must stay below 2^29 in magnitude (the doubled cross terms use 2 a_i)
+    ZK_DEV static fw sqr(const fw& a) {
+        int64_t col[18];
+#pragma unroll
+        for (int k = 0; k < 18; k++) col[k] = 0;
+#pragma unroll
+        for (int i = 0; i < 9; i++) {
+            col[2 * i] += (int64_t)a.d[i] * a.d[i];
+            const int32_t a2 = a.d[i] << 1;
+#pragma unroll
+            for (int j = i + 1; j < 9; j++) col[i + j] += (int64_t)a2 * a.d[j];
+        }
+        return reduce(col);
+    }
+
+    // Cheap necessary condition for value == 0 (mod p) when |value| < 16 p: value = k p forces the low 29 bits to be
+    // k p mod 2^29, i.e. low * p^-1 mod 2^29 lies within [-16, 16].  Passes a non-multiple with probability 2^-24.
+    ZK_DEV static bool maybe_zero(const fw& a) {
+        const uint32_t k = ((uint32_t)a.d[0] * (0u - FP::INV29)) & M29;   // p^-1 = -(-p^-1)
+        return ((k + 16u) & M29) <= 32u;
+    }
+
+    // canonical packed residue in [0, p) of a value with |value| < 64 p
+    ZK_DEV static fe to_fe(const fw& v) {
+        fw a = norm(v);
+        // q ~ floor(value / p) from the top digit, deliberately two short so that the remainder is positive
+        const float qf = floorf((float)a.d[8] * (1.0f / (float)(FP::P29[8] + 1)));
+        const int32_t q = (int32_t)qf - 2;
+        int64_t c = 0;
+        fw w;
+#pragma unroll
+        for (int i = 0; i < 9; i++) {
+            const int64_t t = (int64_t)a.d[i] - (int64_t)q * (int32_t)FP::P29[i] + c;
+            if (i < 8) {
+                w.d[i] = (int32_t)((uint32_t)t & M29);
+                c = t >> 29;
+            } else {
+                w.d[i] = (int32_t)t;
+            }
+        }
+        // now p <= w < 4 p (the float estimate may be one off in either direction): subtract p while it fits
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            fw t;
+            int32_t cc = 0;
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                const int32_t s = w.d[i] - (int32_t)FP::P29[i] + cc;
+                t.d[i] = s & (int32_t)M29;
+                cc = s >> 29;
+            }
+            t.d[8] = w.d[8] - (int32_t)FP::P29[8] + cc;
+            const bool keep = t.d[8] >= 0;
+#pragma unroll
+            for (int i = 0; i < 9; i++) w.d[i] = keep ? t.d[i] : w.d[i];
+        }
+        // pack nine 29-bit digits (top digit < 2^22) into 8 words
+        uint32_t n[10];
+#pragma unroll
+        for (int i = 0; i < 9; i++) n[i] = (uint32_t)w.d[i];
+        n[9] = 0;
+        fe o;
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const int bit = 32 * k, i = bit / 29, s = bit % 29;
+            uint32_t x = n[i] >> s;
+            if (i + 1 < 10) x |= n[i + 1] << (29 - s);
+            if (58 - s < 32 && i + 2 < 10) x |= n[i + 2] << (58 - s);
+            o.l[k] = x;
+        }
+        return o;
+    }
+    // exact test for value == 0 (mod p), |value| < 64 p
+    ZK_DEV static bool is_zero(const fw& v) {
+        const fe c = to_fe(v);
+        uint32_t x = 0;
+#pragma unroll
+        for (int i = 0; i < 8; i++) x |= c.l[i];
+        return x == 0;
+    }
+};
+
+using FrW = Wide<FrParams>;
+using FqW = Wide<FqParams>;
+
+}  // namespace zkhip
