@@ -9,17 +9,23 @@
 //     accumulator for the whole program, so the output is written once instead of once per argument;
 //   * permutation and lookup terms are emitted as instructions following upstream's formulas; their cosets, l0,
 //     l_last, l_active_row and the row's point zeta * extended_omega^idx join the unified column table;
-//   * values get slots by liveness; the slots with the densest use live in LDS ([slot][lane], 32 B), the rest spill
-//     to a [slot][row] buffer in HBM.  The launch reserves only the LDS the program needs, so that three 256-lane
-//     workgroups share a CU.
+//   * values get slots by liveness; the slots with the densest use live in LDS ([slot][digit][lane]), the rest spill
+//     to a [slot][digit][row] buffer in HBM.  The launch reserves only the LDS the program needs, so that three
+//     256-lane workgroups share a CU;
+//   * arithmetic runs in the lazy signed-digit form of wide.cuh (nine 29-bit digits, Montgomery radix 2^261): a
+//     multiply-add is one Montgomery product, nine digit additions and a carry pass, with no comparison against p;
+//     the host bounds every value's magnitude while it builds the program and the kernel canonicalises the result.
 // Every instruction is r = (a * b | a) (+ c | - c | nothing): the interpreter holds one multiplier instance.  The
-// program is wave-uniform: decode runs on the scalar unit, every branch is a scalar branch, column reads are
-// (row + rotation * 2^(ext_k - k)) mod 2^ext_k, i.e. 32 contiguous bytes per lane.
+// program is wave-uniform: its words arrive by scalar loads with column pointers and row offsets already resolved,
+// every branch is a scalar branch, and the column / constant reads of instruction pc + 1 are issued before
+// instruction pc computes.  Column reads are (row + rotation * 2^(ext_k - k)) mod 2^ext_k, i.e. 32 contiguous bytes
+// per lane.
 // Results equal upstream's bit for bit: field arithmetic is exact, only the order of independent operations differs.
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
 #include "domain.h"
+#include "wide.cuh"
 
 using namespace zkhip;
 
@@ -36,64 +42,136 @@ constexpr uint32_t W_ZERO = K_ZERO << 28, W_ACC = K_ACC << 28;
 // scalar table layout
 constexpr uint32_t SC_BETA = 0, SC_GAMMA = 1, SC_THETA = 2, SC_Y = 3, SC_ONE = 4, SC_CHALLENGE0 = 5;
 
+// Linked program: 12 words per instruction,
+//   [0] flags | dst << 8, then for each operand a, b, c: header = kind << 28 | payload, pointer low, pointer high.
+//   L_ROW : pointer = column base, payload = signed row offset of the rotation (28 bits)
+//   L_UNI : pointer = one field element read by every lane (constant / scalar)
+//   L_SLOT: payload = value slot;  L_ACC: the running value;  L_ZERO
+// The words are read through the constant address space, i.e. by scalar loads: decode never touches the vector
+// memory path and needs no table lookups.
+enum LinkKind : uint32_t { L_ZERO = 0, L_ROW, L_UNI, L_SLOT, L_ACC };
+constexpr uint32_t INS_WORDS = 12;
+constexpr int EV_DEPTH = 2;
+typedef const uint32_t __attribute__((address_space(4))) * prog_ptr;
+
+struct Opnd {
+    uint32_t hdr;
+    const fe* ptr;
+};
 struct InterpArgs {
-    const uint32_t* prog;       // 4 words per instruction
     uint32_t n_instr;
-    uint32_t result;            // operand word of the final value
-    const fe* consts;
-    const fe* scalars;
-    const fe* const* cols;      // unified column table (extended cosets)
-    const int32_t* rots;
+    uint32_t result_hdr;        // operand of the final value (slot / running value / zero)
     uint32_t lds_slots;
-    fe* spill;                  // [slot - lds_slots][size]
     uint32_t log_size;          // extended_k
-    uint32_t rot_scale;         // 2^(extended_k - k)
+    int32_t* spill;             // [slot - lds_slots][digit][size]
     fe* out;
 };
 
-__device__ __forceinline__ fe ev_fetch(const InterpArgs& a, uint32_t word, const fe* lds, const fe& acc, uint32_t idx,
-                                       uint32_t mask) {
-    const uint32_t kind = word >> 28, pl = word & 0x0fffffffu;
+__device__ __forceinline__ Opnd ev_operand(prog_ptr w) {
+    Opnd o;
+    o.hdr = w[0];
+    o.ptr = reinterpret_cast<const fe*>(((uint64_t)w[2] << 32) | w[1]);
+    return o;
+}
+// issues the memory read of a column / constant operand (other kinds read nothing)
+__device__ __forceinline__ fe ev_raw(const Opnd& o, uint32_t idx, uint32_t mask) {
+    const uint32_t kind = o.hdr >> 28;
+    if (kind == L_ROW) {
+        const int32_t delta = (int32_t)(o.hdr << 4) >> 4;
+        return load_fe(o.ptr + ((uint32_t)((int32_t)idx + delta) & mask));
+    }
+    if (kind == L_UNI) return load_fe(o.ptr);
+    return Fr::zero();
+}
+// Values are held in the lazy signed-digit form of wide.cuh, 2^261 Montgomery domain, always normalised.  Columns
+// enter through from_fe_shl5 (value up to 32 p); the host tracks magnitudes and keeps every stored value below EV_LIMIT p.
+__device__ __forceinline__ fw ev_value(const InterpArgs& a, const Opnd& o, const fe& raw, const int32_t* lds, const fw& acc,
+                                       uint32_t idx) {
+    const uint32_t kind = o.hdr >> 28, pl = o.hdr & 0x0fffffffu;
     switch (kind) {
-        case K_CONST: return load_fe(a.consts + pl);
-        case K_SLOT:
-            if (pl < a.lds_slots) return lds[pl * EV_THREADS + threadIdx.x];
-            return load_fe(a.spill + ((size_t)(pl - a.lds_slots) << a.log_size) + idx);
-        case K_COL: {
-            const fe* col = a.cols[pl >> 12];
-            const int32_t rot = a.rots[pl & 0xfff];
-            return load_fe(col + ((uint32_t)((int32_t)idx + rot * (int32_t)a.rot_scale) & mask));
+        case L_ROW: return FrW::from_fe_shl5(raw);
+        case L_UNI: return FrW::from_fe(raw);
+        case L_SLOT: {
+            fw v;
+            if (pl < a.lds_slots) {
+#pragma unroll
+                for (int d = 0; d < 9; d++) v.d[d] = lds[(pl * 9 + d) * EV_THREADS + threadIdx.x];
+            } else {
+                const int32_t* base = a.spill + (((size_t)(pl - a.lds_slots) * 9) << a.log_size) + idx;
+#pragma unroll
+                for (int d = 0; d < 9; d++) v.d[d] = base[(size_t)d << a.log_size];
+            }
+            return v;
         }
-        case K_SCALAR: return load_fe(a.scalars + pl);
-        case K_ACC: return acc;
-        default: return Fr::zero();
+        case L_ACC: return acc;
+        default: return FrW::zero();
     }
 }
 
-__global__ void __launch_bounds__(EV_THREADS) evalh_interp_kernel(const InterpArgs a) {
+// decoded instruction plus the raw memory operands whose loads are already in flight
+struct Staged {
+    uint32_t w0;
+    Opnd a, b, c;
+    fe ra, rb, rc;
+};
+__device__ __forceinline__ void ev_stage(Staged& s, prog_ptr w, uint32_t idx, uint32_t mask) {
+    s.w0 = w[0];
+    s.a = ev_operand(w + 1);
+    s.b = ev_operand(w + 4);
+    s.c = ev_operand(w + 7);
+    const uint32_t ka = s.a.hdr >> 28, kb = s.b.hdr >> 28, kc = s.c.hdr >> 28;
+    if (ka == L_ROW || ka == L_UNI) s.ra = ev_raw(s.a, idx, mask);
+    if (kb == L_ROW || kb == L_UNI) s.rb = ev_raw(s.b, idx, mask);
+    if (kc == L_ROW || kc == L_UNI) s.rc = ev_raw(s.c, idx, mask);
+}
+__device__ __forceinline__ void ev_execute(const InterpArgs& a, const Staged& s, int32_t* lds, fw& acc, uint32_t idx) {
+    const uint32_t w0 = s.w0, dst = w0 >> 8;
+    fw t = ev_value(a, s.a, s.ra, lds, acc, idx);
+    if (w0 & F_MUL) t = FrW::mul(t, ev_value(a, s.b, s.rb, lds, acc, idx));
+    if (w0 & (F_ADD | F_SUB)) {
+        const fw c = ev_value(a, s.c, s.rc, lds, acc, idx);
+        t = FrW::norm((w0 & F_ADD) ? FrW::add(t, c) : FrW::sub(t, c));
+    }
+    if (dst == DST_ACC) {
+        acc = t;
+    } else if (dst < a.lds_slots) {
+#pragma unroll
+        for (int d = 0; d < 9; d++) lds[(dst * 9 + d) * EV_THREADS + threadIdx.x] = t.d[d];
+    } else {
+        int32_t* base = a.spill + (((size_t)(dst - a.lds_slots) * 9) << a.log_size) + idx;
+#pragma unroll
+        for (int d = 0; d < 9; d++) base[(size_t)d << a.log_size] = t.d[d];
+    }
+}
+
+__global__ void __launch_bounds__(EV_THREADS) evalh_interp_kernel(const uint32_t* prog_generic, const InterpArgs a) {
     extern __shared__ __align__(16) unsigned char smem[];
-    fe* lds = reinterpret_cast<fe*>(smem);
+    int32_t* lds = reinterpret_cast<int32_t*>(smem);
+    const prog_ptr prog = (prog_ptr)prog_generic;
     const uint32_t idx = blockIdx.x * EV_THREADS + threadIdx.x;
     const uint32_t mask = (1u << a.log_size) - 1;
     if (idx > mask) return;   // domains smaller than one workgroup
-    fe acc = Fr::zero();
-    for (uint32_t pc = 0; pc < a.n_instr; pc++) {
-        const uint32_t w0 = __builtin_amdgcn_readfirstlane(a.prog[4 * pc]);
-        const uint32_t wa = __builtin_amdgcn_readfirstlane(a.prog[4 * pc + 1]);
-        const uint32_t wb = __builtin_amdgcn_readfirstlane(a.prog[4 * pc + 2]);
-        const uint32_t wc = __builtin_amdgcn_readfirstlane(a.prog[4 * pc + 3]);
-        const uint32_t dst = w0 >> 8;
-        fe t = ev_fetch(a, wa, lds, acc, idx, mask);
-        if (w0 & F_MUL) t = Fr::mul(t, ev_fetch(a, wb, lds, acc, idx, mask));
-        if (w0 & (F_ADD | F_SUB)) {
-            const fe c = ev_fetch(a, wc, lds, acc, idx, mask);
-            t = (w0 & F_ADD) ? Fr::add(t, c) : Fr::sub(t, c);
+    fw acc = FrW::zero();
+    // software pipeline over EV_DEPTH staging sets: while instruction pc computes, instructions pc + 1 .. pc + EV_DEPTH - 1
+    // are already decoded and their column / constant loads are in flight
+    Staged st[EV_DEPTH];
+#pragma unroll
+    for (int j = 0; j < EV_DEPTH - 1; j++)
+        if ((uint32_t)j < a.n_instr) ev_stage(st[j], prog + (size_t)j * INS_WORDS, idx, mask);
+    for (uint32_t pc = 0; pc < a.n_instr; pc += EV_DEPTH) {
+#pragma unroll
+        for (int j = 0; j < EV_DEPTH; j++) {
+            const uint32_t cur = pc + j, ahead = cur + EV_DEPTH - 1;
+            if (ahead < a.n_instr) ev_stage(st[(j + EV_DEPTH - 1) % EV_DEPTH], prog + (size_t)ahead * INS_WORDS, idx, mask);
+            if (cur < a.n_instr) ev_execute(a, st[j], lds, acc, idx);
         }
-        if (dst == DST_ACC) acc = t;
-        else if (dst < a.lds_slots) lds[dst * EV_THREADS + threadIdx.x] = t;
-        else store_fe(a.spill + ((size_t)(dst - a.lds_slots) << a.log_size) + idx, t);
     }
-    store_fe(a.out + idx, ev_fetch(a, a.result, lds, acc, idx, mask));
+    // back to the 2^256 domain, canonical
+    Opnd ro;
+    ro.hdr = a.result_hdr;
+    ro.ptr = nullptr;
+    const fw r = ev_value(a, ro, Fr::zero(), lds, acc, idx);
+    store_fe(a.out + idx, FrW::to_fe(FrW::mul(r, FrW::r256())));
 }
 
 // x[idx] = zeta * extended_omega^idx: the point of extended row idx
@@ -179,12 +257,41 @@ struct Builder {
     uint32_t col(uint32_t c, int32_t r) { return (K_COL << 28) | (c << 12) | rot(r); }
     static uint32_t scalar(uint32_t i) { return (K_SCALAR << 28) | i; }
     static uint32_t slot(uint32_t v) { return (K_SLOT << 28) | v; }
-    uint32_t fresh() { return n_virtual++; }
+    uint32_t fresh() {
+        vbound.push_back(0.0);
+        return n_virtual++;
+    }
+    // Upper bounds on |value| / p.  A multiplication maps (x, y) to below x y / 147 + 1 (Montgomery radix 2^261 over
+    // p < 2^254); a column read is below 32; additions add.  Every stored value is kept below EV_LIMIT so that its top
+    // digit stays a valid multiplier operand: a value that would exceed it is multiplied by one right away.
+    static constexpr double EV_LIMIT = 120.0, EV_CONTRACT = 147.0;
+    std::vector<double> vbound;
+    double acc_bound = 0.0;
+    double bound(uint32_t w) const {
+        switch (w >> 28) {
+            case K_CONST: case K_SCALAR: return 1.0;
+            case K_COL: return 32.0;
+            case K_SLOT: return vbound[w & 0x0fffffffu];
+            case K_ACC: return acc_bound;
+            default: return 0.0;
+        }
+    }
     void emit(uint32_t flags, uint32_t dst, uint32_t a, uint32_t b = W_ZERO, uint32_t c = W_ZERO) {
+        double v = bound(a);
+        if (flags & F_MUL) v = v * bound(b) / EV_CONTRACT + 1.0;
+        if (flags & (F_ADD | F_SUB)) v += bound(c);
         words.push_back(flags | (dst << 8));
         words.push_back(a);
         words.push_back(b);
         words.push_back(c);
+        if (v > EV_LIMIT) {
+            words.push_back(F_MUL | (dst << 8));
+            words.push_back(dst == DST_ACC ? W_ACC : slot(dst));
+            words.push_back(scalar(SC_ONE));
+            words.push_back(W_ZERO);
+            v = v / EV_CONTRACT + 1.0;
+        }
+        (dst == DST_ACC ? acc_bound : vbound[dst]) = v;
     }
     // value-returning helpers (destination = fresh virtual value)
     uint32_t mul(uint32_t a, uint32_t b) { const uint32_t d = fresh(); emit(F_MUL, d, a, b); return slot(d); }
@@ -618,9 +725,9 @@ extern "C" int zkhip_evaluate_h(zkhip_domain* dom, const zkhip_evalh_desc* desc,
     ZK_CHECK(ctx, b.n_virtual < DST_ACC, "evaluate_h: program too large");
 
     // ---- slots, tables, launch -----------------------------------------------------------------------
-    // LDS budget per lane: 6 slots of 32 B keep three 256-lane workgroups on a CU (the register file allows three)
+    // LDS budget per lane: 5 slots of 36 B (nine digits) keep three 256-lane workgroups on a CU
     const char* env_slots = getenv("ZKHIP_EVALH_LDS_SLOTS");
-    const uint32_t lds_budget = env_slots && *env_slots ? (uint32_t)atoi(env_slots) : 6;
+    const uint32_t lds_budget = env_slots && *env_slots ? (uint32_t)atoi(env_slots) : 5;
     uint32_t result = W_ACC, lds_slots = 1, n_slots = 1;
     assign_slots(b.words, result, b.n_virtual, lds_budget, lds_slots, n_slots);
     if (getenv("ZKHIP_DEBUG")) {
@@ -648,18 +755,57 @@ extern "C" int zkhip_evaluate_h(zkhip_domain* dom, const zkhip_evalh_desc* desc,
     memcpy(&scal[4 * SC_ONE], HFR.r, 32);
     if (desc->num_challenges) memcpy(&scal[4 * SC_CHALLENGE0], desc->challenges, (size_t)desc->num_challenges * 32);
     scal.insert(scal.end(), extra_scalars.begin(), extra_scalars.end());
+    // scalars and constants move to the interpreter's 2^261 Montgomery domain: x R -> 32 x R
+    {
+        uint64_t k32[4];
+        memcpy(k32, FrParams::TWO5, 32);
+        for (size_t i = 0; i + 4 <= scal.size(); i += 4) h_mul(HFR, &scal[i], &scal[i], k32);
+        for (size_t i = 0; i + 4 <= b.consts.size(); i += 4) h_mul(HFR, &b.consts[i], &b.consts[i], k32);
+    }
 
     InterpArgs a;
     memset(&a, 0, sizeof a);
-    uint32_t* d_prog;
     fe *d_scal, *d_consts;
-    int32_t* d_rots;
-    const fe** d_cols;
-    if ((rc = ar.upload(b.words.data(), b.words.size(), &d_prog))) return rc;
     if ((rc = ar.upload((const fe*)scal.data(), scal.size() / 4, &d_scal))) return rc;
     if ((rc = ar.upload((const fe*)b.consts.data(), b.consts.size() / 4, &d_consts))) return rc;
-    if ((rc = ar.upload(b.rots.data(), b.rots.size(), &d_rots))) return rc;
-    if ((rc = ar.upload(cols.data(), cols.size(), &d_cols))) return rc;
+    // link: operand words -> (header, device pointer)
+    const int32_t rot_scale = 1 << (ek - k);
+    auto link = [&](uint32_t w, uint32_t* o) {
+        const uint32_t kind = w >> 28, pl = w & 0x0fffffffu;
+        uint64_t ptr = 0;
+        uint32_t hdr;
+        switch (kind) {
+            case K_CONST: hdr = L_UNI << 28; ptr = (uint64_t)(uintptr_t)(d_consts + pl); break;
+            case K_SCALAR: hdr = L_UNI << 28; ptr = (uint64_t)(uintptr_t)(d_scal + pl); break;
+            case K_COL: {
+                const int32_t delta = b.rots[pl & 0xfff] * rot_scale;
+                hdr = (L_ROW << 28) | ((uint32_t)delta & 0x0fffffffu);
+                ptr = (uint64_t)(uintptr_t)cols[pl >> 12];
+                break;
+            }
+            case K_SLOT: hdr = (L_SLOT << 28) | pl; break;
+            case K_ACC: hdr = L_ACC << 28; break;
+            default: hdr = L_ZERO << 28; break;
+        }
+        o[0] = hdr;
+        o[1] = (uint32_t)ptr;
+        o[2] = (uint32_t)(ptr >> 32);
+    };
+    for (int32_t r : b.rots)
+        ZK_CHECK(ctx, std::abs((int64_t)r) * rot_scale < (1 << 26), "evaluate_h: rotation %d out of range", r);
+    const size_t n_instr = b.words.size() / 4;
+    std::vector<uint32_t> linked(n_instr * INS_WORDS, 0);
+    for (size_t pc = 0; pc < n_instr; pc++) {
+        uint32_t* o = &linked[pc * INS_WORDS];
+        o[0] = b.words[4 * pc];
+        link(b.words[4 * pc + 1], o + 1);
+        link(b.words[4 * pc + 2], o + 4);
+        link(b.words[4 * pc + 3], o + 7);
+    }
+    uint32_t res_link[3];
+    link(result, res_link);
+    uint32_t* d_prog;
+    if ((rc = ar.upload(linked.data(), linked.size(), &d_prog))) return rc;
     fe* d_out;
     if (host) {
         void* p;
@@ -668,29 +814,23 @@ extern "C" int zkhip_evaluate_h(zkhip_domain* dom, const zkhip_evalh_desc* desc,
     } else {
         d_out = (fe*)out;
     }
-    a.prog = d_prog;
-    a.n_instr = (uint32_t)(b.words.size() / 4);
-    a.result = result;
-    a.consts = d_consts;
-    a.scalars = d_scal;
-    a.cols = d_cols;
-    a.rots = d_rots;
+    a.n_instr = (uint32_t)n_instr;
+    a.result_hdr = res_link[0];
     a.lds_slots = lds_slots;
     if (n_slots > lds_slots) {
         void* sp;
-        if ((rc = ar.alloc((size_t)(n_slots - lds_slots) * size * 32, &sp))) return rc;
-        a.spill = (fe*)sp;
+        if ((rc = ar.alloc((size_t)(n_slots - lds_slots) * size * 36, &sp))) return rc;
+        a.spill = (int32_t*)sp;
     }
     a.log_size = ek;
-    a.rot_scale = 1u << (ek - k);
     a.out = d_out;
-    const size_t lds_bytes = (size_t)lds_slots * EV_THREADS * sizeof(fe);
+    const size_t lds_bytes = (size_t)lds_slots * EV_THREADS * 36;
     ZK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(evalh_interp_kernel),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     {
         TimedRegion tr(ctx, "evalh");
         hipLaunchKernelGGL(evalh_interp_kernel, dim3((unsigned)((size + EV_THREADS - 1) / EV_THREADS)), dim3(EV_THREADS),
-                           lds_bytes, ctx->stream, a);
+                           lds_bytes, ctx->stream, (const uint32_t*)d_prog, a);
         ZK_HIP(ctx, hipGetLastError());
     }
     if (host) ZK_HIP(ctx, hipMemcpyAsync(out, d_out, size * 32, hipMemcpyDeviceToHost, ctx->stream));

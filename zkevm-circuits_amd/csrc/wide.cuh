@@ -48,6 +48,22 @@ struct Wide {
         for (int i = 0; i < 9; i++) o.d[i] = (int32_t)u.d[i];
         return o;
     }
+    // normalised digits of 32 * a for a packed a < 2^256 / 4: the same residue moved from the 2^256 to the 2^261
+    // Montgomery domain (x 2^256 * 32 = x 2^261) at the price of an ordinary unpack; the value may reach 32 p
+    ZK_DEV static fw from_fe_shl5(const fe& a) {
+        fw o;
+        o.d[0] = (int32_t)((a.l[0] << 5) & M29);
+#pragma unroll
+        for (int i = 1; i < 9; i++) {
+            const int bit = 29 * i - 5, w = bit >> 5, s = bit & 31;
+            uint32_t v;
+            if (s == 0) v = a.l[w];
+            else if (w + 1 < 8) v = alignbit(a.l[w + 1], a.l[w], s);
+            else v = a.l[w] >> s;
+            o.d[i] = (int32_t)(v & M29);
+        }
+        return o;
+    }
     ZK_DEV static fw from_words(const uint32_t w[8]) {
         fe t;
 #pragma unroll
