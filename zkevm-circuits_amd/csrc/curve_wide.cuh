@@ -126,8 +126,7 @@ __device__ __forceinline__ g1_xyzz_w xyzz_w_identity() {
 }
 
 // Packed XYZZ in memory (canonical residues, identity: zz = 0), coordinates in the 2^261 domain.
-__device__ __forceinline__ g1_xyzz_w xyzz_w_load(const g1_xyzz* p) {
-    const g1_xyzz v = load_xyzz(p);
+__device__ __forceinline__ g1_xyzz_w xyzz_w_unpack(const g1_xyzz& v) {
     g1_xyzz_w o;
     o.inf = Fq::is_zero(v.zz);
     o.x = FqW::from_fe(v.x);
@@ -136,6 +135,7 @@ __device__ __forceinline__ g1_xyzz_w xyzz_w_load(const g1_xyzz* p) {
     o.zzz = FqW::from_fe(v.zzz);
     return o;
 }
+__device__ __forceinline__ g1_xyzz_w xyzz_w_load(const g1_xyzz* p) { return xyzz_w_unpack(load_xyzz(p)); }
 __device__ __forceinline__ g1_xyzz xyzz_w_pack(const g1_xyzz_w& a) {
     if (a.inf) return xyzz_identity();
     g1_xyzz o;

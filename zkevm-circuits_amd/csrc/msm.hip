@@ -390,7 +390,13 @@ __global__ void __launch_bounds__(256) merge_final_kernel(const g1_xyzz* in, con
         const uint32_t c = cnt_in[b], base = off_in[b];
         if (r < c) {
             acc = xyzz_w_load(in + base + r);
-            for (uint32_t i = r + MERGE_P; i < c; i += MERGE_P) acc = xyzz_w_add(acc, xyzz_w_load(in + base + i));
+            g1_xyzz nxt;
+            if (r + MERGE_P < c) nxt = load_xyzz(in + base + r + MERGE_P);
+            for (uint32_t i = r + MERGE_P; i < c; i += MERGE_P) {
+                const g1_xyzz cur = nxt;
+                if (i + MERGE_P < c) nxt = load_xyzz(in + base + i + MERGE_P);   // in flight during the addition
+                acc = xyzz_w_add(acc, xyzz_w_unpack(cur));
+            }
         }
     }
     for (int d = MERGE_P / 2; d >= 1; d >>= 1) {
@@ -427,7 +433,9 @@ __device__ __forceinline__ g1_xyzz_w wave_sum_xyzz(g1_xyzz_w v, uint32_t lane) {
     return v;
 }
 
-// level 1: sums[b] for b < B (B a multiple of 64) -> a1[j], v1[j] for wave j = b / 64
+// level 1: sums[b] for b < B (B a multiple of 64) -> a1[j], v1[j] for wave j = b / 64.  (Running the plain sums and
+// the weighted sums as two concurrent kernels would shorten the dependency chain from 24 to 18 additions, but the
+// co-scheduled waves slow each other down by more than that: measured 250 us against 213 us.)
 __global__ void __launch_bounds__(256) reduce_level1_kernel(const g1_xyzz* sums, uint32_t B, g1_xyzz* a1, g1_xyzz* v1) {
     const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x, lane = threadIdx.x & 63;
     g1_xyzz_w p = b < B ? xyzz_w_load(sums + b) : xyzz_w_identity();
@@ -531,6 +539,7 @@ constexpr uint32_t MERGE_DIRECT_MAX = 32;   // the final merge level takes bucke
 // one MSM (merge, reduce, host fold) overlap the accumulate phase of the next.
 struct MsmWorkspace {
     hipStream_t stream = nullptr;
+    hipEvent_t ev_info = nullptr;      // the plan has reached h_info
     unsigned char* base = nullptr;
     size_t bytes = 0;
     uint32_t* h_info = nullptr;        // pinned copy of info[0..3]
@@ -538,7 +547,7 @@ struct MsmWorkspace {
     // per-call state
     size_t n = 0, first = 0;
     const fe* d_scalars = nullptr;
-    uint32_t G = 0, l_min = 0, plan_blocks = 0;
+    uint32_t G = 0, l_min = 0, plan_blocks = 0, acc_blocks = 0;
     bool nonzero = false;
     uint32_t *counts, *entries, *start, *cnt, *offA, *cntA, *offB, *cntB, *info, *plan;
     g1_xyzz *itemsA, *itemsB, *sums, *a1, *v1, *out2;
@@ -581,6 +590,8 @@ static int ws_prepare(zkhip_ctx* ctx, MsmWorkspace& ws, const MsmTables& tb, siz
         ws.bytes = off;
     }
     if (!ws.h_info) ZK_HIP(ctx, hipHostMalloc((void**)&ws.h_info, 64));
+    if (!ws.ev_info) ZK_HIP(ctx, hipEventCreateWithFlags(&ws.ev_info, hipEventDisableTiming));
+    ws.acc_blocks = (uint32_t)((T1_max + 255) / 256);
     if (!ws.h_sums) ZK_HIP(ctx, hipHostMalloc((void**)&ws.h_sums, REDUCE_OUT * sizeof(g1_xyzz)));
     unsigned char* p = ws.base;
     ws.counts = (uint32_t*)(p + o_counts);
@@ -617,17 +628,29 @@ static int msm_phase1(zkhip_ctx* ctx, MsmWorkspace& ws, const MsmTables& tb, siz
     hipLaunchKernelGGL(column_scan_kernel, dim3(ws.plan_blocks), dim3(256), 0, st, ws.counts, G, B, ws.cnt, ws.l_min, ws.plan);
     hipLaunchKernelGGL(bucket_scan_kernel, dim3(1), dim3(1024), 0, st, ws.cnt, B, 0u, ws.cntA, ws.offA, ws.start, ws.plan,
                        ws.plan_blocks, ws.l_min, (uint32_t)ctx->num_cus * 256u, FORCE_L, ws.info);
+    // the plan travels to the host while scatter and accumulate run
+    ZK_HIP(ctx, hipMemcpyAsync(ws.h_info, ws.info, 16, hipMemcpyDeviceToHost, st));
+    ZK_HIP(ctx, hipEventRecord(ws.ev_info, st));
     hipLaunchKernelGGL(scatter_kernel, dim3(G), dim3(HIST_THREADS), lds_hist, st, d_scalars, n, chunk, c, W, ws.counts,
                        ws.start, ws.entries);
     ZK_HIP(ctx, hipGetLastError());
-    ZK_HIP(ctx, hipMemcpyAsync(ws.h_info, ws.info, 16, hipMemcpyDeviceToHost, st));
     return ZKHIP_OK;
 }
 
-// phase 2: waits for phase 1's readback, then accumulate, merge, reduce; asynchronous readback of the leftover sums
+// accumulate: launched for the largest slot count the plan may choose; lanes beyond the planned slots leave at once
+static int msm_accumulate(zkhip_ctx* ctx, MsmWorkspace& ws, const MsmTables& tb) {
+    const uint32_t B = 1u << (tb.c - 1);
+    hipLaunchKernelGGL(accumulate_kernel, dim3(ws.acc_blocks), dim3(256), 0, ws.stream, ws.entries, ws.start, ws.cnt, ws.offA,
+                       ws.cntA, B, tb.d_tables, tb.n, ws.first, ws.itemsA);
+    ZK_HIP(ctx, hipGetLastError());
+    return ZKHIP_OK;
+}
+
+// phase 2: waits for the plan (the accumulate kernel is already queued), then merge and reduce; asynchronous readback
+// of the leftover sums
 static int msm_phase2(zkhip_ctx* ctx, MsmWorkspace& ws, const MsmTables& tb, bool timed) {
     hipStream_t st = ws.stream;
-    ZK_HIP(ctx, hipStreamSynchronize(st));
+    ZK_HIP(ctx, hipEventSynchronize(ws.ev_info));
     const uint32_t total_slots = ws.h_info[INFO_SLOTS], max_cnt = ws.h_info[INFO_MAXCNT], L = ws.h_info[INFO_L];
     const uint32_t B = 1u << (tb.c - 1);
     ws.nonzero = total_slots != 0;
@@ -636,12 +659,6 @@ static int msm_phase2(zkhip_ctx* ctx, MsmWorkspace& ws, const MsmTables& tb, boo
         fprintf(stderr, "[zkhip] msm n=%zu: slots=%u max_cnt=%u L=%u entries=%u\n", ws.n, total_slots, max_cnt, L,
                 ws.h_info[INFO_ENTRIES]);
     if (!ws.nonzero) return ZKHIP_OK;   // every scalar is zero
-    {
-        TimedRegion tr(ctx, timed ? "msm_accumulate" : nullptr, st);
-        hipLaunchKernelGGL(accumulate_kernel, dim3((total_slots + 255) / 256), dim3(256), 0, st, ws.entries, ws.start, ws.cnt,
-                           ws.offA, ws.cntA, B, tb.d_tables, tb.n, ws.first, ws.itemsA);
-        ZK_HIP(ctx, hipGetLastError());
-    }
     g1_xyzz *cur_items = ws.itemsA, *nxt_items = ws.itemsB;
     uint32_t *cur_off = ws.offA, *cur_cnt = ws.cntA, *nxt_off = ws.offB, *nxt_cnt = ws.cntB;
     {
@@ -736,6 +753,10 @@ int msm_run(zkhip_ctx* ctx, MsmState& stt, const MsmTables& tb, size_t first, co
         TimedRegion tr(ctx, "msm_sort");
         rc = msm_phase1(ctx, ws, tb, first, d_scalars, n);
     }
+    if (!rc) {
+        TimedRegion tr(ctx, "msm_accumulate");
+        rc = msm_accumulate(ctx, ws, tb);
+    }
     if (!rc) rc = msm_phase2(ctx, ws, tb, true);
     if (!rc) rc = msm_phase3(ctx, ws, out_jacobian);
     return rc;
@@ -764,6 +785,7 @@ int msm_run_batch(zkhip_ctx* ctx, MsmState& stt, const MsmTables& tb, const uint
     for (size_t j = 0; j < batch + 2; j++) {
         if (j < batch) {
             rc = msm_phase1(ctx, *pipe[j % MSM_PIPE], tb, 0, (const fe*)d_scalars[j], n);
+            if (!rc) rc = msm_accumulate(ctx, *pipe[j % MSM_PIPE], tb);
             if (rc) return rc;
         }
         if (j >= 1 && j - 1 < batch) {
@@ -793,6 +815,7 @@ void msm_drop_ctx(zkhip_ctx* ctx) {
         if (w.base) (void)hipFree(w.base);
         if (w.h_info) (void)hipHostFree(w.h_info);
         if (w.h_sums) (void)hipHostFree(w.h_sums);
+        if (w.ev_info) (void)hipEventDestroy(w.ev_info);
         if (st.batch_streams[i]) (void)hipStreamDestroy(st.batch_streams[i]);
         if (st.ev_out[i]) (void)hipEventDestroy(st.ev_out[i]);
     }
