@@ -32,7 +32,10 @@ def build(force: bool = False, verbose: bool = False) -> str:
         objs.append(o)
         if force or _newer(o, deps):
             cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-c", "-x", "hip", s, "-o", o,
-                   "-Wall", "-Wno-unused-function", "-Wno-unused-result"]
+                   "-Wall", "-Wno-unused-function", "-Wno-unused-result",
+                   # the field multiplier is ~250 instructions inline: loops over a lane's eight NTT elements must still
+                   # unroll fully, or their register arrays fall into scratch memory
+                   "-mllvm", "-pragma-unroll-threshold=1000000"]
             if verbose:
                 print(" ".join(cmd), file=sys.stderr)
             procs.append((s, subprocess.Popen(cmd)))

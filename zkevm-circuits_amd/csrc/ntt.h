@@ -10,6 +10,8 @@ struct NttPlan {
     uint32_t h = 0;              // low table holds omega^i for i < 2^h
     void* d_lo = nullptr;
     void* d_hi = nullptr;
+    void* d_lo_w = nullptr;      // the same tables in the 2^261 Montgomery domain (transforms of 2^11 points and more)
+    void* d_hi_w = nullptr;
     std::vector<uint32_t> radix; // log2 radix of each pass
     ~NttPlan();
 };

@@ -9,9 +9,21 @@
 // Fused into the first load: zero padding beyond n_in and the zeta-coset scaling of `coeff_to_extended`;
 // fused into the last store: the 1/n (and inverse zeta) scaling and the truncation of `extended_to_coeff`.
 // Powers of omega come from two L2-resident tables (w^i for i < 2^h, w^(i 2^h)) and one multiplication.
+//
+// Transforms of 2^11 points and more use `ntt_tile_kernel` (below); the LDS-per-stage kernel above it serves the
+// small ones.  The tile kernel keeps the same pass / tile / index structure and changes the inside of a pass:
+//   * arithmetic in the lazy signed-digit form of wide.cuh: a butterfly is one Montgomery product and 18 digit
+//     additions, elements are carry-normalised once per three stages, and nothing is compared against p;
+//   * decimation in time on bit-reversed tile rows, three stages at a time in registers: a lane owns eight elements
+//     of one column, so a radix-2^7 pass crosses LDS three times instead of seven;
+//   * the twiddle w_N^(t (j mod Ns) N/(Ns R)) that the NEXT pass would apply while loading is applied by THIS pass
+//     while storing.  That product also pulls the value back into (-p/100, 1.01 p), so adding p gives a non-negative
+//     residue below 2^256 that is stored as is; only the last pass canonicalises.
+#include <algorithm>
 #include <cstring>
 #include "common.h"
 #include "ntt.h"
+#include "wide.cuh"
 
 namespace zkhip {
 
@@ -116,6 +128,194 @@ __global__ void __launch_bounds__(NTT_THREADS) ntt_pass_kernel(const NttPassArgs
     }
 }
 
+// ---- tile kernel -------------------------------------------------------------------------------------
+constexpr uint32_t TILE = 1u << TILE_LOG;
+
+struct NttTileArgs {
+    const fe* in;
+    fe* out;
+    const fe* lo;      // w^i (i < 2^h) and w^(i 2^h), canonical, 2^261 Montgomery domain
+    const fe* hi;
+    uint32_t h;
+    uint32_t logN, r, logNs, logJ;
+    uint32_t n_in, n_out;
+    uint32_t pre_mode, post_mode;
+    fe pre[3], post[3];           // 2^261 domain
+    uint32_t last;                // final pass: canonical output (after the optional post scaling)
+    uint32_t r_next;              // radix of the next pass (for the twiddle applied on store)
+    uint32_t nrounds;
+    uint32_t pb[3][3];            // round, local bit i -> tile-row bit
+    uint32_t sb[3][3];            // the same bits sorted ascending
+    uint32_t nst[3];              // butterfly stages of the round (local bits 0 .. nst-1)
+    size_t in_stride, out_stride;
+};
+
+// w^e in wide form (normalised, value in (-p/100, 1.01 p))
+__device__ __forceinline__ fw omega_pow_w(const NttTileArgs& a, uint32_t e) {
+    fw l = FrW::from_fe(load_fe(a.lo + (e & ((1u << a.h) - 1))));
+    const uint32_t eh = e >> a.h;
+    if (eh) l = FrW::mul(l, FrW::from_fe(load_fe(a.hi + eh)));
+    return l;
+}
+// digits 0..7 into [-2^28, 2^28): halves the column sums of a product, so the other factor may carry three
+// stages of un-normalised butterfly sums
+__device__ __forceinline__ fw balance_digits(const fw& v) {
+    fw o;
+    int32_t c = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        const int32_t t = v.d[i] + c;
+        c = (t + (1 << 28)) >> 29;
+        o.d[i] = t - (c << 29);
+    }
+    o.d[8] = v.d[8] + c;
+    return o;
+}
+__device__ __forceinline__ uint32_t spread_bits(uint32_t g, const uint32_t sb[3]) {
+#pragma unroll
+    for (int i = 0; i < 3; i++) g = ((g >> sb[i]) << (sb[i] + 1)) | (g & ((1u << sb[i]) - 1));
+    return g;
+}
+__device__ __forceinline__ fw lds_get(const int32_t* x, uint32_t at) {
+    fw v;
+#pragma unroll
+    for (int d = 0; d < 9; d++) v.d[d] = x[d * TILE + at];
+    return v;
+}
+__device__ __forceinline__ void lds_put(int32_t* x, uint32_t at, const fw& v) {
+#pragma unroll
+    for (int d = 0; d < 9; d++) x[d * TILE + at] = v.d[d];
+}
+__device__ __forceinline__ fw tw_get(const int32_t* tw, uint32_t half_r, uint32_t k) {
+    fw v;
+#pragma unroll
+    for (int d = 0; d < 9; d++) v.d[d] = tw[d * half_r + k];
+    return v;
+}
+
+// Butterfly stages of one round on the eight elements of a lane.  e[m] sits in tile row pos[m]; local bit i is tile-row
+// bit 3 * round + i.  FIRST: the round of stages 0..2, whose twiddle indices depend on m only (1, w_4, w_8, w_8^3).
+template <bool FIRST>
+__device__ __forceinline__ void tile_stages(fw e[8], const uint32_t pos[8], uint32_t round, uint32_t nst, uint32_t r,
+                                            const int32_t* tw) {
+    const uint32_t half_r = 1u << (r - 1);
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        if ((uint32_t)i >= nst) break;
+        const uint32_t s = 3 * round + i;
+#pragma unroll
+        for (int m = 0; m < 8; m++) {
+            if (m & (1 << i)) continue;
+            const int mb = m + (1 << i);
+            fw t;
+            if (FIRST) {
+                const uint32_t km = (uint32_t)m & ((1u << i) - 1);   // compile-time
+                if (km == 0) t = (i == 0) ? e[mb] : FrW::norm(e[mb]);
+                else t = FrW::mul(e[mb], tw_get(tw, half_r, km << (r - 1 - s)));
+            } else {
+                const uint32_t k = (pos[m] & ((1u << s) - 1)) << (r - 1 - s);
+                t = FrW::mul(e[mb], tw_get(tw, half_r, k));
+            }
+            e[mb] = FrW::sub(e[m], t);
+            e[m] = FrW::add(e[m], t);
+        }
+    }
+}
+
+__global__ void __launch_bounds__(NTT_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2))) ntt_tile_kernel(const NttTileArgs a) {
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    int32_t* x = reinterpret_cast<int32_t*>(smem_raw);       // [9][R][J]
+    const uint32_t R = 1u << a.r, J = 1u << a.logJ, N = 1u << a.logN;
+    int32_t* tw = x + 9 * TILE;                               // [9][R/2]
+    const uint32_t tid = threadIdx.x;
+    const uint32_t j0 = blockIdx.x << a.logJ;
+    const fe* in = a.in + (size_t)blockIdx.y * a.in_stride;
+    fe* out = a.out + (size_t)blockIdx.y * a.out_stride;
+    const uint32_t rowStride = N >> a.r;
+    const uint32_t c = tid & (J - 1), grp = tid >> a.logJ;   // R / 8 groups of eight rows per column
+    const uint32_t j = j0 + c;
+
+    // tile-local twiddles w_R^k = w_N^(k N/R), balanced digits
+    for (uint32_t k = tid; k < (R >> 1); k += NTT_THREADS) {
+        const fw w = balance_digits(omega_pow_w(a, k << (a.logN - a.r)));
+#pragma unroll
+        for (int d = 0; d < 9; d++) tw[d * (R >> 1) + k] = w.d[d];
+    }
+
+    fw e[8];
+    uint32_t pos[8];
+    // round 0: rows come straight from memory; row p of the tile holds input row bitrev(p)
+    {
+        const uint32_t base = spread_bits(grp, a.sb[0]);
+#pragma unroll
+        for (int m = 0; m < 8; m++) {
+            pos[m] = base | (uint32_t)m;                       // round 0 always owns row bits 0, 1, 2
+            const uint32_t t = bitrev(pos[m], a.r);
+            const uint32_t gi = j + t * rowStride;
+            if (gi < a.n_in) {
+                e[m] = FrW::from_fe(load_fe(in + gi));
+                if (a.pre_mode == 1) {
+                    const uint32_t q = gi % 3;
+                    if (q) e[m] = FrW::mul(e[m], FrW::from_fe(a.pre[q]));
+                }
+            } else {
+                e[m] = FrW::zero();
+            }
+        }
+    }
+    __syncthreads();   // twiddle table
+    tile_stages<true>(e, pos, 0, a.nst[0], a.r, tw);
+#pragma unroll
+    for (int m = 0; m < 8; m++) lds_put(x, (pos[m] << a.logJ) + c, e[m]);
+    __syncthreads();
+    // (constant round indices: indexing the by-value argument block with a loop variable would move it to scratch)
+#pragma unroll
+    for (int rd = 1; rd < 3; rd++) {
+        if ((uint32_t)rd >= a.nrounds) break;
+        const uint32_t base = spread_bits(grp, a.sb[rd]);
+#pragma unroll
+        for (int m = 0; m < 8; m++) {
+            pos[m] = base | ((m & 1) << a.pb[rd][0]) | (((m >> 1) & 1) << a.pb[rd][1]) | (((m >> 2) & 1) << a.pb[rd][2]);
+            e[m] = FrW::norm(lds_get(x, (pos[m] << a.logJ) + c));
+        }
+        tile_stages<false>(e, pos, rd, a.nst[rd], a.r, tw);
+#pragma unroll
+        for (int m = 0; m < 8; m++) lds_put(x, (pos[m] << a.logJ) + c, e[m]);
+        __syncthreads();
+    }
+
+    // store: X[q] sits in tile row q
+    const uint32_t nsMask = (1u << a.logNs) - 1;
+    const uint32_t logNs2 = a.logNs + a.r;                       // the next pass sees Ns * R
+    const uint32_t rowShift2 = a.logN - a.r_next;                // log2 of its row stride
+    const uint32_t twShift2 = a.last ? 0 : a.logN - logNs2 - a.r_next;
+    for (uint32_t idx = tid; idx < TILE; idx += NTT_THREADS) {
+        uint32_t cc, q;
+        if (a.logNs == 0) { q = idx & (R - 1); cc = idx >> a.r; }     // outputs of one j are contiguous
+        else { cc = idx & (J - 1); q = idx >> a.logJ; }
+        const uint32_t jj = j0 + cc;
+        const uint32_t oi = ((jj >> a.logNs) << (a.logNs + a.r)) + (jj & nsMask) + (q << a.logNs);
+        if (oi >= a.n_out) continue;
+        fw v = FrW::norm(lds_get(x, (q << a.logJ) + cc));
+        if (a.last) {
+            if (a.post_mode == 1) v = FrW::mul(v, FrW::from_fe(a.post[0]));
+            else if (a.post_mode == 2) v = FrW::mul(v, FrW::from_fe(a.post[oi % 3]));
+            store_fe(out + oi, FrW::to_fe(v));
+        } else {
+            // what the next pass multiplies element oi by: t2 = its tile row, j2 = its column
+            const uint32_t t2 = oi >> rowShift2, j2 = oi & ((1u << rowShift2) - 1);
+            const uint32_t ex = (t2 * (j2 & ((1u << logNs2) - 1))) << twShift2;
+            v = FrW::mul(v, FrW::from_fe(load_fe(a.lo + (ex & ((1u << a.h) - 1)))));
+            if (ex >> a.h) v = FrW::mul(v, FrW::from_fe(load_fe(a.hi + (ex >> a.h))));
+            // v in (-p/100, 1.01 p): v + p is a non-negative residue below 2^256
+            fw pp;
+#pragma unroll
+            for (int d = 0; d < 9; d++) pp.d[d] = (int32_t)FrParams::P29[d];
+            store_fe(out + oi, FrW::pack_nonneg(FrW::norm(FrW::add(v, pp))));
+        }
+    }
+}
+
 // out[i] = in[i] * scale[i % period]  (divide_by_vanishing_poly and friends)
 __global__ void __launch_bounds__(256) scale_periodic_kernel(fe* a, const fe* scale, uint32_t period_mask, size_t n) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -127,6 +327,8 @@ __global__ void __launch_bounds__(256) scale_periodic_kernel(fe* a, const fe* sc
 NttPlan::~NttPlan() {
     if (d_lo) (void)hipFree(d_lo);
     if (d_hi) (void)hipFree(d_hi);
+    if (d_lo_w) (void)hipFree(d_lo_w);
+    if (d_hi_w) (void)hipFree(d_hi_w);
 }
 
 int ntt_plan_create(zkhip_ctx* ctx, uint32_t log_n, const uint64_t omega[4], NttPlan** out) {
@@ -155,6 +357,17 @@ int ntt_plan_create(zkhip_ctx* ctx, uint32_t log_n, const uint64_t omega[4], Ntt
     if (e == hipSuccess) e = hipMalloc(&plan->d_hi, nhi * 32);
     if (e == hipSuccess) e = hipMemcpy(plan->d_lo, lo.data(), nlo * 32, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(plan->d_hi, hi.data(), nhi * 32, hipMemcpyHostToDevice);
+    if (e == hipSuccess && log_n >= TILE_LOG) {
+        // the same tables in the 2^261 Montgomery domain for the tile kernel (x R -> 32 x R)
+        uint64_t k32[4];
+        memcpy(k32, FrParams::TWO5, 32);
+        for (size_t i = 0; i < nlo; i++) h_mul(HFR, &lo[4 * i], &lo[4 * i], k32);
+        for (size_t i = 0; i < nhi; i++) h_mul(HFR, &hi[4 * i], &hi[4 * i], k32);
+        e = hipMalloc(&plan->d_lo_w, nlo * 32);
+        if (e == hipSuccess) e = hipMalloc(&plan->d_hi_w, nhi * 32);
+        if (e == hipSuccess) e = hipMemcpy(plan->d_lo_w, lo.data(), nlo * 32, hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemcpy(plan->d_hi_w, hi.data(), nhi * 32, hipMemcpyHostToDevice);
+    }
     if (e != hipSuccess) {
         delete plan;
         return set_error(ctx, ZKHIP_ERR_HIP, "ntt plan upload failed: %s", hipGetErrorString(e));
@@ -173,6 +386,8 @@ int ntt_plan_create(zkhip_ctx* ctx, uint32_t log_n, const uint64_t omega[4], Ntt
 
 int ntt_init(zkhip_ctx* ctx) {
     ZK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(ntt_pass_kernel),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+    ZK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(ntt_tile_kernel),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
     return ZKHIP_OK;
 }
@@ -204,6 +419,53 @@ int ntt_run(zkhip_ctx* ctx, const NttPlan* plan, const fe* src, size_t src_strid
     if (npass >= 2 && bufs[1] == src) return set_error(ctx, ZKHIP_ERR_INVALID, "ntt: scratch aliases source");
     uint32_t logNs = 0;
     TimedRegion tr(ctx, "ntt");
+    if (L >= TILE_LOG) {
+        // tile kernel: every pass has radix 2^5 .. 2^8 and a full 2048-element tile
+        uint64_t k32[4];
+        memcpy(k32, FrParams::TWO5, 32);
+        for (uint32_t p = 0; p < npass; p++) {
+            NttTileArgs a;
+            memset(&a, 0, sizeof a);
+            a.in = bufs[p];
+            a.out = bufs[p + 1];
+            a.in_stride = strides[p];
+            a.out_stride = strides[p + 1];
+            a.lo = (const fe*)plan->d_lo_w;
+            a.hi = (const fe*)plan->d_hi_w;
+            a.h = plan->h;
+            a.logN = L;
+            a.r = plan->radix[p];
+            a.logNs = logNs;
+            a.logJ = TILE_LOG - a.r;
+            a.n_in = (p == 0) ? n_in : (uint32_t)N;
+            a.n_out = (p == npass - 1) ? n_out : (uint32_t)N;
+            a.pre_mode = (p == 0) ? fuse.pre_mode : 0;
+            a.post_mode = (p == npass - 1) ? fuse.post_mode : 0;
+            for (int q = 0; q < 3; q++) {
+                h_mul(HFR, (uint64_t*)a.pre[q].l, (const uint64_t*)fuse.pre[q].l, k32);
+                h_mul(HFR, (uint64_t*)a.post[q].l, (const uint64_t*)fuse.post[q].l, k32);
+            }
+            a.last = (p == npass - 1);
+            a.r_next = a.last ? 0 : plan->radix[p + 1];
+            ZK_CHECK(ctx, a.r >= 3 && a.r <= 8, "ntt: tile pass radix 2^%u unsupported", a.r);
+            a.nrounds = (a.r + 2) / 3;
+            for (uint32_t rd = 0; rd < a.nrounds; rd++) {
+                const uint32_t nst = std::min(3u, a.r - 3 * rd);
+                a.nst[rd] = nst;
+                uint32_t filler = 0;   // lowest tile-row bits ride along when a round has fewer than three stages
+                for (uint32_t i = 0; i < 3; i++) a.pb[rd][i] = (i < nst) ? 3 * rd + i : filler++;
+                uint32_t sorted[3] = {a.pb[rd][0], a.pb[rd][1], a.pb[rd][2]};
+                std::sort(sorted, sorted + 3);
+                memcpy(a.sb[rd], sorted, sizeof sorted);
+            }
+            const size_t lds = (9 * (size_t)TILE + 9 * ((size_t)1 << (a.r - 1))) * sizeof(int32_t);
+            dim3 grid((uint32_t)(N >> TILE_LOG), (uint32_t)batch);
+            hipLaunchKernelGGL(ntt_tile_kernel, grid, dim3(NTT_THREADS), lds, ctx->stream, a);
+            ZK_HIP(ctx, hipGetLastError());
+            logNs += a.r;
+        }
+        return ZKHIP_OK;
+    }
     for (uint32_t p = 0; p < npass; p++) {
         NttPassArgs a;
         a.in = bufs[p];

@@ -219,6 +219,23 @@ struct Wide {
         }
         return o;
     }
+    // packs a normalised value known to lie in [0, 2^256) without reducing it modulo p
+    ZK_DEV static fe pack_nonneg(const fw& w) {
+        uint32_t n[10];
+#pragma unroll
+        for (int i = 0; i < 9; i++) n[i] = (uint32_t)w.d[i];
+        n[9] = 0;
+        fe o;
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const int bit = 32 * k, i = bit / 29, s = bit % 29;
+            uint32_t x = n[i] >> s;
+            if (i + 1 < 10) x |= n[i + 1] << (29 - s);
+            if (58 - s < 32 && i + 2 < 10) x |= n[i + 2] << (58 - s);
+            o.l[k] = x;
+        }
+        return o;
+    }
     // exact test for value == 0 (mod p), |value| < 64 p
     ZK_DEV static bool is_zero(const fw& v) {
         const fe c = to_fe(v);
