@@ -138,12 +138,18 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    torch.cuda.set_device(local_rank)
+    # one rank per GPU; ZKHIP_BENCH_BACKEND=gloo rehearses the multi-rank path on a box with fewer GPUs than ranks
+    backend = os.environ.get("ZKHIP_BENCH_BACKEND", "nccl")
+    device_index = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(device_index)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", device_index))
+        else:
+            dist.init_process_group(backend)
 
-    ctx = zk.Context(local_rank)
+    ctx = zk.Context(device_index)
     stream = torch.cuda.Stream()
     ctx.set_stream(stream.cuda_stream)
     gen = torch.Generator(device="cuda")
@@ -206,7 +212,7 @@ def main():
     evalh = None
     if not args.skip_evalh and not args.skip_extras:
         evalh = measure_evalh(ctx, dom, stream, gen, args.evalh_k)
-    finish(args, ctx, dist, world, rank, local_rank, bid, scalars, n, en, elapsed, msm_ms, ntt_ms, acc_us, acc_launches, sort_us,
+    finish(args, ctx, dist, world, rank, device_index, bid, scalars, n, en, elapsed, msm_ms, ntt_ms, acc_us, acc_launches, sort_us,
            merge_us, reduce_us, ntt_us, extra, evalh)
 
 
