@@ -272,6 +272,29 @@ def measure_extras(ctx, dom, bid, stream, gen, n, en, extra):
     del bcoef, bext
     mads, muls = ctx.probe_mad_rate(1024)
     extra["fr_mul_probe_Gps"] = muls / 1e9
+    # the prover steps next to the hot path, n = 2^19: batch inversion, one permutation set of 3 columns, one lookup
+    # product, one polynomial evaluation
+    with torch.cuda.stream(stream):
+        cols = [rand_fr_device(n, gen) for _ in range(7)]
+    stream.synchronize()
+    sc = rand_fr_device(4, gen).cpu().numpy().view(np.uint64)
+    ptr = [c.data_ptr() for c in cols]
+
+    def timed(fn, reps=5):
+        fn()
+        ctx.sync()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        ctx.sync()
+        return (time.perf_counter() - t0) / reps * 1e3
+
+    extra["batch_invert_2p19_ms"] = timed(lambda: ctx.batch_invert_dev(0, ptr[6], n))
+    extra["permutation_product_3cols_2p19_ms"] = timed(
+        lambda: dom.permutation_product_dev(ptr[0:3], ptr[3:6], sc[0], sc[1], sc[2], sc[3], ptr[6]))
+    extra["lookup_product_2p19_ms"] = timed(lambda: dom.lookup_product_dev(ptr[0], ptr[1], ptr[2], ptr[3], sc[0], sc[1], ptr[6]))
+    extra["eval_polynomial_2p19_ms"] = timed(lambda: ctx.eval_polynomial_dev(ptr[0], n, sc[0]))
+    del cols
 
 
 def measure_evalh(ctx, dom, stream, gen, evalh_k):

@@ -177,9 +177,37 @@ typedef struct {
 /* out: 2^ext_k x 4 (host or device per desc->mem) = numerator of the quotient on the extended coset. */
 int zkhip_evaluate_h(zkhip_domain* dom, const zkhip_evalh_desc* desc, uint64_t* out);
 
+/* ------------------------------------------------------------------ grand products and openings -----
+ * The prover steps adjacent to the hot path (the rest of `plonk::prover::create_proof`, reached from
+ * zkevm-circuits/benches/benchmark_list/main.rs:265 and prover/src/chunk/prover.rs:85).  All pointers are device
+ * pointers to Montgomery Fr vectors of n = 2^k elements on the domain's context; calls are asynchronous on the
+ * context's stream except where a host result is returned.
+ *
+ * zkhip_batch_invert_dev       `ff::BatchInvert::batch_invert`: every non-zero element replaced by its inverse, zeros kept.
+ * zkhip_prefix_product_dev     out[0] = init, out[i] = init * m[0] * ... * m[i-1]  (n outputs; m may alias out).
+ * zkhip_permutation_product_dev  one column set of `plonk::permutation::prover::Argument::commit`:
+ *     z[0] = z0, z[i+1] = z[i] * prod_j (v_j[i] + delta^(j0+j) beta omega^i + gamma) / (v_j[i] + beta sigma_j[i] + gamma)
+ *     d_values / d_sigmas: HOST arrays of num_cols device pointers (column values and `pk.permutation.permutations`,
+ *     Lagrange basis); delta_start = delta^j0 for the set's first column j0; z0 = 1 for the first set, last_z after.
+ * zkhip_lookup_product_dev     `plonk::lookup::prover::Permuted::commit_product`:
+ *     z[0] = 1, z[i+1] = z[i] * (a[i] + beta)(s[i] + gamma) / ((a'[i] + beta)(s'[i] + gamma))
+ * Both write all n rows of z; upstream then overwrites the last `blinding_factors` rows with values from the prover's
+ * RNG, which stays on the caller's side (last_z is row n - blinding_factors - 1).
+ * zkhip_eval_polynomial_dev    `arithmetic::eval_polynomial`: sum_i coeff[i] x^i, result on the host (synchronises). */
+int zkhip_batch_invert_dev(zkhip_ctx* ctx, int field, uint64_t* d_a, size_t n);
+int zkhip_prefix_product_dev(zkhip_ctx* ctx, const uint64_t* d_m, uint64_t* d_out, size_t n, const uint64_t init[4]);
+int zkhip_permutation_product_dev(zkhip_domain* dom, const uint64_t* const* d_values, const uint64_t* const* d_sigmas,
+                                  uint32_t num_cols, const uint64_t beta[4], const uint64_t gamma[4],
+                                  const uint64_t delta_start[4], const uint64_t z0[4], uint64_t* d_z);
+int zkhip_lookup_product_dev(zkhip_domain* dom, const uint64_t* d_compressed_input, const uint64_t* d_compressed_table,
+                             const uint64_t* d_permuted_input, const uint64_t* d_permuted_table, const uint64_t beta[4],
+                             const uint64_t gamma[4], uint64_t* d_z);
+int zkhip_eval_polynomial_dev(zkhip_ctx* ctx, const uint64_t* d_coeff, size_t n, const uint64_t x[4], uint64_t out[4]);
+
 /* Kernel timing hook: average duration in microseconds of the launches of the named kernel family issued on
  * this context since the last zkhip_timing_reset (measured with HIP events on the launch stream).
- * families: "ntt", "msm_sort", "msm_accumulate", "msm_merge", "msm_reduce", "evalh".  A family brackets every launch of its stage in one call (e.g. the passes of one NTT). */
+ * families: "ntt", "msm_sort", "msm_accumulate", "msm_merge", "msm_reduce", "evalh", "batch_invert",
+ * "prefix_product", "grand_product", "eval_polynomial".  A family brackets every launch of its stage in one call (e.g. the passes of one NTT). */
 int zkhip_timing_enable(zkhip_ctx* ctx, int on);
 int zkhip_timing_reset(zkhip_ctx* ctx);
 int zkhip_timing_get(zkhip_ctx* ctx, const char* family, double* avg_us, uint64_t* launches);

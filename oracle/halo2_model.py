@@ -330,3 +330,67 @@ def evaluate_h(dom: EvaluationDomain, inp: EvalInputs, desc) -> list:
             v = (v * y + a_minus_s * (ac[idx] - ac[r_prev]) * l_active[idx]) % P
             values[idx] = v
     return values
+
+
+# ---------------------------------------------------------------------------------------------
+# Grand products and openings: the prover steps right after the hot path inside create_proof
+# (`ff::BatchInvert`, `plonk::permutation::prover::Argument::commit`,
+#  `plonk::lookup::prover::Permuted::commit_product`, `arithmetic::eval_polynomial`; the reference reaches them
+#  through /root/reference/zkevm-circuits/benches/benchmark_list/main.rs:265).  Blinding rows are not modelled:
+#  upstream fills the last `blinding_factors` rows of z from the prover's RNG after these computations.
+# ---------------------------------------------------------------------------------------------
+def batch_invert(values):
+    """Every non-zero element replaced by its inverse; zeros stay (ff::BatchInvert)."""
+    acc = 1
+    tmp = []
+    for v in values:
+        tmp.append(acc)
+        if v:
+            acc = acc * v % P
+    acc = pow(acc, P - 2, P)
+    out = list(values)
+    for i in range(len(values) - 1, -1, -1):
+        v = values[i]
+        if v:
+            out[i] = tmp[i] * acc % P
+            acc = acc * v % P
+    return out
+
+
+def prefix_product(m, init: int):
+    """out[0] = init, out[i] = init * m[0] * ... * m[i-1]; len(m) outputs."""
+    out = []
+    acc = init % P
+    for v in m:
+        out.append(acc)
+        acc = acc * v % P
+    return out
+
+
+def permutation_product(omega: int, values, sigmas, beta: int, gamma: int, delta_start: int, z0: int):
+    """One column set of permutation::prover::Argument::commit, all n rows of z (before blinding).
+    values[j], sigmas[j]: Lagrange-basis columns; delta_start = delta^(index of the set's first column)."""
+    n = len(values[0])
+    modified = [1] * n
+    for v, s in zip(values, sigmas):
+        for i in range(n):
+            modified[i] = modified[i] * ((beta * s[i] + gamma + v[i]) % P) % P
+    modified = batch_invert(modified)
+    deltaomega = delta_start
+    for v in values:
+        cur = deltaomega
+        for i in range(n):
+            modified[i] = modified[i] * ((cur * beta + gamma + v[i]) % P) % P
+            cur = cur * omega % P
+        deltaomega = deltaomega * FR_DELTA % P
+    return prefix_product(modified, z0)
+
+
+def lookup_product(compressed_input, compressed_table, permuted_input, permuted_table, beta: int, gamma: int):
+    """lookup::prover::Permuted::commit_product, all n rows of z (before blinding)."""
+    n = len(compressed_input)
+    prod = [((beta + permuted_input[i]) * (gamma + permuted_table[i])) % P for i in range(n)]
+    prod = batch_invert(prod)
+    for i in range(n):
+        prod[i] = prod[i] * ((compressed_input[i] + beta) % P) % P * ((compressed_table[i] + gamma) % P) % P
+    return prefix_product(prod, 1)

@@ -339,6 +339,55 @@ def gen_evalh():
     dump("evalh.json", out)
 
 
+# --------------------------------------------------------------------------------------------- grand products
+def gen_products():
+    """Permutation / lookup grand products, batch inversion and polynomial evaluation from their definitions: every
+    fraction is formed with its own modular inverse (pow(d, P - 2, P)), no batch trick, no scan."""
+    rnd = random.Random(SEED + 7)
+    out = {"comment": "grand products before blinding, canonical hex; z has n rows, z[0] = z0", "permutation": [],
+           "lookup": [], "batch_invert": [], "eval_polynomial": []}
+    inv = lambda v: pow(v, P - 2, P)
+    for k, cols, j0 in [(3, 1, 0), (4, 3, 2), (5, 4, 5)]:
+        n = 1 << k
+        dom = hm.EvaluationDomain(3, k)
+        values = [[rnd.randrange(P) for _ in range(n)] for _ in range(cols)]
+        sigmas = [[rnd.randrange(P) for _ in range(n)] for _ in range(cols)]
+        beta, gamma, z0 = rnd.randrange(P), rnd.randrange(P), rnd.randrange(1, P)
+        z = [z0]
+        for i in range(n - 1):
+            num = den = 1
+            for j in range(cols):
+                num = num * (values[j][i] + pow(bn.FR_DELTA, j0 + j, P) * beta % P * pow(dom.omega, i, P) + gamma) % P
+                den = den * (values[j][i] + beta * sigmas[j][i] + gamma) % P
+            z.append(z[-1] * num % P * inv(den) % P)
+        assert hm.permutation_product(dom.omega, values, sigmas, beta, gamma, pow(bn.FR_DELTA, j0, P), z0) == z
+        out["permutation"].append({"k": k, "first_column": j0, "values": [[hx(v) for v in c] for c in values],
+                                   "sigmas": [[hx(v) for v in c] for c in sigmas], "beta": hx(beta), "gamma": hx(gamma),
+                                   "z0": hx(z0), "z": [hx(v) for v in z]})
+    for k in (3, 5):
+        n = 1 << k
+        a, s, ap, sp = ([rnd.randrange(P) for _ in range(n)] for _ in range(4))
+        beta, gamma = rnd.randrange(P), rnd.randrange(P)
+        z = [1]
+        for i in range(n - 1):
+            z.append(z[-1] * (a[i] + beta) % P * (s[i] + gamma) % P * inv((ap[i] + beta) * (sp[i] + gamma) % P) % P)
+        assert hm.lookup_product(a, s, ap, sp, beta, gamma) == z
+        out["lookup"].append({"k": k, "input": [hx(v) for v in a], "table": [hx(v) for v in s],
+                              "permuted_input": [hx(v) for v in ap], "permuted_table": [hx(v) for v in sp],
+                              "beta": hx(beta), "gamma": hx(gamma), "z": [hx(v) for v in z]})
+    vals = [0, 1, P - 1, 2, 0, 0] + [rnd.randrange(P) for _ in range(27)]
+    expect = [inv(v) if v else 0 for v in vals]
+    assert hm.batch_invert(vals) == expect
+    out["batch_invert"].append({"input": [hx(v) for v in vals], "output": [hx(v) for v in expect]})
+    for n in (1, 5, 40):
+        c = [rnd.randrange(P) for _ in range(n)]
+        x = rnd.randrange(P)
+        direct = sum(ci * pow(x, i, P) for i, ci in enumerate(c)) % P
+        assert hm.eval_poly(c, x) == direct
+        out["eval_polynomial"].append({"coeff": [hx(v) for v in c], "x": hx(x), "value": hx(direct)})
+    dump("products.json", out)
+
+
 if __name__ == "__main__":
     bn.self_check()
     gen_field()
@@ -348,3 +397,4 @@ if __name__ == "__main__":
     gen_ntt()
     gen_domain()
     gen_evalh()
+    gen_products()

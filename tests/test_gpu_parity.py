@@ -357,3 +357,158 @@ def test_evaluate_h_rejects_malformed_graph(ctx):
     with pytest.raises(zk.ZkhipError):
         d.evaluate_h(call.build(ffi.MEM_HOST, ffi.FORM_EXTENDED))
     d.close()
+
+
+# ------------------------------------------------------------------------------------------------ grand products, openings
+def _with_zeros(rng, n, every=97):
+    a = rand_fr(rng, n)
+    a[::every] = 0
+    return a
+
+
+@pytest.mark.parametrize("n", [1, 2, 255, 4096, 70001])
+def test_batch_invert_and_prefix_product(ctx, n):
+    import halo2_model as hm
+    rng = np.random.default_rng(n)
+    a = _with_zeros(rng, n) if n > 2 else rand_fr(rng, n)
+    d = ctx.upload(a)
+    ctx.batch_invert_dev(0, d, n)
+    got = ctx.download(d, (n, 4))
+    exp = hm.batch_invert(fr_ints(a))
+    assert fr_ints(got) == exp
+    # product with the input is one wherever the input is non-zero
+    prod = ctx.field_binop(0, 2, got, a)
+    one = fr_arr([1])[0]
+    nz = a.any(axis=1)
+    assert (prod[nz] == one).all() and not prod[~nz].any()
+    # running product, in place and out of place
+    m = rand_fr(rng, n)
+    init = rand_fr(rng, 1)[0]
+    d_m, d_o = ctx.upload(m), ctx.alloc(n * 32)
+    ctx.prefix_product_dev(d_m, d_o, n, init)
+    exp = hm.prefix_product(fr_ints(m), fr_ints(init[None])[0])
+    assert fr_ints(ctx.download(d_o, (n, 4))) == exp
+    ctx.prefix_product_dev(d_m, d_m, n, init)
+    assert fr_ints(ctx.download(d_m, (n, 4))) == exp
+    for p in (d, d_m, d_o):
+        ctx.free(p)
+
+
+def test_batch_invert_fq_and_empty(ctx):
+    rng = np.random.default_rng(5)
+    a = rand_fr(rng, 1000)          # < 2^252, valid Fq residues as well
+    d = ctx.upload(a)
+    ctx.batch_invert_dev(1, d, 1000)
+    got = ctx.download(d, (1000, 4))
+    assert (ctx.field_binop(1, 2, got, a) == fq_arr([1])[0]).all()
+    ctx.batch_invert_dev(0, 0, 0)
+    ctx.free(d)
+
+
+@pytest.mark.parametrize("k,cols", [(4, 1), (9, 3), (12, 7)])
+def test_permutation_and_lookup_products(ctx, k, cols):
+    import halo2_model as hm
+    n = 1 << k
+    rng = np.random.default_rng(k * 10 + cols)
+    d = zk.Domain(ctx, 5, k)
+    omega = fr_ints(d.constant(0)[None])[0]
+    values = [rand_fr(rng, n) for _ in range(cols)]
+    sigmas = [rand_fr(rng, n) for _ in range(cols)]
+    beta, gamma, z0 = (rand_fr(rng, 1)[0] for _ in range(3))
+    j0 = 3
+    delta_start = fr_arr([pow(bn.FR_DELTA, j0, P)])[0]
+    d_vals = [ctx.upload(v) for v in values]
+    d_sigs = [ctx.upload(s) for s in sigmas]
+    d_z = ctx.alloc(n * 32)
+    d.permutation_product_dev(d_vals, d_sigs, beta, gamma, delta_start, z0, d_z)
+    exp = hm.permutation_product(omega, [fr_ints(v) for v in values], [fr_ints(s) for s in sigmas], fr_ints(beta[None])[0],
+                                 fr_ints(gamma[None])[0], pow(bn.FR_DELTA, j0, P), fr_ints(z0[None])[0])
+    assert fr_ints(ctx.download(d_z, (n, 4))) == exp
+    # lookup product; a' / s' with some (a' + beta) = 0 rows would be a broken witness, so plain random data
+    a, s, ap, sp = (rand_fr(rng, n) for _ in range(4))
+    ptrs = [ctx.upload(x) for x in (a, s, ap, sp)]
+    d.lookup_product_dev(ptrs[0], ptrs[1], ptrs[2], ptrs[3], beta, gamma, d_z)
+    exp = hm.lookup_product(fr_ints(a), fr_ints(s), fr_ints(ap), fr_ints(sp), fr_ints(beta[None])[0], fr_ints(gamma[None])[0])
+    assert fr_ints(ctx.download(d_z, (n, 4))) == exp
+    for p in d_vals + d_sigs + ptrs + [d_z]:
+        ctx.free(p)
+    d.close()
+
+
+def test_grand_product_full_size_telescopes(ctx):
+    """n = 2^19: with sigma_j[i] = delta^j omega^i (the identity permutation) every fraction is one, so z is constant;
+    and for a lookup with a' = a, s' = s likewise.  Checks the scan and the inversion at full size without a CPU pass."""
+    k = 19
+    n = 1 << k
+    rng = np.random.default_rng(19)
+    d = zk.Domain(ctx, 5, k)
+    omega = fr_ints(d.constant(0)[None])[0]
+    beta, gamma, z0 = (rand_fr(rng, 1)[0] for _ in range(3))
+    # identity permutation columns: delta^j * omega^i, built with the device NTT-free way: powers by prefix product
+    om = np.repeat(fr_arr([omega]), n, axis=0)
+    d_om = ctx.upload(om)
+    sig = []
+    for j in range(2):
+        dj = ctx.alloc(n * 32)
+        ctx.prefix_product_dev(d_om, dj, n, fr_arr([pow(bn.FR_DELTA, j, P)])[0])
+        sig.append(dj)
+    vals = [ctx.upload(rand_fr(rng, n)) for _ in range(2)]
+    d_z = ctx.alloc(n * 32)
+    d.permutation_product_dev(vals, sig, beta, gamma, fr_arr([1])[0], z0, d_z)
+    z = ctx.download(d_z, (n, 4))
+    assert (z == z0).all()
+    d.lookup_product_dev(vals[0], vals[1], vals[0], vals[1], beta, gamma, d_z)
+    assert (ctx.download(d_z, (n, 4)) == fr_arr([1])[0]).all()
+    for p in [d_om, d_z] + sig + vals:
+        ctx.free(p)
+    d.close()
+
+
+@pytest.mark.parametrize("n", [1, 17, 4096, 100003, 1 << 19])
+def test_eval_polynomial(ctx, n):
+    import halo2_model as hm
+    rng = np.random.default_rng(n)
+    c = rand_fr(rng, n)
+    x = rand_fr(rng, 1)[0]
+    d = ctx.upload(c)
+    got = fr_ints(ctx.eval_polynomial_dev(d, n, x)[None])[0]
+    assert got == hm.eval_poly(fr_ints(c), fr_ints(x[None])[0])
+    assert not ctx.eval_polynomial_dev(0, 0, x).any()
+    ctx.free(d)
+
+
+def test_grand_products_golden(ctx):
+    g = golden("products.json")
+    for c in g["permutation"]:
+        n = 1 << c["k"]
+        d = zk.Domain(ctx, 3, c["k"])
+        d_vals = [ctx.upload(hex_fr(v)) for v in c["values"]]
+        d_sigs = [ctx.upload(hex_fr(v)) for v in c["sigmas"]]
+        d_z = ctx.alloc(n * 32)
+        d.permutation_product_dev(d_vals, d_sigs, hex_fr([c["beta"]])[0], hex_fr([c["gamma"]])[0],
+                                  fr_arr([pow(bn.FR_DELTA, c["first_column"], P)])[0], hex_fr([c["z0"]])[0], d_z)
+        assert np.array_equal(ctx.download(d_z, (n, 4)), hex_fr(c["z"]))
+        for p in d_vals + d_sigs + [d_z]:
+            ctx.free(p)
+        d.close()
+    for c in g["lookup"]:
+        n = 1 << c["k"]
+        d = zk.Domain(ctx, 4, c["k"])
+        ptrs = [ctx.upload(hex_fr(c[key])) for key in ("input", "table", "permuted_input", "permuted_table")]
+        d_z = ctx.alloc(n * 32)
+        d.lookup_product_dev(ptrs[0], ptrs[1], ptrs[2], ptrs[3], hex_fr([c["beta"]])[0], hex_fr([c["gamma"]])[0], d_z)
+        assert np.array_equal(ctx.download(d_z, (n, 4)), hex_fr(c["z"]))
+        for p in ptrs + [d_z]:
+            ctx.free(p)
+        d.close()
+    for c in g["batch_invert"]:
+        a = hex_fr(c["input"])
+        d_a = ctx.upload(a)
+        ctx.batch_invert_dev(0, d_a, len(a))
+        assert np.array_equal(ctx.download(d_a, (len(a), 4)), hex_fr(c["output"]))
+        ctx.free(d_a)
+    for c in g["eval_polynomial"]:
+        co_ = hex_fr(c["coeff"])
+        d_c = ctx.upload(co_)
+        assert np.array_equal(ctx.eval_polynomial_dev(d_c, len(co_), hex_fr([c["x"]])[0]), hex_fr([c["value"]])[0])
+        ctx.free(d_c)

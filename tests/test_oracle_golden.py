@@ -149,6 +149,26 @@ def test_evaluate_h_golden(co):
         assert np.array_equal(out, hex_fr(case["h"])), case["cs"]
 
 
+def test_grand_products_golden():
+    """the Python model's batch-inverse + scan formulation against the per-row definitions stored in products.json"""
+    g = golden("products.json")
+    ints = lambda hs: [int(h, 16) for h in hs]
+    for c in g["permutation"]:
+        dom = hm.EvaluationDomain(3, c["k"])
+        z = hm.permutation_product(dom.omega, [ints(v) for v in c["values"]], [ints(v) for v in c["sigmas"]],
+                                   int(c["beta"], 16), int(c["gamma"], 16), pow(bn.FR_DELTA, c["first_column"], bn.FR_MODULUS),
+                                   int(c["z0"], 16))
+        assert z == ints(c["z"])
+    for c in g["lookup"]:
+        z = hm.lookup_product(ints(c["input"]), ints(c["table"]), ints(c["permuted_input"]), ints(c["permuted_table"]),
+                              int(c["beta"], 16), int(c["gamma"], 16))
+        assert z == ints(c["z"])
+    for c in g["batch_invert"]:
+        assert hm.batch_invert(ints(c["input"])) == ints(c["output"])
+    for c in g["eval_polynomial"]:
+        assert hm.eval_poly(ints(c["coeff"]), int(c["x"], 16)) == int(c["value"], 16)
+
+
 def test_model_multiexp_threads_agree():
     rnd = np.random.default_rng(5)
     n = 40

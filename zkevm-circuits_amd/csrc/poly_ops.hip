@@ -1,0 +1,380 @@
+// Device versions of the prover steps right next to the hot path: the grand products of the permutation and lookup
+// arguments and polynomial evaluation at a point.
+//
+//   `ff::BatchInvert::batch_invert`                    -> zkhip_batch_invert_dev
+//   running product z[i+1] = z[i] * m[i]               -> zkhip_prefix_product_dev
+//   `plonk::permutation::prover::Argument::commit`     -> zkhip_permutation_product_dev   (one column set)
+//   `plonk::lookup::prover::Permuted::commit_product`  -> zkhip_lookup_product_dev
+//   `arithmetic::eval_polynomial`                      -> zkhip_eval_polynomial_dev
+//
+// The blinding rows are left to the caller: upstream draws them from the prover's RNG in a fixed order, so the host
+// overwrites the last `blinding_factors` rows of z after these calls and reads last_z from row n - blinding - 1.
+// Field inverses are unique, so any exact inversion scheme reproduces upstream's values bit for bit.
+#include <algorithm>
+#include <cstring>
+#include <vector>
+#include "common.h"
+#include "domain.h"
+
+using namespace zkhip;
+
+namespace zkhip {
+
+constexpr int PO_THREADS = 256;
+
+template <class F, class FP>
+ZK_DEV fe field_invert(const fe& x) {
+    fe acc = F::one();
+    for (int bit = 255; bit >= 0; bit--) {
+        acc = F::sqr(acc);
+        uint32_t word = FP::P[bit >> 5];
+        if ((bit >> 5) == 0) word -= 2;   // exponent p - 2; the low word of p is > 2
+        if ((word >> (bit & 31)) & 1) acc = F::mul(acc, x);
+    }
+    return acc;
+}
+
+// ---- batch inversion ---------------------------------------------------------------------------------
+// Lane t owns the elements t, t + S, t + 2S, ... (S = lanes of the launch; coalesced).  Forward: running products of
+// its elements into `prefix`; one Fermat inversion of the lane's total; backward: a_k^-1 = prefix_k * inv, inv *= a_k.
+// Zeros are skipped and stay zero.
+template <class F, class FP>
+__global__ void __launch_bounds__(PO_THREADS) batch_invert_kernel(fe* a, fe* prefix, size_t n, size_t lanes) {
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= lanes) return;
+    fe run = F::one();
+    for (size_t i = t; i < n; i += lanes) {
+        store_fe(prefix + i, run);
+        const fe v = load_fe(a + i);
+        if (!F::is_zero(v)) run = F::mul(run, v);
+    }
+    fe inv = field_invert<F, FP>(run);
+    // backward over the same elements
+    size_t last = t + ((n - 1 - t) / lanes) * lanes;
+    for (size_t i = last;; i -= lanes) {
+        const fe v = load_fe(a + i);
+        if (!F::is_zero(v)) {
+            store_fe(a + i, F::mul(load_fe(prefix + i), inv));
+            inv = F::mul(inv, v);
+        }
+        if (i < lanes) break;
+    }
+}
+
+// ---- prefix product ----------------------------------------------------------------------------------
+constexpr int PP_PER = 8;                       // elements per lane
+constexpr int PP_BLOCK = PO_THREADS * PP_PER;   // elements per block
+
+__device__ __forceinline__ fe block_exclusive_product(const fe& v, fe* sh /*[PO_THREADS]*/, fe* total) {
+    // Hillis-Steele inclusive scan, then shift
+    const uint32_t tid = threadIdx.x;
+    sh[tid] = v;
+    __syncthreads();
+    fe cur = v;
+    for (uint32_t off = 1; off < PO_THREADS; off <<= 1) {
+        fe other;
+        const bool take = tid >= off;
+        if (take) other = sh[tid - off];
+        __syncthreads();
+        if (take) {
+            cur = Fr::mul(other, cur);
+            sh[tid] = cur;
+        }
+        __syncthreads();
+    }
+    if (total) *total = sh[PO_THREADS - 1];
+    fe excl = tid ? sh[tid - 1] : Fr::one();
+    __syncthreads();
+    return excl;
+}
+
+// phase 1: out[i] = product of m[block start .. i) within the block; totals[block] = product of the block's elements
+__global__ void __launch_bounds__(PO_THREADS) prefix_local_kernel(const fe* m, fe* out, size_t n, fe* totals) {
+    __shared__ fe sh[PO_THREADS];
+    const size_t base = (size_t)blockIdx.x * PP_BLOCK + (size_t)threadIdx.x * PP_PER;
+    fe loc[PP_PER];
+    fe run = Fr::one();
+#pragma unroll
+    for (int k = 0; k < PP_PER; k++) {
+        loc[k] = run;
+        if (base + k < n) run = Fr::mul(run, load_fe(m + base + k));
+    }
+    fe total;
+    const fe excl = block_exclusive_product(run, sh, &total);
+#pragma unroll
+    for (int k = 0; k < PP_PER; k++)
+        if (base + k < n) store_fe(out + base + k, Fr::mul(excl, loc[k]));
+    if (threadIdx.x == 0) store_fe(totals + blockIdx.x, total);
+}
+// phase 2 (one block): totals[b] <- init * product of totals[0 .. b)
+__global__ void __launch_bounds__(PO_THREADS) prefix_totals_kernel(fe* totals, size_t nblocks, fe init) {
+    __shared__ fe sh[PO_THREADS];
+    fe carry = init;
+    for (size_t base = 0; base < nblocks; base += PO_THREADS) {
+        const size_t i = base + threadIdx.x;
+        const fe v = i < nblocks ? load_fe(totals + i) : Fr::one();
+        fe total;
+        const fe excl = block_exclusive_product(v, sh, &total);
+        if (i < nblocks) store_fe(totals + i, Fr::mul(carry, excl));
+        carry = Fr::mul(carry, total);
+    }
+}
+// phase 3: out[i] *= totals[block]
+__global__ void __launch_bounds__(PO_THREADS) prefix_apply_kernel(fe* out, size_t n, const fe* totals) {
+    const fe off = load_fe(totals + blockIdx.x);
+    const size_t base = (size_t)blockIdx.x * PP_BLOCK;
+    for (int k = 0; k < PP_PER; k++) {
+        const size_t i = base + (size_t)k * PO_THREADS + threadIdx.x;
+        if (i < n) store_fe(out + i, Fr::mul(load_fe(out + i), off));
+    }
+}
+
+// ---- permutation / lookup fractions ------------------------------------------------------------------
+struct PermArgs {
+    const fe* const* values;   // device array of column pointers (Lagrange basis)
+    const fe* const* sigmas;
+    uint32_t num_cols;
+    fe beta, gamma, delta_start;   // delta_start = delta^(index of the set's first column)
+    const fe* om_lo;
+    const fe* om_hi;
+    uint32_t h;
+};
+// out[i] = prod_j (beta * sigma_j[i] + gamma + v_j[i])
+__global__ void __launch_bounds__(PO_THREADS) perm_denominator_kernel(const PermArgs a, fe* out, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    fe acc = Fr::one();
+    for (uint32_t j = 0; j < a.num_cols; j++) {
+        const fe t = Fr::add(Fr::add(Fr::mul(a.beta, load_fe(a.sigmas[j] + i)), a.gamma), load_fe(a.values[j] + i));
+        acc = Fr::mul(acc, t);
+    }
+    store_fe(out + i, acc);
+}
+// io[i] *= prod_j (delta^(j0 + j) * beta * omega^i + gamma + v_j[i])
+__global__ void __launch_bounds__(PO_THREADS) perm_numerator_kernel(const PermArgs a, fe* io, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    fe w = load_fe(a.om_lo + (i & ((1u << a.h) - 1)));
+    if (i >> a.h) w = Fr::mul(w, load_fe(a.om_hi + (i >> a.h)));
+    fe cur = Fr::mul(Fr::mul(w, a.beta), a.delta_start);
+    fe delta;
+#pragma unroll
+    for (int k = 0; k < 8; k++) delta.l[k] = FrParams::DELTA[k];
+    fe acc = load_fe(io + i);
+    for (uint32_t j = 0; j < a.num_cols; j++) {
+        acc = Fr::mul(acc, Fr::add(Fr::add(cur, a.gamma), load_fe(a.values[j] + i)));
+        cur = Fr::mul(cur, delta);
+    }
+    store_fe(io + i, acc);
+}
+// out[i] = (x[i] + beta) * (y[i] + gamma)        (lookup denominators from a', s')
+__global__ void __launch_bounds__(PO_THREADS) shifted_product_kernel(const fe* x, const fe* y, fe beta, fe gamma, fe* out, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    store_fe(out + i, Fr::mul(Fr::add(load_fe(x + i), beta), Fr::add(load_fe(y + i), gamma)));
+}
+// io[i] *= (x[i] + beta) * (y[i] + gamma)         (lookup numerators from the compressed expressions)
+__global__ void __launch_bounds__(PO_THREADS) shifted_product_mul_kernel(const fe* x, const fe* y, fe beta, fe gamma, fe* io, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const fe t = Fr::mul(Fr::add(load_fe(x + i), beta), Fr::add(load_fe(y + i), gamma));
+    store_fe(io + i, Fr::mul(load_fe(io + i), t));
+}
+
+// ---- polynomial evaluation ---------------------------------------------------------------------------
+// Lane t evaluates its EP_PER consecutive coefficients by Horner, scales by x^(t * EP_PER) (x_per = x^EP_PER given)
+// and the block sums its lanes; partial[block] goes to the host.
+constexpr int EP_PER = 16;
+__global__ void __launch_bounds__(PO_THREADS) eval_poly_kernel(const fe* coeff, size_t n, fe x, fe x_per, fe* partial) {
+    __shared__ fe sh[PO_THREADS];
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t base = t * EP_PER;
+    fe acc = Fr::zero();
+    if (base < n) {
+        const size_t hi = base + EP_PER < n ? base + EP_PER : n;
+        for (size_t i = hi; i-- > base;) acc = Fr::add(Fr::mul(acc, x), load_fe(coeff + i));
+        // x^(t * EP_PER) = x_per^t
+        fe p = Fr::one(), b = x_per;
+        for (size_t e = t; e; e >>= 1) {
+            if (e & 1) p = Fr::mul(p, b);
+            b = Fr::sqr(b);
+        }
+        acc = Fr::mul(acc, p);
+    }
+    sh[threadIdx.x] = acc;
+    __syncthreads();
+    for (uint32_t half = PO_THREADS / 2; half >= 1; half >>= 1) {
+        if (threadIdx.x < half) sh[threadIdx.x] = Fr::add(sh[threadIdx.x], sh[threadIdx.x + half]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) store_fe(partial + blockIdx.x, sh[0]);
+}
+
+// ---- launch helpers ----------------------------------------------------------------------------------
+static fe fe_from(const uint64_t v[4]) {
+    fe o;
+    memcpy(o.l, v, 32);
+    return o;
+}
+
+static size_t invert_lanes(const zkhip_ctx* ctx, size_t n) {
+    // 16 elements per lane amortise the 380-multiplication inversion; never fewer lanes than one wave per SIMD
+    size_t lanes = (n + 15) / 16;
+    const size_t floor_lanes = (size_t)ctx->num_cus * 256;
+    if (lanes < floor_lanes) lanes = std::min(n, floor_lanes);
+    return lanes;
+}
+
+// a (n elements, device) -> inverses in place; tmp: n elements of scratch
+static int batch_invert_dev(zkhip_ctx* ctx, int field, fe* d_a, fe* d_tmp, size_t n) {
+    if (n == 0) return ZKHIP_OK;
+    const size_t lanes = invert_lanes(ctx, n);
+    const dim3 grid((unsigned)((lanes + PO_THREADS - 1) / PO_THREADS));
+    if (field == 0)
+        hipLaunchKernelGGL((batch_invert_kernel<Fr, FrParams>), grid, dim3(PO_THREADS), 0, ctx->stream, d_a, d_tmp, n, lanes);
+    else
+        hipLaunchKernelGGL((batch_invert_kernel<Fq, FqParams>), grid, dim3(PO_THREADS), 0, ctx->stream, d_a, d_tmp, n, lanes);
+    ZK_HIP(ctx, hipGetLastError());
+    return ZKHIP_OK;
+}
+
+// out[0] = init, out[i] = init * m[0] * ... * m[i-1]; totals: ceil(n / PP_BLOCK) elements of scratch.  m may equal out.
+static int prefix_product_dev(zkhip_ctx* ctx, const fe* d_m, fe* d_out, fe* d_totals, size_t n, const fe& init) {
+    if (n == 0) return ZKHIP_OK;
+    const size_t nblocks = (n + PP_BLOCK - 1) / PP_BLOCK;
+    hipLaunchKernelGGL(prefix_local_kernel, dim3((unsigned)nblocks), dim3(PO_THREADS), 0, ctx->stream, d_m, d_out, n, d_totals);
+    hipLaunchKernelGGL(prefix_totals_kernel, dim3(1), dim3(PO_THREADS), 0, ctx->stream, d_totals, nblocks, init);
+    hipLaunchKernelGGL(prefix_apply_kernel, dim3((unsigned)nblocks), dim3(PO_THREADS), 0, ctx->stream, d_out, n, d_totals);
+    ZK_HIP(ctx, hipGetLastError());
+    return ZKHIP_OK;
+}
+
+}  // namespace zkhip
+
+extern "C" {
+
+int zkhip_batch_invert_dev(zkhip_ctx* ctx, int field, uint64_t* d_a, size_t n) {
+    if (!ctx) return ZKHIP_ERR_INVALID;
+    ZK_CHECK(ctx, field == 0 || field == 1, "batch_invert: field %d", field);
+    ZK_CHECK(ctx, d_a || n == 0, "batch_invert: null pointer");
+    ZK_HIP(ctx, hipSetDevice(ctx->device));
+    int rc = ensure_scratch(ctx, n * 32);
+    if (rc) return rc;
+    TimedRegion tr(ctx, "batch_invert");
+    return batch_invert_dev(ctx, field, (fe*)d_a, (fe*)ctx->scratch, n);
+}
+
+int zkhip_prefix_product_dev(zkhip_ctx* ctx, const uint64_t* d_m, uint64_t* d_out, size_t n, const uint64_t init[4]) {
+    if (!ctx) return ZKHIP_ERR_INVALID;
+    ZK_CHECK(ctx, (d_m && d_out && init) || n == 0, "prefix_product: null pointer");
+    ZK_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t nblocks = (n + PP_BLOCK - 1) / PP_BLOCK;
+    int rc = ensure_scratch(ctx, (nblocks + 1) * 32);
+    if (rc) return rc;
+    TimedRegion tr(ctx, "prefix_product");
+    return prefix_product_dev(ctx, (const fe*)d_m, (fe*)d_out, (fe*)ctx->scratch, n, fe_from(init));
+}
+
+int zkhip_permutation_product_dev(zkhip_domain* dom, const uint64_t* const* d_values, const uint64_t* const* d_sigmas,
+                                  uint32_t num_cols, const uint64_t beta[4], const uint64_t gamma[4],
+                                  const uint64_t delta_start[4], const uint64_t z0[4], uint64_t* d_z) {
+    if (!dom) return ZKHIP_ERR_INVALID;
+    zkhip_ctx* ctx = dom->ctx;
+    ZK_CHECK(ctx, d_values && d_sigmas && beta && gamma && delta_start && z0 && d_z, "permutation_product: null pointer");
+    ZK_CHECK(ctx, num_cols >= 1 && num_cols <= 64, "permutation_product: %u columns in one set", num_cols);
+    for (uint32_t j = 0; j < num_cols; j++)
+        ZK_CHECK(ctx, d_values[j] && d_sigmas[j], "permutation_product: null column %u", j);
+    ZK_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t n = (size_t)1 << dom->k;
+    const size_t nblocks = (n + PP_BLOCK - 1) / PP_BLOCK;
+    // scratch: [prefix temp n][totals nblocks][pointer tables]
+    const size_t ptr_bytes = 2 * (size_t)num_cols * sizeof(void*);
+    int rc = ensure_scratch(ctx, (n + nblocks + 1) * 32 + ptr_bytes);
+    if (rc) return rc;
+    fe* d_tmp = (fe*)ctx->scratch;
+    fe* d_totals = d_tmp + n;
+    const fe** d_ptrs = (const fe**)(d_totals + nblocks + 1);
+    ZK_HIP(ctx, hipMemcpyAsync(d_ptrs, d_values, num_cols * sizeof(void*), hipMemcpyHostToDevice, ctx->stream));
+    ZK_HIP(ctx, hipMemcpyAsync(d_ptrs + num_cols, d_sigmas, num_cols * sizeof(void*), hipMemcpyHostToDevice, ctx->stream));
+    PermArgs a;
+    a.values = d_ptrs;
+    a.sigmas = d_ptrs + num_cols;
+    a.num_cols = num_cols;
+    a.beta = fe_from(beta);
+    a.gamma = fe_from(gamma);
+    a.delta_start = fe_from(delta_start);
+    a.om_lo = (const fe*)dom->plan_fwd->d_lo;
+    a.om_hi = (const fe*)dom->plan_fwd->d_hi;
+    a.h = dom->plan_fwd->h;
+    TimedRegion tr(ctx, "grand_product");
+    const dim3 grid((unsigned)((n + PO_THREADS - 1) / PO_THREADS));
+    fe* z = (fe*)d_z;
+    hipLaunchKernelGGL(perm_denominator_kernel, grid, dim3(PO_THREADS), 0, ctx->stream, a, z, n);
+    ZK_HIP(ctx, hipGetLastError());
+    rc = batch_invert_dev(ctx, 0, z, d_tmp, n);
+    if (rc) return rc;
+    hipLaunchKernelGGL(perm_numerator_kernel, grid, dim3(PO_THREADS), 0, ctx->stream, a, z, n);
+    ZK_HIP(ctx, hipGetLastError());
+    return prefix_product_dev(ctx, z, z, d_totals, n, fe_from(z0));
+}
+
+int zkhip_lookup_product_dev(zkhip_domain* dom, const uint64_t* d_compressed_input, const uint64_t* d_compressed_table,
+                             const uint64_t* d_permuted_input, const uint64_t* d_permuted_table, const uint64_t beta[4],
+                             const uint64_t gamma[4], uint64_t* d_z) {
+    if (!dom) return ZKHIP_ERR_INVALID;
+    zkhip_ctx* ctx = dom->ctx;
+    ZK_CHECK(ctx, d_compressed_input && d_compressed_table && d_permuted_input && d_permuted_table && beta && gamma && d_z,
+             "lookup_product: null pointer");
+    ZK_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t n = (size_t)1 << dom->k;
+    const size_t nblocks = (n + PP_BLOCK - 1) / PP_BLOCK;
+    int rc = ensure_scratch(ctx, (n + nblocks + 1) * 32);
+    if (rc) return rc;
+    fe* d_tmp = (fe*)ctx->scratch;
+    fe* d_totals = d_tmp + n;
+    TimedRegion tr(ctx, "grand_product");
+    const dim3 grid((unsigned)((n + PO_THREADS - 1) / PO_THREADS));
+    fe* z = (fe*)d_z;
+    const fe b = fe_from(beta), g = fe_from(gamma);
+    hipLaunchKernelGGL(shifted_product_kernel, grid, dim3(PO_THREADS), 0, ctx->stream, (const fe*)d_permuted_input,
+                       (const fe*)d_permuted_table, b, g, z, n);
+    ZK_HIP(ctx, hipGetLastError());
+    rc = batch_invert_dev(ctx, 0, z, d_tmp, n);
+    if (rc) return rc;
+    hipLaunchKernelGGL(shifted_product_mul_kernel, grid, dim3(PO_THREADS), 0, ctx->stream, (const fe*)d_compressed_input,
+                       (const fe*)d_compressed_table, b, g, z, n);
+    ZK_HIP(ctx, hipGetLastError());
+    fe one;
+    memcpy(one.l, HFR.r, 32);
+    return prefix_product_dev(ctx, z, z, d_totals, n, one);
+}
+
+int zkhip_eval_polynomial_dev(zkhip_ctx* ctx, const uint64_t* d_coeff, size_t n, const uint64_t x[4], uint64_t out[4]) {
+    if (!ctx || !out) return ZKHIP_ERR_INVALID;
+    ZK_CHECK(ctx, (d_coeff && x) || n == 0, "eval_polynomial: null pointer");
+    memset(out, 0, 32);
+    if (n == 0) return ZKHIP_OK;
+    ZK_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t lanes = (n + EP_PER - 1) / EP_PER;
+    const size_t nblocks = (lanes + PO_THREADS - 1) / PO_THREADS;
+    int rc = ensure_scratch(ctx, nblocks * 32);
+    if (rc) return rc;
+    uint64_t x_per[4];
+    h_pow(HFR, x_per, x, EP_PER);
+    {
+        TimedRegion tr(ctx, "eval_polynomial");
+        hipLaunchKernelGGL(eval_poly_kernel, dim3((unsigned)nblocks), dim3(PO_THREADS), 0, ctx->stream, (const fe*)d_coeff, n,
+                           fe_from(x), fe_from(x_per), (fe*)ctx->scratch);
+        ZK_HIP(ctx, hipGetLastError());
+    }
+    std::vector<uint64_t> part(nblocks * 4);
+    ZK_HIP(ctx, hipMemcpyAsync(part.data(), ctx->scratch, nblocks * 32, hipMemcpyDeviceToHost, ctx->stream));
+    ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    // block b holds sum_t p_t x^(t EP_PER) with t global, so the partials simply add up
+    uint64_t acc[4] = {0, 0, 0, 0};
+    for (size_t b = 0; b < nblocks; b++) h_add(HFR, acc, acc, &part[4 * b]);
+    memcpy(out, acc, 32);
+    return ZKHIP_OK;
+}
+
+}  // extern "C"

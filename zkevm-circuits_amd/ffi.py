@@ -28,6 +28,8 @@ EXPORTS = [
     "zkhip_lagrange_to_coeff_dev", "zkhip_coeff_to_lagrange_dev", "zkhip_coeff_to_extended_dev",
     "zkhip_extended_to_coeff_dev", "zkhip_divide_by_vanishing_poly_dev",
     "zkhip_evaluate_h",
+    "zkhip_batch_invert_dev", "zkhip_prefix_product_dev", "zkhip_permutation_product_dev", "zkhip_lookup_product_dev",
+    "zkhip_eval_polynomial_dev",
     "zkhip_timing_enable", "zkhip_timing_reset", "zkhip_timing_get",
 ]
 
@@ -268,6 +270,20 @@ class Context:
         self._ck(self._l.zkhip_ntt_dev(self.h, C.c_void_p(d_a), C.c_uint32(log_n), _p(om), C.c_size_t(batch)))
 
     # -- timing ---------------------------------------------------------------------------------
+    # grand products and openings (device-resident)
+    def batch_invert_dev(self, field: int, d_a: int, n: int):
+        self._ck(self._l.zkhip_batch_invert_dev(self.h, C.c_int(field), C.c_void_p(d_a), C.c_size_t(n)))
+
+    def prefix_product_dev(self, d_m: int, d_out: int, n: int, init):
+        init = u64(init)
+        self._ck(self._l.zkhip_prefix_product_dev(self.h, C.c_void_p(d_m), C.c_void_p(d_out), C.c_size_t(n), _p(init)))
+
+    def eval_polynomial_dev(self, d_coeff: int, n: int, x):
+        x = u64(x)
+        out = np.zeros(4, dtype=np.uint64)
+        self._ck(self._l.zkhip_eval_polynomial_dev(self.h, C.c_void_p(d_coeff), C.c_size_t(n), _p(x), _p(out)))
+        return out
+
     def timing_enable(self, on=True):
         self._ck(self._l.zkhip_timing_enable(self.h, C.c_int(1 if on else 0)))
 
@@ -360,6 +376,23 @@ class Domain:
 
     def divide_by_vanishing_poly_dev(self, d_ext: int, batch: int = 1):
         self.ctx._ck(self._l.zkhip_divide_by_vanishing_poly_dev(self.h, C.c_void_p(d_ext), C.c_size_t(batch)))
+
+    def permutation_product_dev(self, d_values, d_sigmas, beta, gamma, delta_start, z0, d_z: int):
+        """One column set of `permutation::prover::Argument::commit` (all n rows; blinding rows are the caller's)."""
+        assert len(d_values) == len(d_sigmas) and d_values
+        vals = (C.c_void_p * len(d_values))(*d_values)
+        sigs = (C.c_void_p * len(d_sigmas))(*d_sigmas)
+        beta, gamma, delta_start, z0 = u64(beta), u64(gamma), u64(delta_start), u64(z0)
+        self.ctx._ck(self._l.zkhip_permutation_product_dev(self.h, vals, sigs, C.c_uint32(len(d_values)), _p(beta), _p(gamma),
+                                                           _p(delta_start), _p(z0), C.c_void_p(d_z)))
+
+    def lookup_product_dev(self, d_input: int, d_table: int, d_permuted_input: int, d_permuted_table: int, beta, gamma,
+                           d_z: int):
+        """`lookup::prover::Permuted::commit_product` (all n rows; blinding rows are the caller's)."""
+        beta, gamma = u64(beta), u64(gamma)
+        self.ctx._ck(self._l.zkhip_lookup_product_dev(self.h, C.c_void_p(d_input), C.c_void_p(d_table),
+                                                      C.c_void_p(d_permuted_input), C.c_void_p(d_permuted_table), _p(beta),
+                                                      _p(gamma), C.c_void_p(d_z)))
 
     def evaluate_h(self, desc: EvalhDesc, out_dev: int | None = None):
         """`Evaluator::evaluate_h`.  Host descriptor -> numpy result; device descriptor -> writes out_dev."""
