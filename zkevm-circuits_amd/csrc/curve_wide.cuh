@@ -1,7 +1,8 @@
 // XYZZ bucket accumulation on the lazy signed-digit arithmetic of wide.cuh (the MSM accumulate kernel's inner loop).
 //
 // Coordinates live in the 2^261 Montgomery domain (the MSM tables are stored in it; see msm.hip).  A mixed addition
-// is 8 mul + 2 sqr, seven digit-wise subtractions and two carry normalisations; nothing is reduced modulo p.
+// is 8 mul + 2 sqr (the two products of y3 share one reduction), digit-wise subtractions and one carry
+// normalisation; nothing is reduced modulo p.
 // Digit-magnitude bookkeeping (see wide.cuh): acc.x, acc.y, acc.zz, acc.zzz are normalised; every subtraction below
 // takes two normalised values, so its result is a valid mul / sqr operand; x3 (four terms) and y3 are normalised
 // before they are stored.  Value bookkeeping: with |x| < 3.3 p, |y| < 1.2 p at entry, P and Rr stay below 4.3 p and
@@ -27,7 +28,7 @@ __device__ __forceinline__ void xyzz_w_double_affine(g1_xyzz_w& acc, const fw& x
     const fw x2 = FqW::sqr(x);
     const fw m = FqW::norm(FqW::add(FqW::dbl(x2), x2));
     const fw x3 = FqW::norm(FqW::sub(FqW::sqr(m), FqW::dbl(s)));
-    acc.y = FqW::norm(FqW::sub(FqW::mul(m, FqW::sub(s, x3)), FqW::mul(w, yn)));
+    acc.y = FqW::mul_sub_mul(m, FqW::sub(s, x3), w, yn);
     acc.x = x3;
     acc.zz = v;
     acc.zzz = w;
@@ -65,7 +66,7 @@ __device__ __forceinline__ void xyzz_w_add_affine(g1_xyzz_w& acc, const g1_affin
     const fw ppp = FqW::mul(p, pp);
     const fw qq = FqW::mul(acc.x, pp);
     const fw x3 = FqW::norm(FqW::sub(FqW::sub(FqW::sqr(r), ppp), FqW::dbl(qq)));
-    acc.y = FqW::norm(FqW::sub(FqW::mul(r, FqW::sub(qq, x3)), FqW::mul(acc.y, ppp)));
+    acc.y = FqW::mul_sub_mul(r, FqW::sub(qq, x3), acc.y, ppp);
     acc.x = x3;
     acc.zz = FqW::mul(acc.zz, pp);
     acc.zzz = FqW::mul(acc.zzz, ppp);
@@ -81,7 +82,7 @@ __device__ __forceinline__ g1_xyzz_w xyzz_w_double(const g1_xyzz_w& a) {
     const fw x2 = FqW::sqr(a.x);
     const fw m = FqW::norm(FqW::add(FqW::dbl(x2), x2));
     o.x = FqW::norm(FqW::sub(FqW::sqr(m), FqW::dbl(s)));
-    o.y = FqW::norm(FqW::sub(FqW::mul(m, FqW::sub(s, o.x)), FqW::mul(w, a.y)));
+    o.y = FqW::mul_sub_mul(m, FqW::sub(s, o.x), w, a.y);
     o.zz = FqW::mul(v, a.zz);
     o.zzz = FqW::mul(w, a.zzz);
     o.inf = false;
@@ -111,7 +112,7 @@ __device__ __forceinline__ g1_xyzz_w xyzz_w_add(const g1_xyzz_w& a, const g1_xyz
     const fw ppp = FqW::mul(p, pp);
     const fw qq = FqW::mul(u1, pp);
     o.x = FqW::norm(FqW::sub(FqW::sub(FqW::sqr(r), ppp), FqW::dbl(qq)));
-    o.y = FqW::norm(FqW::sub(FqW::mul(r, FqW::sub(qq, o.x)), FqW::mul(s1, ppp)));
+    o.y = FqW::mul_sub_mul(r, FqW::sub(qq, o.x), s1, ppp);
     o.zz = FqW::mul(FqW::mul(a.zz, b.zz), pp);
     o.zzz = FqW::mul(FqW::mul(a.zzz, b.zzz), ppp);
     o.inf = false;

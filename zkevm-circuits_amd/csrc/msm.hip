@@ -24,6 +24,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
+#include <mutex>
 #include "common.h"
 #include "curve.cuh"
 #include "curve_wide.cuh"
@@ -334,7 +336,7 @@ ZK_DEV uint32_t find_bucket(const uint32_t* off, uint32_t B, uint32_t t) {
 
 // ---- accumulate ------------------------------------------------------------------------------------
 // lane t = slot s of bucket b: folds entries [s * cnt / f, (s + 1) * cnt / f) of the bucket, f = slots of the bucket
-__global__ void __launch_bounds__(256) accumulate_kernel(const uint32_t* entries, const uint32_t* start, const uint32_t* cnt,
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) accumulate_kernel(const uint32_t* entries, const uint32_t* start, const uint32_t* cnt,
                                                          const uint32_t* slot_off, const uint32_t* slot_cnt, uint32_t B,
                                                          const g1_affine* tables, size_t table_stride, size_t first,
                                                          g1_xyzz* items) {
@@ -730,9 +732,20 @@ struct MsmState {
     hipEvent_t ev_in = nullptr, ev_out[MSM_PIPE] = {nullptr, nullptr, nullptr};
     hipStream_t batch_streams[MSM_PIPE] = {nullptr, nullptr, nullptr};
 };
-static std::map<zkhip_ctx*, MsmState>& registry() {
+// Per-context MSM state.  The map is shared by all contexts of the process (one per device), so lookups are
+// serialised; a context itself is not re-entrant, so the state found is then used without the lock.  std::map never
+// moves its nodes: the reference stays valid while other contexts come and go.
+static std::mutex& registry_mutex() {
+    static std::mutex m;
+    return m;
+}
+static std::map<zkhip_ctx*, MsmState>& registry_unlocked() {
     static std::map<zkhip_ctx*, MsmState> r;
     return r;
+}
+static MsmState& state_of(zkhip_ctx* ctx) {
+    std::lock_guard<std::mutex> lock(registry_mutex());
+    return registry_unlocked()[ctx];
 }
 
 static int check_args(zkhip_ctx* ctx, const MsmTables& tb, size_t first, size_t n) {
@@ -805,8 +818,9 @@ int msm_run_batch(zkhip_ctx* ctx, MsmState& stt, const MsmTables& tb, const uint
 }
 
 void msm_drop_ctx(zkhip_ctx* ctx) {
-    auto it = registry().find(ctx);
-    if (it == registry().end()) return;
+    std::lock_guard<std::mutex> lock(registry_mutex());
+    auto it = registry_unlocked().find(ctx);
+    if (it == registry_unlocked().end()) return;
     MsmState& st = it->second;
     for (auto& kv : st.tables)
         if (kv.second.d_tables) (void)hipFree(kv.second.d_tables);
@@ -820,7 +834,7 @@ void msm_drop_ctx(zkhip_ctx* ctx) {
         if (st.ev_out[i]) (void)hipEventDestroy(st.ev_out[i]);
     }
     if (st.ev_in) (void)hipEventDestroy(st.ev_in);
-    registry().erase(it);
+    registry_unlocked().erase(it);
 }
 
 int msm_init(zkhip_ctx* ctx) {
@@ -862,14 +876,14 @@ int zkhip_register_bases(zkhip_ctx* ctx, const uint64_t* affine_xy, size_t n, ui
         return set_error(ctx, ZKHIP_ERR_HIP, "register_bases failed: %s", hipGetErrorString(e));
     }
     const uint32_t id = ctx->next_bases_id++;
-    registry()[ctx].tables[id] = tb;
+    state_of(ctx).tables[id] = tb;
     *out_id = id;
     return ZKHIP_OK;
 }
 
 int zkhip_release_bases(zkhip_ctx* ctx, uint32_t bases_id) {
     if (!ctx) return ZKHIP_ERR_INVALID;
-    auto& m = registry()[ctx].tables;
+    auto& m = state_of(ctx).tables;
     auto it = m.find(bases_id);
     ZK_CHECK(ctx, it != m.end(), "release_bases: unknown id %u", bases_id);
     ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -881,7 +895,7 @@ int zkhip_release_bases(zkhip_ctx* ctx, uint32_t bases_id) {
 int zkhip_msm_range_dev(zkhip_ctx* ctx, uint32_t bases_id, size_t first, const uint64_t* d_scalars, size_t n,
                         uint64_t out_jacobian[12]) {
     if (!ctx || !out_jacobian) return ZKHIP_ERR_INVALID;
-    MsmState& stt = registry()[ctx];
+    MsmState& stt = state_of(ctx);
     auto it = stt.tables.find(bases_id);
     ZK_CHECK(ctx, it != stt.tables.end(), "msm: unknown bases id %u", bases_id);
     ZK_CHECK(ctx, d_scalars || n == 0, "msm: null scalars");
@@ -893,7 +907,7 @@ int zkhip_msm_batch_dev(zkhip_ctx* ctx, uint32_t bases_id, const uint64_t* const
                         uint64_t* out_jacobian) {
     if (!ctx) return ZKHIP_ERR_INVALID;
     ZK_CHECK(ctx, (d_scalars && out_jacobian) || batch == 0, "msm_batch: null pointer");
-    MsmState& stt = registry()[ctx];
+    MsmState& stt = state_of(ctx);
     auto it = stt.tables.find(bases_id);
     ZK_CHECK(ctx, it != stt.tables.end(), "msm: unknown bases id %u", bases_id);
     for (size_t b = 0; b < batch; b++) ZK_CHECK(ctx, d_scalars[b] || n == 0, "msm_batch: null scalars");
