@@ -9,9 +9,9 @@
 //     accumulator for the whole program, so the output is written once instead of once per argument;
 //   * permutation and lookup terms are emitted as instructions following upstream's formulas; their cosets, l0,
 //     l_last, l_active_row and the row's point zeta * extended_omega^idx join the unified column table;
-//   * values get slots by liveness; the slots with the densest use live in LDS ([slot][digit][lane]), the rest spill
-//     to a [slot][digit][row] buffer in HBM.  The launch reserves only the LDS the program needs, so that three
-//     256-lane workgroups share a CU;
+//   * values get slots by liveness; the slots with the densest use stay on chip (slot 0 in registers, the next ones
+//     in LDS as [slot][digit][lane]), the rest spill to a [slot][digit][row] buffer in HBM.  The launch reserves only
+//     the LDS the program needs, so that four 256-lane workgroups share a CU;
 //   * arithmetic runs in the lazy signed-digit form of wide.cuh (nine 29-bit digits, Montgomery radix 2^261): a
 //     multiply-add is one Montgomery product, nine digit additions and a carry pass, with no comparison against p;
 //     the host bounds every value's magnitude while it builds the program and the kernel canonicalises the result.
@@ -85,17 +85,19 @@ __device__ __forceinline__ fe ev_raw(const Opnd& o, uint32_t idx, uint32_t mask)
 }
 // Values are held in the lazy signed-digit form of wide.cuh, 2^261 Montgomery domain, always normalised.  Columns
 // enter through from_fe_shl5 (value up to 32 p); the host tracks magnitudes and keeps every stored value below EV_LIMIT p.
+// Value slots: slot 0 is a register of the lane, slots 1 .. lds_slots-1 live in LDS, the rest in the spill buffer.
 __device__ __forceinline__ fw ev_value(const InterpArgs& a, const Opnd& o, const fe& raw, const int32_t* lds, const fw& acc,
-                                       uint32_t idx) {
+                                       const fw& reg0, uint32_t idx) {
     const uint32_t kind = o.hdr >> 28, pl = o.hdr & 0x0fffffffu;
     switch (kind) {
         case L_ROW: return FrW::from_fe_shl5(raw);
         case L_UNI: return FrW::from_fe(raw);
         case L_SLOT: {
+            if (pl == 0) return reg0;
             fw v;
             if (pl < a.lds_slots) {
 #pragma unroll
-                for (int d = 0; d < 9; d++) v.d[d] = lds[(pl * 9 + d) * EV_THREADS + threadIdx.x];
+                for (int d = 0; d < 9; d++) v.d[d] = lds[((pl - 1) * 9 + d) * EV_THREADS + threadIdx.x];
             } else {
                 const int32_t* base = a.spill + (((size_t)(pl - a.lds_slots) * 9) << a.log_size) + idx;
 #pragma unroll
@@ -124,19 +126,21 @@ __device__ __forceinline__ void ev_stage(Staged& s, prog_ptr w, uint32_t idx, ui
     if (kb == L_ROW || kb == L_UNI) s.rb = ev_raw(s.b, idx, mask);
     if (kc == L_ROW || kc == L_UNI) s.rc = ev_raw(s.c, idx, mask);
 }
-__device__ __forceinline__ void ev_execute(const InterpArgs& a, const Staged& s, int32_t* lds, fw& acc, uint32_t idx) {
+__device__ __forceinline__ void ev_execute(const InterpArgs& a, const Staged& s, int32_t* lds, fw& acc, fw& reg0, uint32_t idx) {
     const uint32_t w0 = s.w0, dst = w0 >> 8;
-    fw t = ev_value(a, s.a, s.ra, lds, acc, idx);
-    if (w0 & F_MUL) t = FrW::mul(t, ev_value(a, s.b, s.rb, lds, acc, idx));
+    fw t = ev_value(a, s.a, s.ra, lds, acc, reg0, idx);
+    if (w0 & F_MUL) t = FrW::mul(t, ev_value(a, s.b, s.rb, lds, acc, reg0, idx));
     if (w0 & (F_ADD | F_SUB)) {
-        const fw c = ev_value(a, s.c, s.rc, lds, acc, idx);
+        const fw c = ev_value(a, s.c, s.rc, lds, acc, reg0, idx);
         t = FrW::norm((w0 & F_ADD) ? FrW::add(t, c) : FrW::sub(t, c));
     }
     if (dst == DST_ACC) {
         acc = t;
+    } else if (dst == 0) {
+        reg0 = t;
     } else if (dst < a.lds_slots) {
 #pragma unroll
-        for (int d = 0; d < 9; d++) lds[(dst * 9 + d) * EV_THREADS + threadIdx.x] = t.d[d];
+        for (int d = 0; d < 9; d++) lds[((dst - 1) * 9 + d) * EV_THREADS + threadIdx.x] = t.d[d];
     } else {
         int32_t* base = a.spill + (((size_t)(dst - a.lds_slots) * 9) << a.log_size) + idx;
 #pragma unroll
@@ -151,7 +155,7 @@ __global__ void __launch_bounds__(EV_THREADS) evalh_interp_kernel(const uint32_t
     const uint32_t idx = blockIdx.x * EV_THREADS + threadIdx.x;
     const uint32_t mask = (1u << a.log_size) - 1;
     if (idx > mask) return;   // domains smaller than one workgroup
-    fw acc = FrW::zero();
+    fw acc = FrW::zero(), reg0 = FrW::zero();
     // software pipeline over EV_DEPTH staging sets: while instruction pc computes, instructions pc + 1 .. pc + EV_DEPTH - 1
     // are already decoded and their column / constant loads are in flight
     Staged st[EV_DEPTH];
@@ -163,14 +167,14 @@ __global__ void __launch_bounds__(EV_THREADS) evalh_interp_kernel(const uint32_t
         for (int j = 0; j < EV_DEPTH; j++) {
             const uint32_t cur = pc + j, ahead = cur + EV_DEPTH - 1;
             if (ahead < a.n_instr) ev_stage(st[(j + EV_DEPTH - 1) % EV_DEPTH], prog + (size_t)ahead * INS_WORDS, idx, mask);
-            if (cur < a.n_instr) ev_execute(a, st[j], lds, acc, idx);
+            if (cur < a.n_instr) ev_execute(a, st[j], lds, acc, reg0, idx);
         }
     }
     // back to the 2^256 domain, canonical
     Opnd ro;
     ro.hdr = a.result_hdr;
     ro.ptr = nullptr;
-    const fw r = ev_value(a, ro, Fr::zero(), lds, acc, idx);
+    const fw r = ev_value(a, ro, Fr::zero(), lds, acc, reg0, idx);
     store_fe(a.out + idx, FrW::to_fe(FrW::mul(r, FrW::r256())));
 }
 
@@ -725,7 +729,7 @@ extern "C" int zkhip_evaluate_h(zkhip_domain* dom, const zkhip_evalh_desc* desc,
     ZK_CHECK(ctx, b.n_virtual < DST_ACC, "evaluate_h: program too large");
 
     // ---- slots, tables, launch -----------------------------------------------------------------------
-    // LDS budget per lane: 5 slots of 36 B (nine digits) keep three 256-lane workgroups on a CU
+    // on-chip budget per lane: one register slot + four LDS slots of 36 B (nine digits): four 256-lane workgroups per CU
     const char* env_slots = getenv("ZKHIP_EVALH_LDS_SLOTS");
     const uint32_t lds_budget = env_slots && *env_slots ? (uint32_t)atoi(env_slots) : 5;
     uint32_t result = W_ACC, lds_slots = 1, n_slots = 1;
@@ -824,7 +828,7 @@ extern "C" int zkhip_evaluate_h(zkhip_domain* dom, const zkhip_evalh_desc* desc,
     }
     a.log_size = ek;
     a.out = d_out;
-    const size_t lds_bytes = (size_t)lds_slots * EV_THREADS * 36;
+    const size_t lds_bytes = (size_t)(lds_slots > 1 ? lds_slots - 1 : 1) * EV_THREADS * 36;
     ZK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(evalh_interp_kernel),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     {
