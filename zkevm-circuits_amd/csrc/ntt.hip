@@ -130,6 +130,7 @@ __global__ void __launch_bounds__(NTT_THREADS) ntt_pass_kernel(const NttPassArgs
 
 // ---- tile kernel -------------------------------------------------------------------------------------
 constexpr uint32_t TILE = 1u << TILE_LOG;
+constexpr uint32_t NTT_BOUNDARY_TABLE_MAX_LOG = 22;   // 128 MiB
 
 struct NttTileArgs {
     const fe* in;
@@ -143,6 +144,7 @@ struct NttTileArgs {
     fe pre[3], post[3];           // 2^261 domain
     uint32_t last;                // final pass: canonical output (after the optional post scaling)
     uint32_t r_next;              // radix of the next pass (for the twiddle applied on store)
+    const fe* b0;                 // non-null: single-lookup twiddles of this pass boundary, indexed by t * (j mod Ns)
     uint32_t nrounds;
     uint32_t pb[3][3];            // round, local bit i -> tile-row bit
     uint32_t sb[3][3];            // the same bits sorted ascending
@@ -304,9 +306,14 @@ __global__ void __launch_bounds__(NTT_THREADS) __attribute__((amdgpu_waves_per_e
         } else {
             // what the next pass multiplies element oi by: t2 = its tile row, j2 = its column
             const uint32_t t2 = oi >> rowShift2, j2 = oi & ((1u << rowShift2) - 1);
-            const uint32_t ex = (t2 * (j2 & ((1u << logNs2) - 1))) << twShift2;
-            v = FrW::mul(v, FrW::from_fe(load_fe(a.lo + (ex & ((1u << a.h) - 1)))));
-            if (ex >> a.h) v = FrW::mul(v, FrW::from_fe(load_fe(a.hi + (ex >> a.h))));
+            const uint32_t prod = t2 * (j2 & ((1u << logNs2) - 1));
+            if (a.b0) {
+                v = FrW::mul(v, FrW::from_fe(load_fe(a.b0 + prod)));
+            } else {
+                const uint32_t ex = prod << twShift2;
+                v = FrW::mul(v, FrW::from_fe(load_fe(a.lo + (ex & ((1u << a.h) - 1)))));
+                if (ex >> a.h) v = FrW::mul(v, FrW::from_fe(load_fe(a.hi + (ex >> a.h))));
+            }
             // v in (-p/100, 1.01 p): v + p is a non-negative residue below 2^256
             fw pp;
 #pragma unroll
@@ -329,6 +336,8 @@ NttPlan::~NttPlan() {
     if (d_hi) (void)hipFree(d_hi);
     if (d_lo_w) (void)hipFree(d_lo_w);
     if (d_hi_w) (void)hipFree(d_hi_w);
+    for (void* t : d_bt)
+        if (t) (void)hipFree(t);
 }
 
 int ntt_plan_create(zkhip_ctx* ctx, uint32_t log_n, const uint64_t omega[4], NttPlan** out) {
@@ -379,6 +388,28 @@ int ntt_plan_create(zkhip_ctx* ctx, uint32_t log_n, const uint64_t omega[4], Ntt
         const uint32_t r = (left + (npass - p) - 1) / (npass - p);
         plan->radix.push_back(r);
         left -= r;
+    }
+    if (log_n >= TILE_LOG) {
+        uint64_t k32[4];
+        memcpy(k32, FrParams::TWO5, 32);
+        uint32_t bits = plan->radix[0];
+        for (uint32_t p = 0; p + 1 < npass; p++) {
+            bits += plan->radix[p + 1];
+            plan->d_bt.push_back(nullptr);
+            if (bits > NTT_BOUNDARY_TABLE_MAX_LOG) continue;
+            const size_t cnt = (size_t)1 << bits;
+            std::vector<uint64_t> bt(cnt * 4);
+            uint64_t step[4];
+            h_pow(HFR, step, omega, (uint64_t)1 << (log_n - bits));
+            h_mul(HFR, &bt[0], HFR.r, k32);                       // one, 2^261 domain
+            for (size_t i = 1; i < cnt; i++) h_mul(HFR, &bt[4 * i], &bt[4 * (i - 1)], step);
+            hipError_t e2 = hipMalloc(&plan->d_bt[p], cnt * 32);
+            if (e2 == hipSuccess) e2 = hipMemcpy(plan->d_bt[p], bt.data(), cnt * 32, hipMemcpyHostToDevice);
+            if (e2 != hipSuccess) {
+                delete plan;
+                return set_error(ctx, ZKHIP_ERR_HIP, "ntt plan upload failed: %s", hipGetErrorString(e2));
+            }
+        }
     }
     *out = plan;
     return ZKHIP_OK;
@@ -447,6 +478,7 @@ int ntt_run(zkhip_ctx* ctx, const NttPlan* plan, const fe* src, size_t src_strid
             }
             a.last = (p == npass - 1);
             a.r_next = a.last ? 0 : plan->radix[p + 1];
+            a.b0 = a.last ? nullptr : (const fe*)plan->d_bt[p];
             ZK_CHECK(ctx, a.r >= 3 && a.r <= 8, "ntt: tile pass radix 2^%u unsupported", a.r);
             a.nrounds = (a.r + 2) / 3;
             for (uint32_t rd = 0; rd < a.nrounds; rd++) {
