@@ -754,6 +754,60 @@ static int check_args(zkhip_ctx* ctx, const MsmTables& tb, size_t first, size_t 
     return ZKHIP_OK;
 }
 
+struct MsmItem {
+    size_t first;
+    const fe* d_scalars;
+    size_t n;
+};
+
+// Up to MSM_PIPE MSMs in flight on internal streams, so that one MSM's latency-bound tail (merge, reduce, host join)
+// overlaps the accumulate phase of the next.  out: one Jacobian point per item.
+static int msm_pipeline(zkhip_ctx* ctx, MsmState& stt, const MsmTables& tb, const std::vector<MsmItem>& items, uint64_t* out,
+                        bool timed) {
+    const size_t batch = items.size();
+    if (!stt.ev_in) {
+        ZK_HIP(ctx, hipEventCreateWithFlags(&stt.ev_in, hipEventDisableTiming));
+        for (int i = 0; i < MSM_PIPE; i++) ZK_HIP(ctx, hipEventCreateWithFlags(&stt.ev_out[i], hipEventDisableTiming));
+    }
+    MsmWorkspace* pipe[MSM_PIPE];
+    for (int i = 0; i < MSM_PIPE; i++) {
+        if (!stt.batch_streams[i]) ZK_HIP(ctx, hipStreamCreateWithFlags(&stt.batch_streams[i], hipStreamNonBlocking));
+        stt.ws[i].stream = stt.batch_streams[i];
+        pipe[i] = &stt.ws[i];
+    }
+    ZK_HIP(ctx, hipEventRecord(stt.ev_in, ctx->stream));
+    for (int i = 0; i < MSM_PIPE; i++) ZK_HIP(ctx, hipStreamWaitEvent(pipe[i]->stream, stt.ev_in, 0));
+    // software pipeline: phase1(j + 2), phase2(j + 1), phase3(j)
+    int rc;
+    for (size_t j = 0; j < batch + 2; j++) {
+        if (j < batch) {
+            MsmWorkspace& ws = *pipe[j % MSM_PIPE];
+            {
+                TimedRegion tr(ctx, timed ? "msm_sort" : nullptr, ws.stream);
+                rc = msm_phase1(ctx, ws, tb, items[j].first, items[j].d_scalars, items[j].n);
+            }
+            if (!rc) {
+                TimedRegion tr(ctx, timed ? "msm_accumulate" : nullptr, ws.stream);
+                rc = msm_accumulate(ctx, ws, tb);
+            }
+            if (rc) return rc;
+        }
+        if (j >= 1 && j - 1 < batch) {
+            rc = msm_phase2(ctx, *pipe[(j - 1) % MSM_PIPE], tb, timed);
+            if (rc) return rc;
+        }
+        if (j >= 2 && j - 2 < batch) {
+            rc = msm_phase3(ctx, *pipe[(j - 2) % MSM_PIPE], out + 12 * (j - 2));
+            if (rc) return rc;
+        }
+    }
+    for (int i = 0; i < MSM_PIPE; i++) {
+        ZK_HIP(ctx, hipEventRecord(stt.ev_out[i], pipe[i]->stream));
+        ZK_HIP(ctx, hipStreamWaitEvent(ctx->stream, stt.ev_out[i], 0));
+    }
+    return ZKHIP_OK;
+}
+
 int msm_run(zkhip_ctx* ctx, MsmState& stt, const MsmTables& tb, size_t first, const fe* d_scalars, size_t n,
             uint64_t out_jacobian[12]) {
     memset(out_jacobian, 0, 96);
@@ -775,46 +829,15 @@ int msm_run(zkhip_ctx* ctx, MsmState& stt, const MsmTables& tb, size_t first, co
     return rc;
 }
 
-// Batch: up to MSM_PIPE MSMs in flight on internal streams, so one MSM's tail overlaps the next one's accumulate phase.
 int msm_run_batch(zkhip_ctx* ctx, MsmState& stt, const MsmTables& tb, const uint64_t* const* d_scalars, size_t batch, size_t n,
                   uint64_t* out) {
     memset(out, 0, batch * 96);
     if (n == 0 || batch == 0) return ZKHIP_OK;
     int rc = check_args(ctx, tb, 0, n);
     if (rc) return rc;
-    if (!stt.ev_in) {
-        ZK_HIP(ctx, hipEventCreateWithFlags(&stt.ev_in, hipEventDisableTiming));
-        for (int i = 0; i < MSM_PIPE; i++) ZK_HIP(ctx, hipEventCreateWithFlags(&stt.ev_out[i], hipEventDisableTiming));
-    }
-    MsmWorkspace* pipe[MSM_PIPE];
-    for (int i = 0; i < MSM_PIPE; i++) {
-        if (!stt.batch_streams[i]) ZK_HIP(ctx, hipStreamCreateWithFlags(&stt.batch_streams[i], hipStreamNonBlocking));
-        stt.ws[i].stream = stt.batch_streams[i];   // slot 0 is rebound to the caller's stream by single MSMs
-        pipe[i] = &stt.ws[i];
-    }
-    ZK_HIP(ctx, hipEventRecord(stt.ev_in, ctx->stream));
-    for (int i = 0; i < MSM_PIPE; i++) ZK_HIP(ctx, hipStreamWaitEvent(pipe[i]->stream, stt.ev_in, 0));
-    // software pipeline: phase1(j + 2), phase2(j + 1), phase3(j)
-    for (size_t j = 0; j < batch + 2; j++) {
-        if (j < batch) {
-            rc = msm_phase1(ctx, *pipe[j % MSM_PIPE], tb, 0, (const fe*)d_scalars[j], n);
-            if (!rc) rc = msm_accumulate(ctx, *pipe[j % MSM_PIPE], tb);
-            if (rc) return rc;
-        }
-        if (j >= 1 && j - 1 < batch) {
-            rc = msm_phase2(ctx, *pipe[(j - 1) % MSM_PIPE], tb, false);
-            if (rc) return rc;
-        }
-        if (j >= 2 && j - 2 < batch) {
-            rc = msm_phase3(ctx, *pipe[(j - 2) % MSM_PIPE], out + 12 * (j - 2));
-            if (rc) return rc;
-        }
-    }
-    for (int i = 0; i < MSM_PIPE; i++) {
-        ZK_HIP(ctx, hipEventRecord(stt.ev_out[i], pipe[i]->stream));
-        ZK_HIP(ctx, hipStreamWaitEvent(ctx->stream, stt.ev_out[i], 0));
-    }
-    return ZKHIP_OK;
+    std::vector<MsmItem> items;
+    for (size_t j = 0; j < batch; j++) items.push_back({0, (const fe*)d_scalars[j], n});
+    return msm_pipeline(ctx, stt, tb, items, out, false);
 }
 
 void msm_drop_ctx(zkhip_ctx* ctx) {
