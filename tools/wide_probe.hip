@@ -96,6 +96,25 @@ __global__ void __launch_bounds__(256) rate_kernel(const fe* in, fe* out, int it
     }
 }
 
+// issue-rate probe: CHAINS independent multiplication chains per lane, launched at one wave per SIMD
+template <int CHAINS>
+__global__ void __launch_bounds__(256) ilp_kernel(const fe* in, fe* out, int iters) {
+    using W = Wide<FqParams>;
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    fw x[CHAINS];
+    const fw y = W::from_fe(in[2 * i + 1]);
+#pragma unroll
+    for (int c = 0; c < CHAINS; c++) { x[c] = W::from_fe(in[2 * i]); x[c].d[0] ^= c; }
+    for (int k = 0; k < iters; k++) {
+#pragma unroll
+        for (int c = 0; c < CHAINS; c++) x[c] = W::mul(x[c], y);
+    }
+    fw r = x[0];
+#pragma unroll
+    for (int c = 1; c < CHAINS; c++) r = W::add(r, x[c]);
+    out[i] = W::to_fe(W::norm(r));
+}
+
 int main() {
     const size_t n = 1 << 16;
     std::vector<fe> h(4 * n);
@@ -152,6 +171,26 @@ int main() {
             if (ms < best) best = ms;
         }
         printf("%s mul chain: %.3f ms, %.1f G mul/s\n", wide ? "wide  " : "packed", best, (double)lanes * iters / best / 1e6);
+    }
+    // one wave per SIMD (256 CUs x 4): how much of the issue rate can a lone wave use, and does ILP help?
+    {
+        const int blocks = 256;
+        for (int chains = 1; chains <= 4; chains *= 2) {
+            float best = 1e30f;
+            for (int rep = 0; rep < 3; rep++) {
+                CK(hipEventRecord(e0));
+                if (chains == 1) ilp_kernel<1><<<blocks, 256>>>(d_rin, d_out, iters);
+                else if (chains == 2) ilp_kernel<2><<<blocks, 256>>>(d_rin, d_out, iters);
+                else ilp_kernel<4><<<blocks, 256>>>(d_rin, d_out, iters);
+                CK(hipEventRecord(e1));
+                CK(hipEventSynchronize(e1));
+                float ms;
+                CK(hipEventElapsedTime(&ms, e0, e1));
+                if (ms < best) best = ms;
+            }
+            printf("one wave per SIMD, %d chain(s): %.3f ms, %.1f G mul/s\n", chains, best,
+                   (double)blocks * 256 * iters * chains / best / 1e6);
+        }
     }
     return (bad_q | bad_r | hb[0] | hb[1]) ? 1 : 0;
 }

@@ -13,9 +13,9 @@ struct NttPlan {
     void* d_lo_w = nullptr;      // the same tables in the 2^261 Montgomery domain (transforms of 2^11 points and more)
     void* d_hi_w = nullptr;
     // twiddles of pass boundary p by one lookup instead of lo * hi: d_bt[p][k] = omega^(k * 2^(log_n - bits_p)) for
-    // k < 2^bits_p, bits_p = r_0 + ... + r_(p+1), 2^261 domain.  Built while 2^bits_p elements stay within
-    // NTT_BOUNDARY_TABLE_MAX (the last boundary of a 2^21 transform is a 64 MiB table: memory is the cheap resource
-    // here, multiplier issue slots are not).
+    // k < 2^bits_p, bits_p = r_0 + ... + r_(p+1), 2^261 domain.  Built up to 2^22 entries (128 MiB; the last boundary
+    // of a 2^21 transform is a 64 MiB table shared by every column of a batch): one product per element saved for
+    // 32 more bytes read.  Null beyond that size.
     std::vector<void*> d_bt;
     std::vector<uint32_t> radix; // log2 radix of each pass
     ~NttPlan();

@@ -13,9 +13,9 @@
 // Transforms of 2^11 points and more use `ntt_tile_kernel` (below); the LDS-per-stage kernel above it serves the
 // small ones.  The tile kernel keeps the same pass / tile / index structure and changes the inside of a pass:
 //   * arithmetic in the lazy signed-digit form of wide.cuh: a butterfly is one Montgomery product and 18 digit
-//     additions, elements are carry-normalised once per three stages, and nothing is compared against p;
-//   * decimation in time on bit-reversed tile rows, three stages at a time in registers: a lane owns eight elements
-//     of one column, so a radix-2^7 pass crosses LDS three times instead of seven;
+//     additions, elements are carry-normalised once per LDS round trip, and nothing is compared against p;
+//   * decimation in time on bit-reversed tile rows, two stages at a time in registers: a lane owns four elements
+//     of one column, so a radix-2^7 pass crosses LDS four times instead of seven;
 //   * the twiddle w_N^(t (j mod Ns) N/(Ns R)) that the NEXT pass would apply while loading is applied by THIS pass
 //     while storing.  That product also pulls the value back into (-p/100, 1.01 p), so adding p gives a non-negative
 //     residue below 2^256 that is stored as is; only the last pass canonicalises.
@@ -130,6 +130,14 @@ __global__ void __launch_bounds__(NTT_THREADS) ntt_pass_kernel(const NttPassArgs
 
 // ---- tile kernel -------------------------------------------------------------------------------------
 constexpr uint32_t TILE = 1u << TILE_LOG;
+// Elements per lane.  Four (two butterfly stages per LDS round trip) instead of eight (three stages) costs one more
+// round trip per radix-2^7 pass and buys twice the waves for the same LDS footprint at 98 VGPRs.  Measured equal for a
+// batch (0.24 ms per 2^21 column) and slightly ahead for a lone transform, whose workgroups start in lockstep and
+// therefore overlap their load / compute / store phases poorly whatever the occupancy.
+constexpr int TK_LOGE = 2;
+constexpr int TK_E = 1 << TK_LOGE;
+constexpr int TK_THREADS = (1 << TILE_LOG) / TK_E;
+constexpr int TK_MAX_ROUNDS = 4;
 constexpr uint32_t NTT_BOUNDARY_TABLE_MAX_LOG = 22;   // 128 MiB
 
 struct NttTileArgs {
@@ -146,9 +154,9 @@ struct NttTileArgs {
     uint32_t r_next;              // radix of the next pass (for the twiddle applied on store)
     const fe* b0;                 // non-null: single-lookup twiddles of this pass boundary, indexed by t * (j mod Ns)
     uint32_t nrounds;
-    uint32_t pb[3][3];            // round, local bit i -> tile-row bit
-    uint32_t sb[3][3];            // the same bits sorted ascending
-    uint32_t nst[3];              // butterfly stages of the round (local bits 0 .. nst-1)
+    uint32_t pb[TK_MAX_ROUNDS][TK_LOGE];   // round, local bit i -> tile-row bit
+    uint32_t sb[TK_MAX_ROUNDS][TK_LOGE];   // the same bits sorted ascending
+    uint32_t nst[TK_MAX_ROUNDS];           // butterfly stages of the round (local bits 0 .. nst-1)
     size_t in_stride, out_stride;
 };
 
@@ -173,10 +181,27 @@ __device__ __forceinline__ fw balance_digits(const fw& v) {
     o.d[8] = v.d[8] + c;
     return o;
 }
-__device__ __forceinline__ uint32_t spread_bits(uint32_t g, const uint32_t sb[3]) {
+__device__ __forceinline__ uint32_t spread_bits(uint32_t g, const uint32_t sb[TK_LOGE]) {
 #pragma unroll
-    for (int i = 0; i < 3; i++) g = ((g >> sb[i]) << (sb[i] + 1)) | (g & ((1u << sb[i]) - 1));
+    for (int i = 0; i < TK_LOGE; i++) g = ((g >> sb[i]) << (sb[i] + 1)) | (g & ((1u << sb[i]) - 1));
     return g;
+}
+// Word index of tile element (row p, column c) inside one digit plane.  Rows are J words long, so without help a
+// wave that walks rows in steps of the register-group size or reads one column down the rows (the transposed
+// store of the first pass) lands in a quarter or a single one of the 64 banks.  Within every aligned 64-word line the
+// index is XORed with bits of the line number: the high bits of the swizzle move the lane groups of one wave to
+// different bank quarters, the low bits permute the columns differently in each line.  A bijection inside each
+// line, so the plane stays dense.
+__device__ __forceinline__ uint32_t tile_at(uint32_t p, uint32_t c, uint32_t logJ) {
+    const uint32_t w = (p << logJ) + c, u = w >> 6;
+    uint32_t swz;
+    if (logJ >= 6) {
+        swz = u & 63;
+    } else {
+        const uint32_t nb = 6 - logJ;                        // row bits inside the bank index
+        swz = (((u >> (3 - nb)) & ((1u << nb) - 1)) << logJ) | (u & ((1u << logJ) - 1));
+    }
+    return (u << 6) | ((w & 63) ^ swz);
 }
 __device__ __forceinline__ fw lds_get(const int32_t* x, uint32_t at) {
     fw v;
@@ -195,18 +220,18 @@ __device__ __forceinline__ fw tw_get(const int32_t* tw, uint32_t half_r, uint32_
     return v;
 }
 
-// Butterfly stages of one round on the eight elements of a lane.  e[m] sits in tile row pos[m]; local bit i is tile-row
-// bit 3 * round + i.  FIRST: the round of stages 0..2, whose twiddle indices depend on m only (1, w_4, w_8, w_8^3).
+// Butterfly stages of one round on the TK_E elements of a lane.  e[m] sits in tile row pos[m]; local bit i is tile-row
+// bit TK_LOGE * round + i.  FIRST: the round of the lowest stages, whose twiddle indices depend on m only.
 template <bool FIRST>
-__device__ __forceinline__ void tile_stages(fw e[8], const uint32_t pos[8], uint32_t round, uint32_t nst, uint32_t r,
+__device__ __forceinline__ void tile_stages(fw e[TK_E], const uint32_t pos[TK_E], uint32_t round, uint32_t nst, uint32_t r,
                                             const int32_t* tw) {
     const uint32_t half_r = 1u << (r - 1);
 #pragma unroll
-    for (int i = 0; i < 3; i++) {
+    for (int i = 0; i < TK_LOGE; i++) {
         if ((uint32_t)i >= nst) break;
-        const uint32_t s = 3 * round + i;
+        const uint32_t s = TK_LOGE * round + i;
 #pragma unroll
-        for (int m = 0; m < 8; m++) {
+        for (int m = 0; m < TK_E; m++) {
             if (m & (1 << i)) continue;
             const int mb = m + (1 << i);
             fw t;
@@ -224,7 +249,7 @@ __device__ __forceinline__ void tile_stages(fw e[8], const uint32_t pos[8], uint
     }
 }
 
-__global__ void __launch_bounds__(NTT_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2))) ntt_tile_kernel(const NttTileArgs a) {
+__global__ void __launch_bounds__(TK_THREADS) ntt_tile_kernel(const NttTileArgs a) {
     extern __shared__ __align__(16) unsigned char smem_raw[];
     int32_t* x = reinterpret_cast<int32_t*>(smem_raw);       // [9][R][J]
     const uint32_t R = 1u << a.r, J = 1u << a.logJ, N = 1u << a.logN;
@@ -234,24 +259,24 @@ __global__ void __launch_bounds__(NTT_THREADS) __attribute__((amdgpu_waves_per_e
     const fe* in = a.in + (size_t)blockIdx.y * a.in_stride;
     fe* out = a.out + (size_t)blockIdx.y * a.out_stride;
     const uint32_t rowStride = N >> a.r;
-    const uint32_t c = tid & (J - 1), grp = tid >> a.logJ;   // R / 8 groups of eight rows per column
+    const uint32_t c = tid & (J - 1), grp = tid >> a.logJ;   // R / TK_E groups of TK_E rows per column
     const uint32_t j = j0 + c;
 
     // tile-local twiddles w_R^k = w_N^(k N/R), balanced digits
-    for (uint32_t k = tid; k < (R >> 1); k += NTT_THREADS) {
+    for (uint32_t k = tid; k < (R >> 1); k += TK_THREADS) {
         const fw w = balance_digits(omega_pow_w(a, k << (a.logN - a.r)));
 #pragma unroll
         for (int d = 0; d < 9; d++) tw[d * (R >> 1) + k] = w.d[d];
     }
 
-    fw e[8];
-    uint32_t pos[8];
+    fw e[TK_E];
+    uint32_t pos[TK_E];
     // round 0: rows come straight from memory; row p of the tile holds input row bitrev(p)
     {
         const uint32_t base = spread_bits(grp, a.sb[0]);
 #pragma unroll
-        for (int m = 0; m < 8; m++) {
-            pos[m] = base | (uint32_t)m;                       // round 0 always owns row bits 0, 1, 2
+        for (int m = 0; m < TK_E; m++) {
+            pos[m] = base | (uint32_t)m;                       // round 0 always owns the lowest row bits
             const uint32_t t = bitrev(pos[m], a.r);
             const uint32_t gi = j + t * rowStride;
             if (gi < a.n_in) {
@@ -268,21 +293,25 @@ __global__ void __launch_bounds__(NTT_THREADS) __attribute__((amdgpu_waves_per_e
     __syncthreads();   // twiddle table
     tile_stages<true>(e, pos, 0, a.nst[0], a.r, tw);
 #pragma unroll
-    for (int m = 0; m < 8; m++) lds_put(x, (pos[m] << a.logJ) + c, e[m]);
+    for (int m = 0; m < TK_E; m++) lds_put(x, tile_at(pos[m], c, a.logJ), e[m]);
     __syncthreads();
     // (constant round indices: indexing the by-value argument block with a loop variable would move it to scratch)
 #pragma unroll
-    for (int rd = 1; rd < 3; rd++) {
+    for (int rd = 1; rd < TK_MAX_ROUNDS; rd++) {
         if ((uint32_t)rd >= a.nrounds) break;
         const uint32_t base = spread_bits(grp, a.sb[rd]);
+        uint32_t at[TK_E];
 #pragma unroll
-        for (int m = 0; m < 8; m++) {
-            pos[m] = base | ((m & 1) << a.pb[rd][0]) | (((m >> 1) & 1) << a.pb[rd][1]) | (((m >> 2) & 1) << a.pb[rd][2]);
-            e[m] = FrW::norm(lds_get(x, (pos[m] << a.logJ) + c));
+        for (int m = 0; m < TK_E; m++) {
+            pos[m] = base;
+#pragma unroll
+            for (int i = 0; i < TK_LOGE; i++) pos[m] |= (uint32_t)((m >> i) & 1) << a.pb[rd][i];
+            at[m] = tile_at(pos[m], c, a.logJ);
+            e[m] = FrW::norm(lds_get(x, at[m]));
         }
         tile_stages<false>(e, pos, rd, a.nst[rd], a.r, tw);
 #pragma unroll
-        for (int m = 0; m < 8; m++) lds_put(x, (pos[m] << a.logJ) + c, e[m]);
+        for (int m = 0; m < TK_E; m++) lds_put(x, at[m], e[m]);
         __syncthreads();
     }
 
@@ -291,35 +320,59 @@ __global__ void __launch_bounds__(NTT_THREADS) __attribute__((amdgpu_waves_per_e
     const uint32_t logNs2 = a.logNs + a.r;                       // the next pass sees Ns * R
     const uint32_t rowShift2 = a.logN - a.r_next;                // log2 of its row stride
     const uint32_t twShift2 = a.last ? 0 : a.logN - logNs2 - a.r_next;
-    for (uint32_t idx = tid; idx < TILE; idx += NTT_THREADS) {
-        uint32_t cc, q;
+    auto place = [&](uint32_t idx, uint32_t& q, uint32_t& cc) -> uint32_t {
         if (a.logNs == 0) { q = idx & (R - 1); cc = idx >> a.r; }     // outputs of one j are contiguous
         else { cc = idx & (J - 1); q = idx >> a.logJ; }
         const uint32_t jj = j0 + cc;
-        const uint32_t oi = ((jj >> a.logNs) << (a.logNs + a.r)) + (jj & nsMask) + (q << a.logNs);
-        if (oi >= a.n_out) continue;
-        fw v = FrW::norm(lds_get(x, (q << a.logJ) + cc));
-        if (a.last) {
+        return ((jj >> a.logNs) << (a.logNs + a.r)) + (jj & nsMask) + (q << a.logNs);
+    };
+    if (a.last) {
+        for (uint32_t idx = tid; idx < TILE; idx += TK_THREADS) {
+            uint32_t cc, q;
+            const uint32_t oi = place(idx, q, cc);
+            if (oi >= a.n_out) continue;
+            fw v = FrW::norm(lds_get(x, tile_at(q, cc, a.logJ)));
             if (a.post_mode == 1) v = FrW::mul(v, FrW::from_fe(a.post[0]));
             else if (a.post_mode == 2) v = FrW::mul(v, FrW::from_fe(a.post[oi % 3]));
             store_fe(out + oi, FrW::to_fe(v));
-        } else {
-            // what the next pass multiplies element oi by: t2 = its tile row, j2 = its column
-            const uint32_t t2 = oi >> rowShift2, j2 = oi & ((1u << rowShift2) - 1);
-            const uint32_t prod = t2 * (j2 & ((1u << logNs2) - 1));
-            if (a.b0) {
-                v = FrW::mul(v, FrW::from_fe(load_fe(a.b0 + prod)));
-            } else {
-                const uint32_t ex = prod << twShift2;
-                v = FrW::mul(v, FrW::from_fe(load_fe(a.lo + (ex & ((1u << a.h) - 1)))));
-                if (ex >> a.h) v = FrW::mul(v, FrW::from_fe(load_fe(a.hi + (ex >> a.h))));
-            }
-            // v in (-p/100, 1.01 p): v + p is a non-negative residue below 2^256
-            fw pp;
-#pragma unroll
-            for (int d = 0; d < 9; d++) pp.d[d] = (int32_t)FrParams::P29[d];
-            store_fe(out + oi, FrW::pack_nonneg(FrW::norm(FrW::add(v, pp))));
         }
+        return;
+    }
+    // not the last pass (every output is stored): multiply by what the next pass would apply to element oi while
+    // loading it (t2 = its tile row, j2 = its column).  The twiddle reads of the next element are issued before this
+    // element's products, so their latency is covered even with two waves per SIMD.
+    auto twiddle_reads = [&](uint32_t oi, fe& ra, fe& rb) -> bool {
+        const uint32_t t2 = oi >> rowShift2, j2 = oi & ((1u << rowShift2) - 1);
+        const uint32_t prod = t2 * (j2 & ((1u << logNs2) - 1));
+        if (a.b0) {
+            ra = load_fe(a.b0 + prod);
+            return false;
+        }
+        const uint32_t ex = prod << twShift2;
+        ra = load_fe(a.lo + (ex & ((1u << a.h) - 1)));
+        if (ex >> a.h) rb = load_fe(a.hi + (ex >> a.h));
+        return (ex >> a.h) != 0;
+    };
+    fw pp;
+#pragma unroll
+    for (int d = 0; d < 9; d++) pp.d[d] = (int32_t)FrParams::P29[d];
+    uint32_t q, cc;
+    uint32_t oi = place(tid, q, cc);
+    fe ra, rb;
+    bool two = twiddle_reads(oi, ra, rb);
+    for (uint32_t idx = tid; idx < TILE; idx += TK_THREADS) {
+        const uint32_t cur_oi = oi, cur_q = q, cur_cc = cc;
+        const fe ca = ra, cb = rb;
+        const bool cur_two = two;
+        if (idx + TK_THREADS < TILE) {
+            oi = place(idx + TK_THREADS, q, cc);
+            two = twiddle_reads(oi, ra, rb);
+        }
+        fw v = FrW::norm(lds_get(x, tile_at(cur_q, cur_cc, a.logJ)));
+        v = FrW::mul(v, FrW::from_fe(ca));
+        if (cur_two) v = FrW::mul(v, FrW::from_fe(cb));
+        // v in (-p/100, 1.01 p): v + p is a non-negative residue below 2^256
+        store_fe(out + cur_oi, FrW::pack_nonneg(FrW::norm(FrW::add(v, pp))));
     }
 }
 
@@ -480,19 +533,19 @@ int ntt_run(zkhip_ctx* ctx, const NttPlan* plan, const fe* src, size_t src_strid
             a.r_next = a.last ? 0 : plan->radix[p + 1];
             a.b0 = a.last ? nullptr : (const fe*)plan->d_bt[p];
             ZK_CHECK(ctx, a.r >= 3 && a.r <= 8, "ntt: tile pass radix 2^%u unsupported", a.r);
-            a.nrounds = (a.r + 2) / 3;
+            a.nrounds = (a.r + TK_LOGE - 1) / TK_LOGE;
             for (uint32_t rd = 0; rd < a.nrounds; rd++) {
-                const uint32_t nst = std::min(3u, a.r - 3 * rd);
+                const uint32_t nst = std::min<uint32_t>(TK_LOGE, a.r - TK_LOGE * rd);
                 a.nst[rd] = nst;
-                uint32_t filler = 0;   // lowest tile-row bits ride along when a round has fewer than three stages
-                for (uint32_t i = 0; i < 3; i++) a.pb[rd][i] = (i < nst) ? 3 * rd + i : filler++;
-                uint32_t sorted[3] = {a.pb[rd][0], a.pb[rd][1], a.pb[rd][2]};
-                std::sort(sorted, sorted + 3);
+                uint32_t filler = 0;   // lowest tile-row bits ride along when a round has fewer stages than local bits
+                uint32_t sorted[TK_LOGE];
+                for (uint32_t i = 0; i < TK_LOGE; i++) sorted[i] = a.pb[rd][i] = (i < nst) ? TK_LOGE * rd + i : filler++;
+                std::sort(sorted, sorted + TK_LOGE);
                 memcpy(a.sb[rd], sorted, sizeof sorted);
             }
             const size_t lds = (9 * (size_t)TILE + 9 * ((size_t)1 << (a.r - 1))) * sizeof(int32_t);
             dim3 grid((uint32_t)(N >> TILE_LOG), (uint32_t)batch);
-            hipLaunchKernelGGL(ntt_tile_kernel, grid, dim3(NTT_THREADS), lds, ctx->stream, a);
+            hipLaunchKernelGGL(ntt_tile_kernel, grid, dim3(TK_THREADS), lds, ctx->stream, a);
             ZK_HIP(ctx, hipGetLastError());
             logNs += a.r;
         }
