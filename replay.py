@@ -1,0 +1,236 @@
+#!/usr/bin/env python3
+"""Replay of the polynomial pipeline of one `create_proof` call on one MI355X.
+
+The reference's SuperCircuit cannot be instantiated here (its halo2 fork and a Rust toolchain are absent), so this
+script runs the *operator multiset* that `create_proof` issues for a constraint system of a given shape, on synthetic
+columns, in upstream's phase order:
+
+  1. advice:        commit_lagrange (MSM) and lagrange_to_coeff (iNTT) for every advice column
+  2. lookups:       per lookup two commitments of the permuted columns, the grand product z and its commitment,
+                    three iNTTs   (the host-side sort that builds the permuted columns is NOT replayed)
+  3. permutation:   per column set the grand product z, its commitment and iNTT
+  4. quotient:      coeff_to_extended of every advice / instance / lookup polynomial, evaluate_h,
+                    divide_by_vanishing_poly, extended_to_coeff, commitments of the d-1 pieces of h
+  5. openings:      eval_polynomial for every (polynomial, rotation) query, two MSMs for SHPLONK
+                    (the SHPLONK polynomial arithmetic between them is NOT replayed)
+
+Witness generation, transcript hashing and the RNG stay on the host in the reference and are not part of this number.
+The default shape is the estimate for the k = 19 SuperCircuit (standard feature set): about 380 advice and 60 fixed
+columns, one instance column, about 200 lookup arguments, 12 permutation columns, constraint degree 9 (extended
+domain 8n).  Prints one JSON line with per-phase seconds.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+import zkhip_pkg  # noqa: E402
+
+zk = zkhip_pkg.load()
+from zkevm_circuits_amd import evalh_host, ffi, synthetic  # noqa: E402
+
+
+def rand_fr_device(n, gen):
+    t = torch.randint(-(1 << 63), (1 << 63) - 1, (n, 4), dtype=torch.int64, device="cuda", generator=gen)
+    t[:, 3] &= 0x0FFFFFFFFFFFFFFF
+    return t
+
+
+class Phases:
+    def __init__(self, ctx):
+        self.ctx, self.t = ctx, {}
+
+    def run(self, name, fn):
+        torch.cuda.synchronize()
+        self.ctx.sync()
+        t0 = time.perf_counter()
+        out = fn()
+        torch.cuda.synchronize()
+        self.ctx.sync()
+        self.t[name] = self.t.get(name, 0.0) + time.perf_counter() - t0
+        return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--k", type=int, default=19)
+    ap.add_argument("--advice", type=int, default=380)
+    ap.add_argument("--fixed", type=int, default=60)
+    ap.add_argument("--lookups", type=int, default=200)
+    ap.add_argument("--lookup-width", type=int, default=4)
+    ap.add_argument("--perm-cols", type=int, default=12)
+    ap.add_argument("--degree", type=int, default=9)
+    ap.add_argument("--gate-polys", type=int, default=3000)
+    args = ap.parse_args()
+
+    torch.cuda.set_device(0)
+    ctx = zk.Context(0)
+    stream = torch.cuda.Stream()
+    ctx.set_stream(stream.cuda_stream)
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(20250523)
+    k, n = args.k, 1 << args.k
+
+    t_host0 = time.perf_counter()
+    cs = synthetic.synthetic_cs(num_advice=args.advice, num_fixed=args.fixed, num_instance=1,
+                                num_gate_polys=args.gate_polys, max_degree=args.degree, rotations=(-5, -2, -1, 0, 1),
+                                num_lookups=args.lookups, lookup_width=args.lookup_width, num_perm_cols=args.perm_cols)
+    d = cs.degree()
+    dom = zk.Domain(ctx, d, k)
+    en, ek = dom.extended_len, dom.extended_k
+    call = evalh_host.EvalhCall(cs)
+    host_setup_s = time.perf_counter() - t_host0
+
+    A, F, I, L = cs.num_advice_columns, cs.num_fixed_columns, cs.num_instance_columns, len(cs.lookups)
+    sets = cs.num_permutation_sets()
+    bases = ctx.g1_multiples(n)
+    bid = ctx.register_bases(bases)            # stands for both `g` and `g_lagrange`: same size, same kernels
+
+    with torch.cuda.stream(stream):
+        # Lagrange-basis witness columns (n rows each), one tensor per group
+        advice = rand_fr_device(A * n, gen)
+        instance = rand_fr_device(I * n, gen)
+        lk_cols = rand_fr_device(L * 4 * n, gen)        # per lookup: compressed input, compressed table, a', s'
+        lk_z = torch.empty((L * n, 4), dtype=torch.int64, device="cuda")
+        perm_z = torch.empty((sets * n, 4), dtype=torch.int64, device="cuda")
+        sigma_lagrange = rand_fr_device(len(cs.permutation_columns) * n, gen)
+        # proving-key cosets
+        fixed_ext = rand_fr_device(F * en, gen)
+        sigma_ext = rand_fr_device(len(cs.permutation_columns) * en, gen)
+        l_ext = rand_fr_device(3 * en, gen)
+        # extended cosets produced in phase 4
+        n_ext_cols = A + I + 3 * L + sets
+        ext = torch.empty((n_ext_cols * en, 4), dtype=torch.int64, device="cuda")
+        h = torch.empty((en, 4), dtype=torch.int64, device="cuda")
+        h_coeff = torch.empty((n * dom.quotient_poly_degree, 4), dtype=torch.int64, device="cuda")
+    stream.synchronize()
+    sc = rand_fr_device(8, gen).cpu().numpy().view(np.uint64)
+    beta, gamma, theta, y, x = sc[0], sc[1], sc[2], sc[3], sc[4]
+
+    def colptr(t, i, rows):
+        return t.data_ptr() + i * rows * 32
+
+    ph = Phases(ctx)
+    CH = 64   # columns per batched call
+
+    def batched(fn, total):
+        for s in range(0, total, CH):
+            fn(s, min(CH, total - s))
+
+    # ---- 1. advice --------------------------------------------------------------------------------------
+    ph.run("advice_commit_msm", lambda: batched(
+        lambda s, c: ctx.msm_batch_dev(bid, [colptr(advice, s + i, n) for i in range(c)], n), A))
+    ph.run("advice_lagrange_to_coeff", lambda: batched(lambda s, c: dom.lagrange_to_coeff_dev(colptr(advice, s, n), c), A))
+    dom.lagrange_to_coeff_dev(instance.data_ptr(), I)
+
+    # ---- 2. lookups -------------------------------------------------------------------------------------
+    # commitments of a' and s' (2L MSMs), then z from (input, table, a', s') and its commitment, then 3L iNTTs
+    ph.run("lookup_commit_msm", lambda: batched(
+        lambda s, c: ctx.msm_batch_dev(bid, [colptr(lk_cols, 4 * (s + i) + 2 + j, n) for i in range(c) for j in range(2)], n), L))
+
+    def lookup_products():
+        for i in range(L):
+            dom.lookup_product_dev(colptr(lk_cols, 4 * i, n), colptr(lk_cols, 4 * i + 1, n), colptr(lk_cols, 4 * i + 2, n),
+                                   colptr(lk_cols, 4 * i + 3, n), beta, gamma, colptr(lk_z, i, n))
+    ph.run("lookup_grand_product", lookup_products)
+    ph.run("lookup_commit_msm", lambda: batched(
+        lambda s, c: ctx.msm_batch_dev(bid, [colptr(lk_z, s + i, n) for i in range(c)], n), L))
+
+    def lookup_intt():
+        batched(lambda s, c: dom.lagrange_to_coeff_dev(colptr(lk_z, s, n), c), L)
+        for i in range(L):   # a' and s' sit at stride 4 in lk_cols: two single-column calls per lookup
+            dom.lagrange_to_coeff_dev(colptr(lk_cols, 4 * i + 2, n), 2)
+    ph.run("lookup_lagrange_to_coeff", lookup_intt)
+
+    # ---- 3. permutation ---------------------------------------------------------------------------------
+    chunk = cs.permutation_chunk_len()
+    pcols = cs.permutation_columns
+    one = np.array([0xac96341c4ffffffb, 0x36fc76959f60cd29, 0x666ea36f7879462e, 0x0e0a77c19a07df2f], dtype=np.uint64)  # R mod r
+
+    def perm_products():
+        for s in range(sets):
+            c0, c1 = s * chunk, min((s + 1) * chunk, len(pcols))
+            vals = [colptr(advice, (c % A), n) for c in range(c0, c1)]     # stand-in column values
+            sigs = [colptr(sigma_lagrange, c, n) for c in range(c0, c1)]
+            dom.permutation_product_dev(vals, sigs, beta, gamma, one, one, colptr(perm_z, s, n))
+    ph.run("permutation_grand_product", perm_products)
+    ph.run("permutation_commit_msm", lambda: ctx.msm_batch_dev(bid, [colptr(perm_z, s, n) for s in range(sets)], n))
+    ph.run("permutation_lagrange_to_coeff", lambda: dom.lagrange_to_coeff_dev(perm_z.data_ptr(), sets))
+    ph.run("random_poly_commit_msm", lambda: ctx.msm_range_dev(bid, 0, colptr(advice, 0, n), n))
+
+    # ---- 4. quotient ------------------------------------------------------------------------------------
+    # coefficient polynomials -> extended cosets (advice | instance | per lookup z, a', s' | perm z)
+    def extend_all():
+        o = 0
+        batched(lambda s, c: dom.coeff_to_extended_dev(colptr(advice, s, n), colptr(ext, o + s, en), c), A)
+        o += A
+        dom.coeff_to_extended_dev(instance.data_ptr(), colptr(ext, o, en), I)
+        o += I
+        for i in range(L):
+            dom.coeff_to_extended_dev(colptr(lk_z, i, n), colptr(ext, o + 3 * i, en), 1)
+            dom.coeff_to_extended_dev(colptr(lk_cols, 4 * i + 2, n), colptr(ext, o + 3 * i + 1, en), 2)
+        o += 3 * L
+        dom.coeff_to_extended_dev(perm_z.data_ptr(), colptr(ext, o, en), sets)
+    ph.run("coeff_to_extended", extend_all)
+
+    call.fixed = [colptr(fixed_ext, i, en) for i in range(F)]
+    call.advice = [colptr(ext, i, en) for i in range(A)]
+    call.instance = [colptr(ext, A + i, en) for i in range(I)]
+    call.challenges = rand_fr_device(cs.num_challenges, gen).cpu().numpy().view(np.uint64)
+    call.y, call.beta, call.gamma, call.theta = y, beta, gamma, theta
+    call.l0, call.l_last, call.l_active = (colptr(l_ext, i, en) for i in range(3))
+    o = A + I
+    call.lookups = [(colptr(ext, o + 3 * i, en), colptr(ext, o + 3 * i + 1, en), colptr(ext, o + 3 * i + 2, en)) for i in range(L)]
+    call.perm_sigma = [colptr(sigma_ext, c, en) for c in range(len(pcols))]
+    call.perm_z = [colptr(ext, o + 3 * L + s, en) for s in range(sets)]
+    t0 = time.perf_counter()
+    desc = call.build(ffi.MEM_DEVICE, ffi.FORM_EXTENDED)
+    host_setup_s += time.perf_counter() - t0
+    ctx.timing_enable(True)
+    ctx.timing_reset()
+    ph.run("evaluate_h", lambda: dom.evaluate_h(desc, h.data_ptr()))
+    evalh_kernel_ms = ctx.timing_get("evalh")[0] / 1e3
+    ctx.timing_enable(False)
+    ph.run("divide_by_vanishing_poly", lambda: dom.divide_by_vanishing_poly_dev(h.data_ptr()))
+    ph.run("extended_to_coeff", lambda: dom.extended_to_coeff_dev(h.data_ptr(), h_coeff.data_ptr()))
+    pieces = dom.quotient_poly_degree
+    ph.run("h_commit_msm", lambda: ctx.msm_batch_dev(bid, [colptr(h_coeff, i, n) for i in range(pieces)], n))
+
+    # ---- 5. openings ------------------------------------------------------------------------------------
+    # one eval_polynomial per (polynomial, rotation) query: advice / fixed queries of the gates, 5 per lookup
+    # (z, z(omega x), a', a'(omega^-1 x), s'), 3 per permutation set, h pieces, plus the fixed / sigma polynomials
+    n_queries = 2 * A + F + 5 * L + 3 * sets + len(pcols) + pieces   # about two rotations per advice column
+
+    def openings():
+        for q in range(n_queries):
+            ctx.eval_polynomial_dev(colptr(advice, q % A, n), n, x)
+    ph.run("eval_polynomial", openings)
+    ph.run("shplonk_msm", lambda: ctx.msm_batch_dev(bid, [colptr(advice, 0, n), colptr(advice, 1, n)], n))
+
+    total = sum(ph.t.values())
+    msm_s = sum(v for kk, v in ph.t.items() if kk.endswith("_msm"))
+    n_msm = A + 3 * L + sets + 1 + pieces + 2
+    line = {
+        "what": "replay of the create_proof polynomial pipeline on synthetic columns (one MI355X); host-side witness "
+                "generation, lookup sorting, transcript and SHPLONK polynomial arithmetic are not included",
+        "shape": {"k": k, "extended_k": ek, "advice": A, "fixed": F, "instance": I, "lookups": L,
+                  "lookup_width": args.lookup_width, "permutation_columns": len(pcols), "permutation_sets": sets,
+                  "degree": d, "gate_polynomials": args.gate_polys},
+        "total_s": total, "phases_s": ph.t, "msm_count": n_msm, "msm_total_s": msm_s, "msm_ms_each": msm_s / n_msm * 1e3,
+        "coset_ntt_count": A + I + 3 * L + sets, "evalh_kernel_ms": evalh_kernel_ms, "eval_polynomial_count": n_queries,
+        "host_program_build_s": host_setup_s,
+        "device_memory_GB": torch.cuda.max_memory_allocated() / 1e9,
+    }
+    print(json.dumps(line))
+    ctx.release_bases(bid)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,5 +1,6 @@
 """GPU suite: the HIP path, called through the C ABI, against the golden vectors, the C oracle on seeded inputs, and
 size-independent properties at the benchmark's full sizes.  Bit-exact everywhere (integer arithmetic)."""
+import os
 import numpy as np
 import pytest
 
@@ -512,3 +513,16 @@ def test_grand_products_golden(ctx):
         d_c = ctx.upload(co_)
         assert np.array_equal(ctx.eval_polynomial_dev(d_c, len(co_), hex_fr([c["x"]])[0]), hex_fr([c["value"]])[0])
         ctx.free(d_c)
+
+
+def test_replay_script_small_shape(ctx, capsys, monkeypatch):
+    """replay.py (the create_proof operator multiset) runs end to end on a small shape and reports every phase"""
+    import json
+    import runpy
+    import sys
+    monkeypatch.setattr(sys, "argv", ["replay.py", "--k", "10", "--advice", "9", "--fixed", "4", "--lookups", "3",
+                                      "--gate-polys", "20", "--degree", "5", "--perm-cols", "5"])
+    runpy.run_path(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "replay.py"), run_name="__main__")
+    line = json.loads(capsys.readouterr().out.strip().splitlines()[-1])
+    assert line["msm_count"] == 9 + 3 * 3 + line["shape"]["permutation_sets"] + 1 + 4 + 2
+    assert {"evaluate_h", "coeff_to_extended", "advice_commit_msm", "eval_polynomial"} <= set(line["phases_s"])
