@@ -176,7 +176,7 @@ def test_domain_golden(ctx):
         d.close()
 
 
-@pytest.mark.parametrize("j,k", [(5, 12), (9, 11), (3, 13), (4, 10)])
+@pytest.mark.parametrize("j,k", [(5, 12), (9, 11), (3, 13), (4, 10), (12, 9), (17, 10)])
 def test_domain_vs_oracle_batched(ctx, co, j, k):
     rng = np.random.default_rng(j * 100 + k)
     d, od = zk.Domain(ctx, j, k), co.Domain(j, k, threads=8)

@@ -153,6 +153,7 @@ struct NttTileArgs {
     uint32_t last;                // final pass: canonical output (after the optional post scaling)
     uint32_t r_next;              // radix of the next pass (for the twiddle applied on store)
     const fe* b0;                 // non-null: single-lookup twiddles of this pass boundary, indexed by t * (j mod Ns)
+    uint32_t zskip;               // first pass of a zero-padded transform: n_in = N >> zskip (0 otherwise)
     uint32_t nrounds;
     uint32_t pb[TK_MAX_ROUNDS][TK_LOGE];   // round, local bit i -> tile-row bit
     uint32_t sb[TK_MAX_ROUNDS][TK_LOGE];   // the same bits sorted ascending
@@ -222,9 +223,11 @@ __device__ __forceinline__ fw tw_get(const int32_t* tw, uint32_t half_r, uint32_
 
 // Butterfly stages of one round on the TK_E elements of a lane.  e[m] sits in tile row pos[m]; local bit i is tile-row
 // bit TK_LOGE * round + i.  FIRST: the round of the lowest stages, whose twiddle indices depend on m only.
+// zskip: stages below it see a zero partner (zero-padded input: tile rows >= R >> zskip are zero, i.e. every position
+// with one of its low zskip bits set), so the butterfly degenerates to a copy.
 template <bool FIRST>
 __device__ __forceinline__ void tile_stages(fw e[TK_E], const uint32_t pos[TK_E], uint32_t round, uint32_t nst, uint32_t r,
-                                            const int32_t* tw) {
+                                            uint32_t zskip, const int32_t* tw) {
     const uint32_t half_r = 1u << (r - 1);
 #pragma unroll
     for (int i = 0; i < TK_LOGE; i++) {
@@ -234,6 +237,10 @@ __device__ __forceinline__ void tile_stages(fw e[TK_E], const uint32_t pos[TK_E]
         for (int m = 0; m < TK_E; m++) {
             if (m & (1 << i)) continue;
             const int mb = m + (1 << i);
+            if (s < zskip) {
+                e[mb] = e[m];
+                continue;
+            }
             fw t;
             if (FIRST) {
                 const uint32_t km = (uint32_t)m & ((1u << i) - 1);   // compile-time
@@ -291,7 +298,7 @@ __global__ void __launch_bounds__(TK_THREADS) ntt_tile_kernel(const NttTileArgs 
         }
     }
     __syncthreads();   // twiddle table
-    tile_stages<true>(e, pos, 0, a.nst[0], a.r, tw);
+    tile_stages<true>(e, pos, 0, a.nst[0], a.r, a.zskip, tw);
 #pragma unroll
     for (int m = 0; m < TK_E; m++) lds_put(x, tile_at(pos[m], c, a.logJ), e[m]);
     __syncthreads();
@@ -309,7 +316,7 @@ __global__ void __launch_bounds__(TK_THREADS) ntt_tile_kernel(const NttTileArgs 
             at[m] = tile_at(pos[m], c, a.logJ);
             e[m] = FrW::norm(lds_get(x, at[m]));
         }
-        tile_stages<false>(e, pos, rd, a.nst[rd], a.r, tw);
+        tile_stages<false>(e, pos, rd, a.nst[rd], a.r, a.zskip, tw);
 #pragma unroll
         for (int m = 0; m < TK_E; m++) lds_put(x, at[m], e[m]);
         __syncthreads();
@@ -530,6 +537,12 @@ int ntt_run(zkhip_ctx* ctx, const NttPlan* plan, const fe* src, size_t src_strid
                 h_mul(HFR, (uint64_t*)a.post[q].l, (const uint64_t*)fuse.post[q].l, k32);
             }
             a.last = (p == npass - 1);
+            a.zskip = 0;
+            if (p == 0 && n_in < N && n_in > 0 && (n_in & (n_in - 1)) == 0) {
+                uint32_t z = 0;
+                while (((size_t)n_in << z) < N) z++;
+                a.zskip = std::min(z, a.r);
+            }
             a.r_next = a.last ? 0 : plan->radix[p + 1];
             a.b0 = a.last ? nullptr : (const fe*)plan->d_bt[p];
             ZK_CHECK(ctx, a.r >= 3 && a.r <= 8, "ntt: tile pass radix 2^%u unsupported", a.r);
