@@ -314,7 +314,9 @@ def measure_evalh(ctx, dom, stream, gen, evalh_k):
     k_us, k_n = ctx.timing_get("evalh")
     ctx.timing_enable(False)
     bytes_alg = 32.0 * kdom.extended_len * (c_read + 1)
-    return {"k": evalh_k, "extended_k": kdom.extended_k, "seconds": ev_s, "algorithmic_GB": bytes_alg / 1e9,
+    prog = ctx.evaluate_h_last_stats()
+    mads = prog["multiplications"] * MADS_PER_MUL * float(kdom.extended_len)
+    return {"program": prog, "valu_mads": mads, "valu_frac": mads / (k_us * 1e-6) / VALU_MAD_PEAK if k_us else 0.0,"k": evalh_k, "extended_k": kdom.extended_k, "seconds": ev_s, "algorithmic_GB": bytes_alg / 1e9,
             "GBps": bytes_alg / ev_s / 1e9, "frac_of_hbm_peak": bytes_alg / ev_s / 1e9 / HBM_PEAK,
             "calculations": n_calc, "kernel_ms": k_us / 1e3, "columns_read": c_read}
 

@@ -176,6 +176,10 @@ typedef struct {
 
 /* out: 2^ext_k x 4 (host or device per desc->mem) = numerator of the quotient on the extended coset. */
 int zkhip_evaluate_h(zkhip_domain* dom, const zkhip_evalh_desc* desc, uint64_t* out);
+/* Size of the fused program the last zkhip_evaluate_h call on this context ran per extended row: out[0] instructions,
+ * out[1] field multiplications, out[2] column reads, out[3] value slots (for throughput accounting; no reference
+ * counterpart). */
+int zkhip_evaluate_h_last_stats(zkhip_ctx* ctx, uint64_t out[4]);
 
 /* ------------------------------------------------------------------ grand products and openings -----
  * The prover steps adjacent to the hot path (the rest of `plonk::prover::create_proof`, reached from

@@ -35,6 +35,8 @@ struct zkhip_ctx {
     std::map<std::string, zkhip::TimingSlot> timers;
     int num_cus = 256;
     std::vector<zkhip::NttPlan*> plans;   // cached per (log_n, omega)
+    // program of the last evaluate_h call: instructions, multiplications, column reads, value slots
+    uint64_t evalh_stats[4] = {0, 0, 0, 0};
 };
 
 namespace zkhip {

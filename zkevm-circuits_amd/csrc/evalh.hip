@@ -33,8 +33,9 @@ namespace zkhip {
 
 constexpr int EV_THREADS = 256;
 
-// instruction word 0: bit 0 = multiply a * b, bit 1 = add c, bit 2 = subtract c, bits 8.. = destination
-constexpr uint32_t F_MUL = 1, F_ADD = 2, F_SUB = 4;
+// instruction word 0: bit 0 = multiply a * b, bit 1 = add c, bit 2 = subtract c, bit 3 = carry-normalise the result,
+// bits 4 / 5 = carry-normalise operand a / b after fetching it, bits 8.. = destination
+constexpr uint32_t F_MUL = 1, F_ADD = 2, F_SUB = 4, F_NORM = 8, F_NORM_A = 16, F_NORM_B = 32;
 enum DevKind : uint32_t { K_CONST = 0, K_SLOT, K_COL, K_SCALAR, K_ACC, K_ZERO };
 constexpr uint32_t DST_ACC = 0xffffffu;
 constexpr uint32_t W_ZERO = K_ZERO << 28, W_ACC = K_ACC << 28;
@@ -129,10 +130,16 @@ __device__ __forceinline__ void ev_stage(Staged& s, prog_ptr w, uint32_t idx, ui
 __device__ __forceinline__ void ev_execute(const InterpArgs& a, const Staged& s, int32_t* lds, fw& acc, fw& reg0, uint32_t idx) {
     const uint32_t w0 = s.w0, dst = w0 >> 8;
     fw t = ev_value(a, s.a, s.ra, lds, acc, reg0, idx);
-    if (w0 & F_MUL) t = FrW::mul(t, ev_value(a, s.b, s.rb, lds, acc, reg0, idx));
+    if (w0 & F_NORM_A) t = FrW::norm(t);
+    if (w0 & F_MUL) {
+        fw u = ev_value(a, s.b, s.rb, lds, acc, reg0, idx);
+        if (w0 & F_NORM_B) u = FrW::norm(u);
+        t = FrW::mul(t, u);
+    }
     if (w0 & (F_ADD | F_SUB)) {
         const fw c = ev_value(a, s.c, s.rc, lds, acc, reg0, idx);
-        t = FrW::norm((w0 & F_ADD) ? FrW::add(t, c) : FrW::sub(t, c));
+        t = (w0 & F_ADD) ? FrW::add(t, c) : FrW::sub(t, c);
+        if (w0 & F_NORM) t = FrW::norm(t);
     }
     if (dst == DST_ACC) {
         acc = t;
@@ -263,6 +270,7 @@ struct Builder {
     static uint32_t slot(uint32_t v) { return (K_SLOT << 28) | v; }
     uint32_t fresh() {
         vbound.push_back(0.0);
+        vdig.push_back(Digits());
         return n_virtual++;
     }
     // Upper bounds on |value| / p.  A multiplication maps (x, y) to below x y / 147 + 1 (Montgomery radix 2^261 over
@@ -280,22 +288,59 @@ struct Builder {
             default: return 0.0;
         }
     }
+    // Digit bounds of every value, in units of 2^29 (digits 0..7; the top digit is covered by the value bound above).
+    // Fetched columns / constants and products are normalised: [0, 1].  A product needs |a_i| |b_j| <= 2 * 2^58 so that
+    // the 64-bit columns hold; sums must stay inside int32.  The carry pass after an addition is only emitted when
+    // the result would leave [-2, 2]; an operand is normalised at fetch when a product would otherwise overflow.
+    struct Digits {
+        double lo = 0.0, hi = 0.0;
+        double mag() const { return std::max(-lo, hi); }
+    };
+    std::vector<Digits> vdig;
+    Digits acc_dig;
+    Digits digits(uint32_t w) const {
+        switch (w >> 28) {
+            case K_CONST: case K_SCALAR: case K_COL: return {0.0, 1.0};
+            case K_SLOT: return vdig[w & 0x0fffffffu];
+            case K_ACC: return acc_dig;
+            default: return {0.0, 0.0};
+        }
+    }
     void emit(uint32_t flags, uint32_t dst, uint32_t a, uint32_t b = W_ZERO, uint32_t c = W_ZERO) {
         double v = bound(a);
-        if (flags & F_MUL) v = v * bound(b) / EV_CONTRACT + 1.0;
-        if (flags & (F_ADD | F_SUB)) v += bound(c);
+        Digits t = digits(a);
+        if (flags & F_MUL) {
+            v = v * bound(b) / EV_CONTRACT + 1.0;
+            Digits u = digits(b);
+            if (t.mag() * u.mag() > 2.0 && t.mag() > 1.0) {
+                flags |= F_NORM_A;
+                t = {0.0, 1.0};
+            }
+            if (t.mag() * u.mag() > 2.0) flags |= F_NORM_B;
+            t = {0.0, 1.0};
+        }
+        if (flags & (F_ADD | F_SUB)) {
+            v += bound(c);
+            const Digits w = digits(c);
+            if (!(flags & F_MUL) && t.mag() + w.mag() > 3.5) {   // int32 headroom of the digit sums
+                flags |= F_NORM_A;
+                t = {0.0, 1.0};
+            }
+            if (flags & F_ADD) t = {t.lo + w.lo, t.hi + w.hi};
+            else t = {t.lo - w.hi, t.hi - w.lo};
+            if (t.mag() > 2.0) {
+                flags |= F_NORM;
+                t = {0.0, 1.0};
+            }
+        }
         words.push_back(flags | (dst << 8));
         words.push_back(a);
         words.push_back(b);
         words.push_back(c);
-        if (v > EV_LIMIT) {
-            words.push_back(F_MUL | (dst << 8));
-            words.push_back(dst == DST_ACC ? W_ACC : slot(dst));
-            words.push_back(scalar(SC_ONE));
-            words.push_back(W_ZERO);
-            v = v / EV_CONTRACT + 1.0;
-        }
         (dst == DST_ACC ? acc_bound : vbound[dst]) = v;
+        (dst == DST_ACC ? acc_dig : vdig[dst]) = t;
+        // renormalise the value through a multiplication by one
+        if (v > EV_LIMIT) emit(F_MUL, dst, dst == DST_ACC ? W_ACC : slot(dst), scalar(SC_ONE));
     }
     // value-returning helpers (destination = fresh virtual value)
     uint32_t mul(uint32_t a, uint32_t b) { const uint32_t d = fresh(); emit(F_MUL, d, a, b); return slot(d); }
@@ -734,6 +779,18 @@ extern "C" int zkhip_evaluate_h(zkhip_domain* dom, const zkhip_evalh_desc* desc,
     const uint32_t lds_budget = env_slots && *env_slots ? (uint32_t)atoi(env_slots) : 5;
     uint32_t result = W_ACC, lds_slots = 1, n_slots = 1;
     assign_slots(b.words, result, b.n_virtual, lds_budget, lds_slots, n_slots);
+    {
+        size_t nmul = 0, ncol = 0;
+        for (size_t pc = 0; pc < b.words.size() / 4; pc++) {
+            if (b.words[4 * pc] & F_MUL) nmul++;
+            for (int q = 1; q <= 3; q++)
+                if ((b.words[4 * pc + q] >> 28) == K_COL) ncol++;
+        }
+        ctx->evalh_stats[0] = b.words.size() / 4;
+        ctx->evalh_stats[1] = nmul;
+        ctx->evalh_stats[2] = ncol;
+        ctx->evalh_stats[3] = n_slots;
+    }
     if (getenv("ZKHIP_DEBUG")) {
         size_t nmul = 0, ncol = 0, nspill = 0;
         for (size_t pc = 0; pc < b.words.size() / 4; pc++) {
@@ -839,5 +896,11 @@ extern "C" int zkhip_evaluate_h(zkhip_domain* dom, const zkhip_evalh_desc* desc,
     }
     if (host) ZK_HIP(ctx, hipMemcpyAsync(out, d_out, size * 32, hipMemcpyDeviceToHost, ctx->stream));
     ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return ZKHIP_OK;
+}
+
+extern "C" int zkhip_evaluate_h_last_stats(zkhip_ctx* ctx, uint64_t out[4]) {
+    if (!ctx || !out) return ZKHIP_ERR_INVALID;
+    memcpy(out, ctx->evalh_stats, sizeof ctx->evalh_stats);
     return ZKHIP_OK;
 }

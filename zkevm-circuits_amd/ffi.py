@@ -27,7 +27,7 @@ EXPORTS = [
     "zkhip_divide_by_vanishing_poly",
     "zkhip_lagrange_to_coeff_dev", "zkhip_coeff_to_lagrange_dev", "zkhip_coeff_to_extended_dev",
     "zkhip_extended_to_coeff_dev", "zkhip_divide_by_vanishing_poly_dev",
-    "zkhip_evaluate_h",
+    "zkhip_evaluate_h", "zkhip_evaluate_h_last_stats",
     "zkhip_batch_invert_dev", "zkhip_prefix_product_dev", "zkhip_permutation_product_dev", "zkhip_lookup_product_dev",
     "zkhip_eval_polynomial_dev",
     "zkhip_timing_enable", "zkhip_timing_reset", "zkhip_timing_get",
@@ -283,6 +283,11 @@ class Context:
         out = np.zeros(4, dtype=np.uint64)
         self._ck(self._l.zkhip_eval_polynomial_dev(self.h, C.c_void_p(d_coeff), C.c_size_t(n), _p(x), _p(out)))
         return out
+
+    def evaluate_h_last_stats(self):
+        out = np.zeros(4, dtype=np.uint64)
+        self._ck(self._l.zkhip_evaluate_h_last_stats(self.h, _p(out)))
+        return {"instructions": int(out[0]), "multiplications": int(out[1]), "column_reads": int(out[2]), "slots": int(out[3])}
 
     def timing_enable(self, on=True):
         self._ck(self._l.zkhip_timing_enable(self.h, C.c_int(1 if on else 0)))
