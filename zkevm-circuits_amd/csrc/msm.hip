@@ -78,66 +78,215 @@ ZK_DEV fe fr_canonical(const fe& a) {
     return Fr::mul(a, one);
 }
 // c-bit field of a 256-bit little-endian integer starting at bit `pos`
-ZK_DEV uint32_t bits_at(const fe& v, uint32_t pos, uint32_t c) {
-    if (pos >= 256) return 0;
-    const uint32_t w = pos >> 5, s = pos & 31;
-    uint64_t x = v.l[w];
-    if (w + 1 < 8) x |= (uint64_t)v.l[w + 1] << 32;
-    return (uint32_t)(x >> s) & ((1u << c) - 1);
-}
+// Signed window digits of a canonical scalar: d[w] in (-2^(C-1), 2^(C-1)], sum d[w] 2^(C w) = v.  The window width is a
+// template parameter so that, fully unrolled, every word index and shift is a constant and the digits stay in registers.
+constexpr uint32_t windows_for(uint32_t c) { return (255 + c - 1) / c; }
 
-struct DigitIter {
-    fe v;
+template <uint32_t C>
+ZK_DEV void signed_digits(const fe& v, int32_t (&d)[windows_for(C)]) {
     uint32_t carry = 0;
-    // returns signed digit d in (-2^(c-1), 2^(c-1)] for window w (call with w = 0, 1, ... in order)
-    ZK_DEV int32_t next(uint32_t w, uint32_t c) {
-        uint32_t raw = bits_at(v, w * c, c) + carry;
-        if (raw > (1u << (c - 1))) {
-            carry = 1;
-            return (int32_t)raw - (int32_t)(1u << c);
-        }
-        carry = 0;
-        return (int32_t)raw;
+#pragma unroll
+    for (uint32_t w = 0; w < windows_for(C); w++) {
+        const uint32_t pos = w * C, word = pos >> 5, sh = pos & 31;
+        uint32_t x = v.l[word] >> sh;
+        if (sh + C > 32 && word + 1 < 8) x |= v.l[word + 1] << (32 - sh);
+        const uint32_t raw = (x & ((1u << C) - 1)) + carry;
+        carry = raw > (1u << (C - 1)) ? 1u : 0u;
+        d[w] = (int32_t)raw - (int32_t)(carry << C);
     }
-};
-
-__global__ void __launch_bounds__(HIST_THREADS) digits_hist_kernel(const fe* scalars, size_t n, size_t chunk, uint32_t c,
-                                                                    uint32_t W, uint32_t* counts /*[G][B]*/) {
-    extern __shared__ uint32_t hist[];
-    const uint32_t B = 1u << (c - 1), g = blockIdx.x;
-    for (uint32_t b = threadIdx.x; b < B; b += HIST_THREADS) hist[b] = 0;
-    __syncthreads();
-    const size_t lo = (size_t)g * chunk, hi = lo + chunk < n ? lo + chunk : n;
-    for (size_t i = lo + threadIdx.x; i < hi; i += HIST_THREADS) {
-        DigitIter it;
-        it.v = fr_canonical(load_fe(scalars + i));
-        for (uint32_t w = 0; w < W; w++) {
-            const int32_t d = it.next(w, c);
-            if (d != 0) atomicAdd(&hist[(d < 0 ? -d : d) - 1], 1u);
-        }
-    }
-    __syncthreads();
-    for (uint32_t b = threadIdx.x; b < B; b += HIST_THREADS) counts[(size_t)g * B + b] = hist[b];
 }
 
-__global__ void __launch_bounds__(HIST_THREADS) scatter_kernel(const fe* scalars, size_t n, size_t chunk, uint32_t c,
-                                                               uint32_t W, const uint32_t* offsets /*[G][B]*/,
-                                                               const uint32_t* start /*[B]*/, uint32_t* entries) {
-    extern __shared__ uint32_t cursor[];
-    const uint32_t B = 1u << (c - 1), g = blockIdx.x;
-    for (uint32_t b = threadIdx.x; b < B; b += HIST_THREADS) cursor[b] = start[b] + offsets[(size_t)g * B + b];
+template <uint32_t C>
+__global__ void __launch_bounds__(HIST_THREADS) digits_hist_kernel(const fe* scalars, size_t n, size_t chunk,
+                                                                    uint32_t* counts /*[G][B]*/, uint32_t* bincount /*[G][256]*/) {
+    extern __shared__ uint32_t hist[];   // [B] bucket counts, then [256] counts per bin of 128 buckets
+    constexpr uint32_t B = 1u << (C - 1), W = windows_for(C);
+    const uint32_t g = blockIdx.x;
+    uint32_t* binh = hist + B;
+    for (uint32_t b = threadIdx.x; b < B + 256; b += HIST_THREADS) hist[b] = 0;
     __syncthreads();
     const size_t lo = (size_t)g * chunk, hi = lo + chunk < n ? lo + chunk : n;
     for (size_t i = lo + threadIdx.x; i < hi; i += HIST_THREADS) {
-        DigitIter it;
-        it.v = fr_canonical(load_fe(scalars + i));
-        for (uint32_t w = 0; w < W; w++) {
-            const int32_t d = it.next(w, c);
-            if (d != 0) {
-                const uint32_t pos = atomicAdd(&cursor[(d < 0 ? -d : d) - 1], 1u);
-                entries[pos] = (uint32_t)i | (w << ENTRY_IDX_BITS) | (d < 0 ? 0x80000000u : 0u);
+        int32_t d[W];
+        signed_digits<C>(fr_canonical(load_fe(scalars + i)), d);
+#pragma unroll
+        for (uint32_t w = 0; w < W; w++)
+            if (d[w] != 0) atomicAdd(&hist[(d[w] < 0 ? -d[w] : d[w]) - 1], 1u);
+    }
+    __syncthreads();
+    for (uint32_t b = threadIdx.x; b < B; b += HIST_THREADS) {   // a wave covers 64 buckets of one bin
+        const uint32_t v = hist[b];
+        counts[(size_t)g * B + b] = v;
+        uint32_t t = v;
+        for (int o = 32; o >= 1; o >>= 1) t += __shfl_xor(t, o, 64);
+        if ((threadIdx.x & 63) == 0 && t) atomicAdd(&binh[b >> 7], t);
+    }
+    __syncthreads();
+    if (threadIdx.x < 256) bincount[(size_t)g * 256 + threadIdx.x] = binh[threadIdx.x];
+}
+
+// ---- two-level scatter ------------------------------------------------------------------------------
+// Writing every 4-byte entry straight to its bucket puts each in a 32-byte HBM sector of its own (8x write
+// amplification, measured).  The two-level form first groups a block's entries by coarse bin (128 consecutive buckets) in LDS and writes them as
+// runs of (entry, bucket) records into the bin's range of a temporary array (a bin occupies the same range there as
+// in the final array); a second kernel then places the records of one bin, whose final range is small enough to stay
+// in L2 while it fills.  Any order inside a bucket is fine: bucket sums do not depend on it.
+constexpr uint32_t BIN_LOG = 7;                 // buckets per coarse bin = 128
+constexpr uint32_t BIN_MASK = (1u << BIN_LOG) - 1;
+constexpr uint32_t COARSE_ROUND = 16384;        // records staged per round (128 KiB)
+constexpr int COARSE_THREADS = 1024;
+constexpr uint32_t FINE_SLICE = 4096;           // records one workgroup of the second pass places at a time
+constexpr int FINE_THREADS = 256;
+constexpr int FINE_PER_LANE = FINE_SLICE / FINE_THREADS;
+
+// Workgroup g handles the same chunk of scalars as in digits_hist_kernel, T scalars (one per lane) per round: their
+// nonzero digits are counted per bin, staged bin by bin in LDS and written out as one run per bin.  The workgroup's
+// place in each bin's range follows from the bin counts of the workgroups before it, so the layout of tmp is
+// deterministic and no global atomics are needed.
+template <uint32_t C>
+__global__ void __launch_bounds__(COARSE_THREADS) scatter_coarse_kernel(const fe* scalars, size_t n, size_t chunk, uint32_t T,
+                                                                        const uint32_t* bincount, const uint32_t* start,
+                                                                        uint2* tmp) {
+    extern __shared__ __align__(16) unsigned char smem_sc[];
+    uint32_t* hist = reinterpret_cast<uint32_t*>(smem_sc);        // [256] records of this round per bin
+    uint32_t* roff = hist + 256;                                  // [256] exclusive scan of hist
+    uint32_t* fill = roff + 256;                                  // [256]
+    uint32_t* gdelta = fill + 256;                                // [256] start of this round's run in tmp minus roff
+    uint32_t* cursor = gdelta + 256;                              // [256] next free record of this workgroup, per bin
+    uint2* staging = reinterpret_cast<uint2*>(cursor + 256);      // [COARSE_ROUND]
+    __shared__ uint32_t total_s;
+    constexpr uint32_t W = windows_for(C), NB = (1u << (C - 1)) >> BIN_LOG;
+    const uint32_t tid = threadIdx.x, g = blockIdx.x;
+    if (tid < 256) {
+        cursor[tid] = tid < NB ? start[tid << BIN_LOG] : 0;
+        fill[tid] = 0;
+    }
+    __syncthreads();
+    {
+        const uint32_t q = tid & 255, part = tid >> 8;            // four lanes share the rows before g of one bin
+        uint32_t sum = 0;
+        for (uint32_t r = part; r < g; r += COARSE_THREADS / 256) sum += bincount[(size_t)r * 256 + q];
+        if (sum) atomicAdd(&cursor[q], sum);
+    }
+    const size_t lo = (size_t)g * chunk, hi = lo + chunk < n ? lo + chunk : n;
+    for (size_t r0 = lo; r0 < hi; r0 += T) {
+        if (tid < 256) hist[tid] = 0;
+        __syncthreads();
+        const size_t i = r0 + tid;
+        const bool live = tid < T && i < hi;
+        int32_t d[W];
+        if (live) {
+            signed_digits<C>(fr_canonical(load_fe(scalars + i)), d);
+#pragma unroll
+            for (uint32_t w = 0; w < W; w++)
+                if (d[w] != 0) atomicAdd(&hist[((uint32_t)(d[w] < 0 ? -d[w] : d[w]) - 1) >> BIN_LOG], 1u);
+        }
+        __syncthreads();
+        if (tid < 64) {   // one wave scans the 256 counts, four per lane
+            const uint32_t h0 = hist[4 * tid], h1 = hist[4 * tid + 1], h2 = hist[4 * tid + 2], h3 = hist[4 * tid + 3];
+            const uint32_t sum = h0 + h1 + h2 + h3;
+            uint32_t inc = sum;
+            for (int o = 1; o < 64; o <<= 1) {
+                const uint32_t t = __shfl_up(inc, o, 64);
+                if ((int)tid >= o) inc += t;
+            }
+            const uint32_t e = inc - sum;
+            roff[4 * tid] = e;
+            roff[4 * tid + 1] = e + h0;
+            roff[4 * tid + 2] = e + h0 + h1;
+            roff[4 * tid + 3] = e + h0 + h1 + h2;
+            if (tid == 63) total_s = inc;
+        }
+        __syncthreads();
+        if (tid < 256) {
+            const uint32_t cq = cursor[tid];
+            gdelta[tid] = cq - roff[tid];
+            cursor[tid] = cq + hist[tid];
+        }
+        if (live) {
+#pragma unroll
+            for (uint32_t w = 0; w < W; w++) {
+                if (d[w] != 0) {
+                    const uint32_t bk = (uint32_t)(d[w] < 0 ? -d[w] : d[w]) - 1, q = bk >> BIN_LOG;
+                    const uint32_t rank = atomicAdd(&fill[q], 1u);
+                    staging[roff[q] + rank] = make_uint2((uint32_t)i | (w << ENTRY_IDX_BITS) | (d[w] < 0 ? 0x80000000u : 0u), bk);
+                }
             }
         }
+        __syncthreads();
+        if (tid < 256) fill[tid] = 0;
+        const uint32_t total = total_s;
+        for (uint32_t j0 = tid; j0 < total; j0 += 4 * COARSE_THREADS) {
+            uint2 rec[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const uint32_t j = j0 + k * COARSE_THREADS;
+                if (j < total) rec[k] = staging[j];
+            }
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const uint32_t j = j0 + k * COARSE_THREADS;
+                if (j < total) tmp[gdelta[rec[k].y >> BIN_LOG] + j] = rec[k];
+            }
+        }
+    }
+}
+
+// Second pass: workgroup (bin q, part) places slices of the bin's records, FINE_SLICE at a time.  A slice is sorted by
+// bucket in LDS (ranks from LDS atomics), its per-bucket runs get their place in the bucket ranges with one global atomic
+// per (slice, bucket) on cur[] (initialised to the bucket starts), and the runs are written with consecutive lanes on
+// consecutive entries.
+__global__ void __launch_bounds__(FINE_THREADS) scatter_fine_kernel(const uint2* tmp, const uint32_t* start, const uint32_t* cnt,
+                                                                    uint32_t* cur, uint32_t parts, uint32_t* entries) {
+    __shared__ uint32_t hist[1u << BIN_LOG], delta[1u << BIN_LOG], loff[1u << BIN_LOG], wave_tot[2];
+    __shared__ uint32_t stage_e[FINE_SLICE];
+    __shared__ uint8_t stage_l[FINE_SLICE];
+    const uint32_t q = blockIdx.x / parts, part = blockIdx.x % parts, tid = threadIdx.x;
+    const uint32_t b0 = q << BIN_LOG, b1 = b0 + BIN_MASK;    // the bucket count is a multiple of 128
+    const uint32_t lo_bin = start[b0], hi_bin = start[b1] + cnt[b1];
+    for (uint32_t lo = lo_bin + part * FINE_SLICE; lo < hi_bin; lo += parts * FINE_SLICE) {
+        const uint32_t hi = lo + FINE_SLICE < hi_bin ? lo + FINE_SLICE : hi_bin;
+        if (tid < (1u << BIN_LOG)) hist[tid] = 0;
+        __syncthreads();
+        uint2 rec[FINE_PER_LANE];
+        uint32_t rank[FINE_PER_LANE];
+#pragma unroll
+        for (int k = 0; k < FINE_PER_LANE; k++) {
+            const uint32_t j = lo + k * FINE_THREADS + tid;
+            if (j < hi) rec[k] = tmp[j];
+        }
+#pragma unroll
+        for (int k = 0; k < FINE_PER_LANE; k++)
+            if (lo + k * FINE_THREADS + tid < hi) rank[k] = atomicAdd(&hist[rec[k].y & BIN_MASK], 1u);
+        __syncthreads();
+        uint32_t v = 0, inc = 0, gb = 0;
+        if (tid < (1u << BIN_LOG)) {
+            v = hist[tid];
+            if (v) gb = atomicAdd(&cur[b0 + tid], v);
+            inc = v;
+            for (int d = 1; d < 64; d <<= 1) {
+                const uint32_t t = __shfl_up(inc, d, 64);
+                if ((int)(tid & 63) >= d) inc += t;
+            }
+            if ((tid & 63) == 63) wave_tot[tid >> 6] = inc;
+        }
+        __syncthreads();
+        if (tid < (1u << BIN_LOG)) {
+            const uint32_t e = inc - v + (tid >= 64 ? wave_tot[0] : 0);
+            loff[tid] = e;
+            delta[tid] = gb - e;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < FINE_PER_LANE; k++) {
+            if (lo + k * FINE_THREADS + tid < hi) {
+                const uint32_t l = rec[k].y & BIN_MASK, pos = loff[l] + rank[k];
+                stage_e[pos] = rec[k].x;
+                stage_l[pos] = (uint8_t)l;
+            }
+        }
+        __syncthreads();
+        for (uint32_t j = tid; j < hi - lo; j += FINE_THREADS) entries[delta[stage_l[j]] + j] = stage_e[j];
     }
 }
 
@@ -162,38 +311,39 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
     return v;
 }
 
-// counts[g][b] -> exclusive prefix over g (in place), cnt[b] = bucket size; one lane per bucket, coalesced over b.
+// cnt[b] = sum over g of counts[g][b].  A block of 1024 lanes covers 256 buckets: a wave reads four buckets per lane
+// from one row (1 KiB per load) and the sixteen waves take every sixteenth row; the partial sums meet in LDS.
 // Each block also leaves its share of the plan statistics in plan[blockIdx.x][*].
-__global__ void __launch_bounds__(256) column_scan_kernel(uint32_t* counts /*[G][B]*/, uint32_t G, uint32_t B, uint32_t* cnt,
-                                                          uint32_t l_min, uint32_t* plan) {
+constexpr int COLSUM_THREADS = 1024;
+__global__ void __launch_bounds__(COLSUM_THREADS) column_sum_kernel(const uint32_t* counts /*[G][B]*/, uint32_t G, uint32_t B,
+                                                                    uint32_t* cnt, uint32_t l_min, uint32_t* plan) {
     __shared__ uint32_t sh[PLAN_STRIDE];
-    for (uint32_t i = threadIdx.x; i < PLAN_STRIDE; i += 256) sh[i] = 0;
-    __syncthreads();
-    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
-    uint32_t run = 0;
-    if (b < B) {
-        uint32_t g = 0;
-        for (; g + 8 <= G; g += 8) {
-            uint32_t v[8];
-#pragma unroll
-            for (int k = 0; k < 8; k++) v[k] = counts[(size_t)(g + k) * B + b];
-#pragma unroll
-            for (int k = 0; k < 8; k++) {
-                counts[(size_t)(g + k) * B + b] = run;
-                run += v[k];
-            }
+    __shared__ uint32_t part[COLSUM_THREADS / 64][256];
+    for (uint32_t i = threadIdx.x; i < PLAN_STRIDE; i += COLSUM_THREADS) sh[i] = 0;
+    const uint32_t lane = threadIdx.x & 63, rg = threadIdx.x >> 6, b4 = blockIdx.x * 256 + 4 * lane;
+    uint4 acc = make_uint4(0, 0, 0, 0);
+    if (b4 < B) {   // B is a multiple of 128, so four buckets are inside together
+        for (uint32_t g = rg; g < G; g += COLSUM_THREADS / 64) {
+            const uint4 v = *reinterpret_cast<const uint4*>(counts + (size_t)g * B + b4);
+            acc.x += v.x;
+            acc.y += v.y;
+            acc.z += v.z;
+            acc.w += v.w;
         }
-        for (; g < G; g++) {
-            const uint32_t v = counts[(size_t)g * B + b];
-            counts[(size_t)g * B + b] = run;
-            run += v;
-        }
-        cnt[b] = run;
     }
-    // statistics: lane i < 2 folds max / sum, lane 2 + i the slots of ladder step i, over the block's 256 bucket sizes
-    __shared__ uint32_t cv[256];
-    cv[threadIdx.x] = run;
+    *reinterpret_cast<uint4*>(&part[rg][4 * lane]) = acc;
     __syncthreads();
+    __shared__ uint32_t cv[256];
+    if (threadIdx.x < 256) {
+        uint32_t run = 0;
+#pragma unroll
+        for (int k = 0; k < COLSUM_THREADS / 64; k++) run += part[k][threadIdx.x];
+        const uint32_t b = blockIdx.x * 256 + threadIdx.x;
+        if (b < B) cnt[b] = run;
+        cv[threadIdx.x] = run;
+    }
+    __syncthreads();
+    // statistics: lane i < 2 folds max / sum, lane 2 + i the slots of ladder step i, over the block's 256 bucket sizes
     if (threadIdx.x < PLAN_STRIDE) {
         uint32_t L = l_min;
         for (uint32_t i = 2; i < threadIdx.x && L <= L_MAX; i++) L = next_slot_len(L);
@@ -210,17 +360,18 @@ __global__ void __launch_bounds__(256) column_scan_kernel(uint32_t* counts /*[G]
         sh[threadIdx.x] = acc;
     }
     __syncthreads();
-    for (uint32_t i = threadIdx.x; i < PLAN_STRIDE; i += 256) plan[(size_t)blockIdx.x * PLAN_STRIDE + i] = sh[i];
+    for (uint32_t i = threadIdx.x; i < PLAN_STRIDE; i += COLSUM_THREADS) plan[(size_t)blockIdx.x * PLAN_STRIDE + i] = sh[i];
 }
 
 // One block of 1024 lanes (B a power of two, B <= 32768).
 //   D != 0 : f(b) = ceil(cnt[b] / D)
 //   D == 0 : folds the plan statistics of `plan_blocks` blocks, picks the slot length L (info[INFO_L]) that minimises
 //            rounds * L for `round_lanes` lanes per round, and uses f(b) = ceil(cnt[b] / L);
-//            also writes start_out = exclusive scan of cnt, info[INFO_MAXCNT], info[INFO_ENTRIES]
+//            also writes start_out = cur_out = exclusive scan of cnt, info[INFO_MAXCNT], info[INFO_ENTRIES]
 //   f_out[b] = f(b), off_out[b] = exclusive scan of f, off_out[B] = info[INFO_SLOTS] = total
 __global__ void __launch_bounds__(1024) bucket_scan_kernel(const uint32_t* cnt, uint32_t B, uint32_t D, uint32_t* f_out,
-                                                           uint32_t* off_out, uint32_t* start_out, const uint32_t* plan,
+                                                           uint32_t* off_out, uint32_t* start_out, uint32_t* cur_out,
+                                                           const uint32_t* plan,
                                                            uint32_t plan_blocks, uint32_t l_min, uint32_t round_lanes,
                                                            uint32_t force_L, uint32_t* info) {
     __shared__ uint32_t wsum[2][16];
@@ -313,7 +464,10 @@ __global__ void __launch_bounds__(1024) bucket_scan_kernel(const uint32_t* cnt, 
             const uint32_t idx = base + r * 64;
             if (idx < B) {
                 off_out[idx] = bs + offf[r];
-                if (start_out) start_out[idx] = be + offc[r];
+                if (start_out) {
+                    start_out[idx] = be + offc[r];
+                    cur_out[idx] = be + offc[r];
+                }
             }
         }
     }
@@ -551,7 +705,8 @@ struct MsmWorkspace {
     const fe* d_scalars = nullptr;
     uint32_t G = 0, l_min = 0, plan_blocks = 0, acc_blocks = 0;
     bool nonzero = false;
-    uint32_t *counts, *entries, *start, *cnt, *offA, *cntA, *offB, *cntB, *info, *plan;
+    uint32_t *counts, *entries, *start, *cnt, *offA, *cntA, *offB, *cntB, *info, *plan, *cur, *bincount;
+    uint2* tmp;
     g1_xyzz *itemsA, *itemsB, *sums, *a1, *v1, *out2;
 };
 constexpr size_t REDUCE_OUT = 24;
@@ -574,7 +729,8 @@ static int ws_prepare(zkhip_ctx* ctx, MsmWorkspace& ws, const MsmTables& tb, siz
         off = align_up(off + bytes, 256);
         return o;
     };
-    const size_t o_counts = take((size_t)B * G * 4), o_entries = take(E_max * 4), o_start = take(((size_t)B + 1) * 4),
+    const size_t o_counts = take((size_t)B * G * 4), o_entries = take(E_max * 4), o_tmp = take(E_max * 8),
+                 o_cur = take((size_t)B * 4), o_bin = take((size_t)G * 256 * 4), o_start = take(((size_t)B + 1) * 4),
                  o_cnt = take((size_t)B * 4), o_offA = take(((size_t)B + 1) * 4), o_cntA = take((size_t)B * 4),
                  o_offB = take(((size_t)B + 1) * 4), o_cntB = take((size_t)B * 4), o_info = take(64),
                  o_plan = take((size_t)ws.plan_blocks * PLAN_STRIDE * 4), o_itemsA = take(T1_max * sizeof(g1_xyzz)),
@@ -598,6 +754,9 @@ static int ws_prepare(zkhip_ctx* ctx, MsmWorkspace& ws, const MsmTables& tb, siz
     unsigned char* p = ws.base;
     ws.counts = (uint32_t*)(p + o_counts);
     ws.entries = (uint32_t*)(p + o_entries);
+    ws.tmp = (uint2*)(p + o_tmp);
+    ws.cur = (uint32_t*)(p + o_cur);
+    ws.bincount = (uint32_t*)(p + o_bin);
     ws.start = (uint32_t*)(p + o_start);
     ws.cnt = (uint32_t*)(p + o_cnt);
     ws.offA = (uint32_t*)(p + o_offA);
@@ -624,17 +783,47 @@ static int msm_phase1(zkhip_ctx* ctx, MsmWorkspace& ws, const MsmTables& tb, siz
     ws.d_scalars = d_scalars;
     const uint32_t c = tb.c, W = tb.W, B = 1u << (c - 1), G = ws.G;
     const size_t chunk = (n + G - 1) / G;
-    const size_t lds_hist = (size_t)B * 4;
+    const size_t lds_hist = (size_t)B * 4 + 256 * 4;
     hipStream_t st = ws.stream;
-    hipLaunchKernelGGL(digits_hist_kernel, dim3(G), dim3(HIST_THREADS), lds_hist, st, d_scalars, n, chunk, c, W, ws.counts);
-    hipLaunchKernelGGL(column_scan_kernel, dim3(ws.plan_blocks), dim3(256), 0, st, ws.counts, G, B, ws.cnt, ws.l_min, ws.plan);
-    hipLaunchKernelGGL(bucket_scan_kernel, dim3(1), dim3(1024), 0, st, ws.cnt, B, 0u, ws.cntA, ws.offA, ws.start, ws.plan,
+    ZK_CHECK(ctx, tb.W == windows_for(c), "msm: window count %u does not match window width %u", tb.W, c);
+#define ZK_FOR_WINDOW_WIDTH(X) \
+    switch (c) {               \
+        case 8: X(8); break;   \
+        case 9: X(9); break;   \
+        case 10: X(10); break; \
+        case 11: X(11); break; \
+        case 12: X(12); break; \
+        case 13: X(13); break; \
+        case 14: X(14); break; \
+        case 15: X(15); break; \
+        case 16: X(16); break; \
+        default: ZK_CHECK(ctx, false, "msm: unsupported window width %u", c); \
+    }
+#define ZK_LAUNCH_HIST(C) \
+    hipLaunchKernelGGL(digits_hist_kernel<C>, dim3(G), dim3(HIST_THREADS), lds_hist, st, d_scalars, n, chunk, ws.counts, ws.bincount)
+    ZK_FOR_WINDOW_WIDTH(ZK_LAUNCH_HIST)
+#undef ZK_LAUNCH_HIST
+    hipLaunchKernelGGL(column_sum_kernel, dim3(ws.plan_blocks), dim3(COLSUM_THREADS), 0, st, ws.counts, G, B, ws.cnt, ws.l_min, ws.plan);
+    hipLaunchKernelGGL(bucket_scan_kernel, dim3(1), dim3(1024), 0, st, ws.cnt, B, 0u, ws.cntA, ws.offA, ws.start, ws.cur, ws.plan,
                        ws.plan_blocks, ws.l_min, (uint32_t)ctx->num_cus * 256u, FORCE_L, ws.info);
     // the plan travels to the host while scatter and accumulate run
     ZK_HIP(ctx, hipMemcpyAsync(ws.h_info, ws.info, 16, hipMemcpyDeviceToHost, st));
     ZK_HIP(ctx, hipEventRecord(ws.ev_info, st));
-    hipLaunchKernelGGL(scatter_kernel, dim3(G), dim3(HIST_THREADS), lds_hist, st, d_scalars, n, chunk, c, W, ws.counts,
-                       ws.start, ws.entries);
+    {
+        const size_t lds_coarse = 5 * 256 * 4 + (size_t)COARSE_ROUND * 8;
+        const uint32_t T = std::min<uint32_t>(COARSE_THREADS, COARSE_ROUND / W);
+        const uint32_t NB = B >> BIN_LOG;
+        // slices of an evenly filled bin, with a quarter to spare; fuller bins take more turns of the slice loop
+        const uint32_t parts = (uint32_t)std::max<size_t>(1, (n * W / NB * 5 / 4 + FINE_SLICE - 1) / FINE_SLICE);
+#define ZK_LAUNCH_COARSE(C)                                                                                              \
+    hipLaunchKernelGGL(scatter_coarse_kernel<C>, dim3(G), dim3(COARSE_THREADS), lds_coarse, st, d_scalars, n, chunk, T, \
+                       ws.bincount, ws.start, ws.tmp)
+        ZK_FOR_WINDOW_WIDTH(ZK_LAUNCH_COARSE)
+#undef ZK_LAUNCH_COARSE
+#undef ZK_FOR_WINDOW_WIDTH
+        hipLaunchKernelGGL(scatter_fine_kernel, dim3(NB * parts), dim3(FINE_THREADS), 0, st, ws.tmp, ws.start, ws.cnt, ws.cur,
+                           parts, ws.entries);
+    }
     ZK_HIP(ctx, hipGetLastError());
     return ZKHIP_OK;
 }
@@ -668,7 +857,7 @@ static int msm_phase2(zkhip_ctx* ctx, MsmWorkspace& ws, const MsmTables& tb, boo
         uint32_t level_max = (max_cnt + L - 1) / L, level_total = total_slots;
         while (level_max > MERGE_DIRECT_MAX) {
             hipLaunchKernelGGL(bucket_scan_kernel, dim3(1), dim3(1024), 0, st, cur_cnt, B, MERGE_F, nxt_cnt, nxt_off,
-                               (uint32_t*)nullptr, (const uint32_t*)nullptr, 0u, 0u, 0u, 0u, (uint32_t*)nullptr);
+                               (uint32_t*)nullptr, (uint32_t*)nullptr, (const uint32_t*)nullptr, 0u, 0u, 0u, 0u, (uint32_t*)nullptr);
             const uint32_t bound = level_total / MERGE_F + B + 1;
             hipLaunchKernelGGL(merge_kernel, dim3((bound + 255) / 256), dim3(256), 0, st, cur_items, cur_off, cur_cnt, nxt_off,
                                B, MERGE_F, nxt_items);
@@ -861,10 +1050,14 @@ void msm_drop_ctx(zkhip_ctx* ctx) {
 }
 
 int msm_init(zkhip_ctx* ctx) {
-    ZK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(digits_hist_kernel),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
-    ZK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(scatter_kernel),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+#define ZK_LDS_ATTR(C)                                                                                  \
+    ZK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(digits_hist_kernel<C>),              \
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 132 * 1024));           \
+    ZK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(scatter_coarse_kernel<C>),           \
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024));
+    ZK_LDS_ATTR(8) ZK_LDS_ATTR(9) ZK_LDS_ATTR(10) ZK_LDS_ATTR(11) ZK_LDS_ATTR(12) ZK_LDS_ATTR(13) ZK_LDS_ATTR(14)
+    ZK_LDS_ATTR(15) ZK_LDS_ATTR(16)
+#undef ZK_LDS_ATTR
     return ZKHIP_OK;
 }
 
