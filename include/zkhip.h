@@ -197,7 +197,16 @@ int zkhip_evaluate_h_last_stats(zkhip_ctx* ctx, uint64_t out[4]);
  *     z[0] = 1, z[i+1] = z[i] * (a[i] + beta)(s[i] + gamma) / ((a'[i] + beta)(s'[i] + gamma))
  * Both write all n rows of z; upstream then overwrites the last `blinding_factors` rows with values from the prover's
  * RNG, which stays on the caller's side (last_z is row n - blinding_factors - 1).
- * zkhip_eval_polynomial_dev    `arithmetic::eval_polynomial`: sum_i coeff[i] x^i, result on the host (synchronises). */
+ * zkhip_eval_polynomial_dev    `arithmetic::eval_polynomial`: sum_i coeff[i] x^i, result on the host (synchronises).
+ *
+ * The polynomial arithmetic of the SHPLONK opening (`poly::kzg::multiopen::shplonk::prover::ProverSHPLONK::create_proof`,
+ * selected at zkevm-circuits/benches/benchmark_list/main.rs:26,267 and prover/src/test/proof_test.rs:297):
+ * zkhip_poly_lincomb_dev       out[i] = sum_k coeffs[k] * p_k[i] for i < n, p_k read as zero beyond lens[k] <= n.  This is
+ *     what upstream's chains of `poly * scalar` and `acc + &poly` compute for the quotient and linearisation
+ *     polynomials.  d_polys / lens: HOST arrays of num device pointers / lengths; coeffs: HOST, num x 4 limbs.
+ *     d_out may be one of the inputs (every output element depends on the same element of the inputs only).
+ * zkhip_kate_division_dev      `arithmetic::kate_division(a, point)`: the n - 1 coefficients of the quotient of
+ *     a(X) by (X - point); the remainder a(point) is dropped, as upstream drops it.  d_out must not overlap d_poly. */
 int zkhip_batch_invert_dev(zkhip_ctx* ctx, int field, uint64_t* d_a, size_t n);
 int zkhip_prefix_product_dev(zkhip_ctx* ctx, const uint64_t* d_m, uint64_t* d_out, size_t n, const uint64_t init[4]);
 int zkhip_permutation_product_dev(zkhip_domain* dom, const uint64_t* const* d_values, const uint64_t* const* d_sigmas,
@@ -207,11 +216,14 @@ int zkhip_lookup_product_dev(zkhip_domain* dom, const uint64_t* d_compressed_inp
                              const uint64_t* d_permuted_input, const uint64_t* d_permuted_table, const uint64_t beta[4],
                              const uint64_t gamma[4], uint64_t* d_z);
 int zkhip_eval_polynomial_dev(zkhip_ctx* ctx, const uint64_t* d_coeff, size_t n, const uint64_t x[4], uint64_t out[4]);
+int zkhip_poly_lincomb_dev(zkhip_ctx* ctx, const uint64_t* const* d_polys, const size_t* lens, const uint64_t* coeffs,
+                           uint32_t num, size_t n, uint64_t* d_out);
+int zkhip_kate_division_dev(zkhip_ctx* ctx, const uint64_t* d_poly, size_t n, const uint64_t point[4], uint64_t* d_out);
 
 /* Kernel timing hook: average duration in microseconds of the launches of the named kernel family issued on
  * this context since the last zkhip_timing_reset (measured with HIP events on the launch stream).
  * families: "ntt", "msm_sort", "msm_accumulate", "msm_merge", "msm_reduce", "evalh", "batch_invert",
- * "prefix_product", "grand_product", "eval_polynomial".  A family brackets every launch of its stage in one call (e.g. the passes of one NTT). */
+ * "prefix_product", "grand_product", "eval_polynomial", "poly_lincomb", "kate_division".  A family brackets every launch of its stage in one call (e.g. the passes of one NTT). */
 int zkhip_timing_enable(zkhip_ctx* ctx, int on);
 int zkhip_timing_reset(zkhip_ctx* ctx);
 int zkhip_timing_get(zkhip_ctx* ctx, const char* family, double* avg_us, uint64_t* launches);

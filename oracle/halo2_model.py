@@ -394,3 +394,145 @@ def lookup_product(compressed_input, compressed_table, permuted_input, permuted_
     for i in range(n):
         prod[i] = prod[i] * ((compressed_input[i] + beta) % P) % P * ((compressed_table[i] + gamma) % P) % P
     return prefix_product(prod, 1)
+
+
+# ---------------------------------------------------------------------------------------------
+# arithmetic::{kate_division, lagrange_interpolate} and the SHPLONK opening prover
+# (`poly::kzg::multiopen::shplonk::{construct_intermediate_sets, prover::ProverSHPLONK::create_proof}`;
+# selected by the reference at /root/reference/zkevm-circuits/benches/benchmark_list/main.rs:26,267 and
+# /root/reference/prover/src/test/proof_test.rs:297).  Restated from the published upstream algorithm.
+# ---------------------------------------------------------------------------------------------
+def kate_division(a, point: int):
+    """Coefficients of a(X) / (X - point), remainder dropped: upstream walks from the leading coefficient down,
+    q[i-1] = a[i] + point * q[i]."""
+    q = [0] * (len(a) - 1)
+    tmp = 0
+    for i in range(len(a) - 1, 0, -1):
+        lead = (a[i] + tmp) % P
+        q[i - 1] = lead
+        tmp = lead * point % P
+    return q
+
+
+def lagrange_interpolate(points, evals):
+    """Coefficients (lowest first) of the polynomial of degree < len(points) through (points[i], evals[i])."""
+    assert len(points) == len(evals)
+    n = len(points)
+    if n == 1:
+        return [evals[0] % P]
+    out = [0] * n
+    for j in range(n):
+        # numerator prod_{k != j} (X - x_k), denominator prod_{k != j} (x_j - x_k)
+        num = [1]
+        den = 1
+        for k in range(n):
+            if k == j:
+                continue
+            num = [((num[i - 1] if i > 0 else 0) - points[k] * (num[i] if i < len(num) else 0)) % P
+                   for i in range(len(num) + 1)]
+            den = den * (points[j] - points[k]) % P
+        scale = evals[j] * pow(den, P - 2, P) % P
+        for i in range(n):
+            out[i] = (out[i] + num[i] * scale) % P
+    return out
+
+
+def evaluate_vanishing_polynomial(roots, z: int) -> int:
+    acc = 1
+    for r in roots:
+        acc = acc * (z - r) % P
+    return acc
+
+
+def construct_intermediate_sets(queries):
+    """queries: list of (commitment_key, point, eval); commitment_key is any hashable identity of the polynomial.
+    Returns (rotation_sets, super_point_set): rotation_sets = [(points_sorted, [(commitment_key, evals)])] in upstream's
+    order (first appearance of the commitment, then first appearance of its point set); point sets are ordered as a
+    BTreeSet<Fr>, i.e. by canonical integer value."""
+    def get_eval(key, point):
+        for k, p, e in queries:
+            if k == key and p == point:
+                return e
+        raise KeyError
+    super_points = set()
+    commitment_map = []      # [(key, set(points))]
+    for key, point, _ in queries:
+        super_points.add(point)
+        for entry in commitment_map:
+            if entry[0] == key:
+                entry[1].add(point)
+                break
+        else:
+            commitment_map.append((key, {point}))
+    set_map = []             # [(frozenset(points), [keys])]
+    for key, pts in commitment_map:
+        fs = frozenset(pts)
+        for entry in set_map:
+            if entry[0] == fs:
+                entry[1].append(key)
+                break
+        else:
+            set_map.append((fs, [key]))
+    rotation_sets = []
+    for fs, keys in set_map:
+        pts = sorted(fs)
+        rotation_sets.append((pts, [(key, [get_eval(key, p) for p in pts]) for key in keys]))
+    return rotation_sets, sorted(super_points)
+
+
+def shplonk_create_proof(polys, queries, y: int, v: int, u: int, commit):
+    """polys: {key: coefficient list of length n}; queries as in construct_intermediate_sets; y, v, u: the three
+    transcript challenges in the order upstream squeezes them (u after the first commitment is written);
+    commit(coeffs) -> point.  Returns (h1_commitment, h2_commitment, h_x, final_poly)."""
+    n = len(next(iter(polys.values())))
+    rotation_sets, super_points = construct_intermediate_sets(queries)
+
+    def lincomb(items, base):
+        acc, power = None, 1
+        for poly in items:
+            scaled = [c * power % P for c in poly]
+            acc = scaled if acc is None else [(a + b) % P for a, b in zip(acc, scaled)]
+            power = power * base % P
+        return acc
+
+    ext = []   # per rotation set: (points, [(poly, low_degree_equivalent)])
+    for pts, commitments in rotation_sets:
+        ext.append((pts, [(polys[key], lagrange_interpolate(pts, evals)) for key, evals in commitments]))
+
+    quotients = []
+    for pts, cs in ext:
+        numerators = []
+        for poly, low in cs:
+            num = list(poly)
+            for i, r in enumerate(low):
+                num[i] = (num[i] - r) % P
+            numerators.append(num)
+        n_x = lincomb(numerators, y)
+        for p in pts:
+            n_x = kate_division(n_x, p)
+        quotients.append(n_x + [0] * (n - len(n_x)))
+    h_x = lincomb(quotients, v)
+    h1 = commit(h_x)
+
+    contributions, z_diffs = [], []
+    for pts, cs in ext:
+        diffs = [p for p in super_points if p not in pts]
+        z_i = evaluate_vanishing_polynomial(diffs, u)
+        inner = []
+        for poly, low in cs:
+            r_eval = eval_poly(low, u)
+            lp = list(poly)
+            lp[0] = (lp[0] - r_eval) % P
+            inner.append(lp)
+        l_i = lincomb(inner, y)
+        contributions.append([c * z_i % P for c in l_i])
+        z_diffs.append(z_i)
+    l_x = lincomb(contributions, v)
+    zt_eval = evaluate_vanishing_polynomial(super_points, u)
+    l_x = [(a - b * zt_eval) % P for a, b in zip(l_x, h_x)]
+    assert eval_poly(l_x, u) == 0, "linearisation polynomial does not vanish at u"
+    final = kate_division(l_x, u)
+    z0_inv = pow(z_diffs[0], P - 2, P)
+    final = [c * z0_inv % P for c in final]
+    h2 = commit(final)
+    return h1, h2, h_x, final

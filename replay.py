@@ -11,8 +11,8 @@ columns, in upstream's phase order:
   3. permutation:   per column set the grand product z, its commitment and iNTT
   4. quotient:      coeff_to_extended of every advice / instance / lookup polynomial, evaluate_h,
                     divide_by_vanishing_poly, extended_to_coeff, commitments of the d-1 pieces of h
-  5. openings:      eval_polynomial for every (polynomial, rotation) query, two MSMs for SHPLONK
-                    (the SHPLONK polynomial arithmetic between them is NOT replayed)
+  5. openings:      eval_polynomial for every (polynomial, rotation) query, then the SHPLONK multi-open over those
+                    queries: rotation sets, quotient and linearisation polynomials, Kate divisions, two commitments
 
 Witness generation, transcript hashing and the RNG stay on the host in the reference and are not part of this number.
 The default shape is the estimate for the k = 19 SuperCircuit (standard feature set): about 380 advice and 60 fixed
@@ -34,7 +34,7 @@ import torch  # noqa: E402
 import zkhip_pkg  # noqa: E402
 
 zk = zkhip_pkg.load()
-from zkevm_circuits_amd import evalh_host, ffi, synthetic  # noqa: E402
+from zkevm_circuits_amd import evalh_host, ffi, shplonk, synthetic  # noqa: E402
 
 
 def rand_fr_device(n, gen):
@@ -111,7 +111,7 @@ def main():
         h = torch.empty((en, 4), dtype=torch.int64, device="cuda")
         h_coeff = torch.empty((n * dom.quotient_poly_degree, 4), dtype=torch.int64, device="cuda")
     stream.synchronize()
-    sc = rand_fr_device(8, gen).cpu().numpy().view(np.uint64)
+    sc = rand_fr_device(12, gen).cpu().numpy().view(np.uint64)
     beta, gamma, theta, y, x = sc[0], sc[1], sc[2], sc[3], sc[4]
 
     def colptr(t, i, rows):
@@ -204,27 +204,66 @@ def main():
     ph.run("h_commit_msm", lambda: ctx.msm_batch_dev(bid, [colptr(h_coeff, i, n) for i in range(pieces)], n))
 
     # ---- 5. openings ------------------------------------------------------------------------------------
-    # one eval_polynomial per (polynomial, rotation) query: advice / fixed queries of the gates, 5 per lookup
-    # (z, z(omega x), a', a'(omega^-1 x), s'), 3 per permutation set, h pieces, plus the fixed / sigma polynomials
-    n_queries = 2 * A + F + 5 * L + 3 * sets + len(pcols) + pieces   # about two rotations per advice column
+    # one query per (polynomial, rotation): advice columns at the rotation patterns gates use (0 | 0,+1 | 0,-1 | 0,+1,-1),
+    # fixed and sigma polynomials at 0, per lookup z at (0,+1), a' at (0,-1), s' at 0, per permutation set z at
+    # (0, +1, last row), the random polynomial and the combined h polynomial at 0
+    FRP = shplonk.P
+    r_inv = pow(1 << 256, FRP - 2, FRP)
+    to_int = lambda limbs: sum(int(w) << (64 * j) for j, w in enumerate(limbs)) * r_inv % FRP
+    omega, x_int = to_int(dom.constant(0)), to_int(x)
+    last_rot = -(cs.blinding_factors() + 1)
+    shapes = []
+    adv_pat = [(0,), (0, 1), (0, -1), (0, 1, -1)]
+    shapes += [(colptr(advice, i, n), adv_pat[i % 4]) for i in range(A)]
+    shapes += [(colptr(fixed_ext, i, n), (0,)) for i in range(F)]              # stand-ins of the right size
+    shapes += [(colptr(sigma_lagrange, c, n), (0,)) for c in range(len(pcols))]
+    for i in range(L):
+        shapes += [(colptr(lk_z, i, n), (0, 1)), (colptr(lk_cols, 4 * i + 2, n), (0, -1)), (colptr(lk_cols, 4 * i + 3, n), (0,))]
+    shapes += [(colptr(perm_z, s_, n), (0, 1, last_rot)) for s_ in range(sets)]
+    shapes += [(colptr(h_coeff, 0, n), (0,)), (colptr(h_coeff, 1, n), (0,))]
+    points = {r: x_int * pow(omega, r % n, FRP) % FRP for r in {r for _, rots in shapes for r in rots}}
+    point_limbs = {r: np.array(evalh_host.fr_to_mont_limbs(p_), dtype=np.uint64) for r, p_ in points.items()}
+    n_queries = sum(len(rots) for _, rots in shapes)
+    queries = []
 
     def openings():
-        for q in range(n_queries):
-            ctx.eval_polynomial_dev(colptr(advice, q % A, n), n, x)
+        for key, (ptr, rots) in enumerate(shapes):
+            for r in rots:
+                queries.append(shplonk.Query(key, points[r], to_int(ctx.eval_polynomial_dev(ptr, n, point_limbs[r]))))
     ph.run("eval_polynomial", openings)
-    ph.run("shplonk_msm", lambda: ctx.msm_batch_dev(bid, [colptr(advice, 0, n), colptr(advice, 1, n)], n))
+
+    class Transcript:   # the Blake2b transcript stays on the host in the reference; challenges are stand-ins
+        def __init__(self):
+            self.i = 5
+        def squeeze_challenge(self):
+            self.i += 1
+            return to_int(sc[self.i])
+        def write_point(self, jac):
+            pass
+    polys = {key: ptr for key, (ptr, _) in enumerate(shapes)}
+    prover = shplonk.ProverSHPLONK(ctx, bid, n)
+    ctx.timing_enable(True)
+    ctx.timing_reset()
+    outs = ph.run("shplonk_multiopen", lambda: prover.create_proof(polys, queries, Transcript()))
+    lincomb_us, lincomb_n = ctx.timing_get("poly_lincomb")
+    kate_us, kate_n = ctx.timing_get("kate_division")
+    ctx.timing_enable(False)
+    for p_ in outs:
+        ctx.free(p_)
 
     total = sum(ph.t.values())
     msm_s = sum(v for kk, v in ph.t.items() if kk.endswith("_msm"))
-    n_msm = A + 3 * L + sets + 1 + pieces + 2
+    n_msm = A + 3 * L + sets + 1 + pieces
     line = {
         "what": "replay of the create_proof polynomial pipeline on synthetic columns (one MI355X); host-side witness "
-                "generation, lookup sorting, transcript and SHPLONK polynomial arithmetic are not included",
+                "generation, lookup sorting and transcript hashing are not included",
         "shape": {"k": k, "extended_k": ek, "advice": A, "fixed": F, "instance": I, "lookups": L,
                   "lookup_width": args.lookup_width, "permutation_columns": len(pcols), "permutation_sets": sets,
                   "degree": d, "gate_polynomials": args.gate_polys},
         "total_s": total, "phases_s": ph.t, "msm_count": n_msm, "msm_total_s": msm_s, "msm_ms_each": msm_s / n_msm * 1e3,
         "coset_ntt_count": A + I + 3 * L + sets, "evalh_kernel_ms": evalh_kernel_ms, "eval_polynomial_count": n_queries,
+        "shplonk": {"polynomials": len(shapes), "queries": n_queries, "poly_lincomb_calls": lincomb_n,
+                    "poly_lincomb_avg_us": lincomb_us, "kate_division_calls": kate_n, "kate_division_avg_us": kate_us},
         "host_program_build_s": host_setup_s,
         "device_memory_GB": torch.cuda.max_memory_allocated() / 1e9,
     }

@@ -8,6 +8,10 @@ for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
     if p not in sys.path:
         sys.path.insert(0, p)
 
+# torch first: its bundled HIP runtime must be the one the process loads, whichever test file is collected first
+# (libzkhip.so then binds to the same runtime; two runtimes in one process do not both see the GPU)
+import torch  # noqa: E402,F401
+
 import zkhip_pkg  # noqa: E402
 
 zkhip_pkg.load()

@@ -388,6 +388,118 @@ def gen_products():
     dump("products.json", out)
 
 
+def poly_divmod(a, b):
+    """schoolbook long division of coefficient lists (lowest first): a = q b + r"""
+    a = list(a)
+    q = [0] * max(1, len(a) - len(b) + 1)
+    lead_inv = pow(b[-1], P - 2, P)
+    for i in range(len(a) - len(b), -1, -1):
+        f = a[i + len(b) - 1] * lead_inv % P
+        q[i] = f
+        for j, bj in enumerate(b):
+            a[i + j] = (a[i + j] - f * bj) % P
+    return q, a[:len(b) - 1]
+
+
+def gen_shplonk():
+    """SHPLONK opening from its definition: h(X) = sum_i v^i (sum_j y^j (P_ij - R_ij)) / Z_i by schoolbook long
+    division with the expanded vanishing polynomial (remainder checked to be zero), R_ij by solving the interpolation
+    conditions, the final quotient L(X) / (X - u) / z_0 again by long division.  Commitments are taken against the bases
+    (i + 1) G, where sum_i c_i (i + 1) G needs one scalar multiplication."""
+    rnd = random.Random(SEED + 11)
+    out = {"comment": "canonical hex; queries = [poly index, point, eval]; bases are (i+1)G", "cases": [],
+           "kate_division": [], "lincomb": []}
+    for k, shape in [(3, [(0,), (0, 1)]), (5, [(0, 1, -1), (0,), (0, 1), (0,), (0, 1, -1), (-2,)])]:
+        n = 1 << k
+        dom = hm.EvaluationDomain(3, k)
+        x = rnd.randrange(1, P)
+        polys = [[rnd.randrange(P) for _ in range(n)] for _ in shape]
+        queries = []
+        for r_idx in range(3):
+            for key, rots in enumerate(shape):
+                if r_idx < len(rots):
+                    pnt = dom.rotate_omega(x, rots[r_idx])
+                    queries.append((key, pnt, sum(c * pow(pnt, i, P) for i, c in enumerate(polys[key])) % P))
+        y, v, u = rnd.randrange(P), rnd.randrange(P), rnd.randrange(P)
+        # group by point set, in order of first appearance of each polynomial, then of each set
+        point_sets = {}
+        for key, pnt, _ in queries:
+            point_sets.setdefault(key, set()).add(pnt)
+        groups = []
+        for key in sorted(point_sets, key=lambda kk: [q[0] for q in queries].index(kk)):
+            fs = frozenset(point_sets[key])
+            for gset, keys in groups:
+                if gset == fs:
+                    keys.append(key)
+                    break
+            else:
+                groups.append((fs, [key]))
+        all_points = sorted({pnt for _, pnt, _ in queries})
+
+        def expand(roots):
+            z = [1]
+            for r in roots:
+                z = [((z[i - 1] if i else 0) - r * (z[i] if i < len(z) else 0)) % P for i in range(len(z) + 1)]
+            return z
+
+        def add_scaled(acc, poly, c):
+            return [((acc[i] if i < len(acc) else 0) + c * (poly[i] if i < len(poly) else 0)) % P
+                    for i in range(max(len(acc), len(poly)))]
+
+        h_x, l_x, z_diffs = [0] * n, [0] * n, []
+        for i, (fs, keys) in enumerate(groups):
+            pts = sorted(fs)
+            z_i_poly = expand(pts)
+            z_diff = 1
+            for p_ in all_points:
+                if p_ not in fs:
+                    z_diff = z_diff * (u - p_) % P
+            z_diffs.append(z_diff)
+            num, lin = [0] * n, [0] * n
+            for j, key in enumerate(keys):
+                # R = P mod Z_i is the unique polynomial of degree < |points| agreeing with P on the points
+                _, r = poly_divmod(polys[key], z_i_poly)
+                for pnt in pts:
+                    ev = [e for kk, pp, e in queries if kk == key and pp == pnt][0]
+                    assert sum(c * pow(pnt, t, P) for t, c in enumerate(r)) % P == ev
+                num = add_scaled(num, add_scaled(polys[key], r, P - 1), pow(y, j, P))
+                r_u = sum(c * pow(u, t, P) for t, c in enumerate(r)) % P
+                lin = add_scaled(lin, add_scaled(polys[key], [r_u], P - 1), pow(y, j, P))
+            q, rem = poly_divmod(num, z_i_poly)
+            assert not any(rem)
+            h_x = add_scaled(h_x, q, pow(v, i, P))
+            l_x = add_scaled(l_x, lin, pow(v, i, P) * z_diff % P)
+        zt = 1
+        for p_ in all_points:
+            zt = zt * (u - p_) % P
+        l_x = add_scaled(l_x, h_x, (P - zt) % P)
+        fin, rem = poly_divmod(l_x, [(P - u) % P, 1])
+        assert not any(rem)
+        z0_inv = pow(z_diffs[0], P - 2, P)
+        fin = [c * z0_inv % P for c in fin]
+        commit = lambda cs: bn.g1_mul(bn.G1_GENERATOR, sum(c * (i + 1) for i, c in enumerate(cs)) % P)
+        h1, h2 = commit(h_x), commit(fin)
+        model = hm.shplonk_create_proof(dict(enumerate(polys)), queries, y, v, u, commit)
+        assert model == (h1, h2, h_x, fin)
+        out["cases"].append({"k": k, "polys": [[hx(c) for c in p_] for p_ in polys],
+                             "queries": [[key, hx(pnt), hx(ev)] for key, pnt, ev in queries], "y": hx(y), "v": hx(v),
+                             "u": hx(u), "h_x": [hx(c) for c in h_x], "final": [hx(c) for c in fin], "h1": pt(h1),
+                             "h2": pt(h2)})
+    for n in (2, 7, 33):
+        a = [rnd.randrange(P) for _ in range(n)]
+        z = rnd.randrange(P)
+        q, _ = poly_divmod(a, [(P - z) % P, 1])
+        assert hm.kate_division(a, z) == q
+        out["kate_division"].append({"a": [hx(c) for c in a], "point": hx(z), "q": [hx(c) for c in q]})
+    lens = [9, 4, 9, 1, 6]
+    ps = [[rnd.randrange(P) for _ in range(l)] for l in lens]
+    cs = [rnd.randrange(P), 0, P - 1, 1, rnd.randrange(P)]
+    res = [sum(c * p_[i] for c, p_ in zip(cs, ps) if i < len(p_)) % P for i in range(9)]
+    out["lincomb"].append({"polys": [[hx(c) for c in p_] for p_ in ps], "coeffs": [hx(c) for c in cs],
+                           "n": 9, "out": [hx(c) for c in res]})
+    dump("shplonk.json", out)
+
+
 if __name__ == "__main__":
     bn.self_check()
     gen_field()
@@ -398,3 +510,4 @@ if __name__ == "__main__":
     gen_domain()
     gen_evalh()
     gen_products()
+    gen_shplonk()

@@ -524,5 +524,169 @@ def test_replay_script_small_shape(ctx, capsys, monkeypatch):
                                       "--gate-polys", "20", "--degree", "5", "--perm-cols", "5"])
     runpy.run_path(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "replay.py"), run_name="__main__")
     line = json.loads(capsys.readouterr().out.strip().splitlines()[-1])
-    assert line["msm_count"] == 9 + 3 * 3 + line["shape"]["permutation_sets"] + 1 + 4 + 2
-    assert {"evaluate_h", "coeff_to_extended", "advice_commit_msm", "eval_polynomial"} <= set(line["phases_s"])
+    assert line["msm_count"] == 9 + 3 * 3 + line["shape"]["permutation_sets"] + 1 + 4
+    assert {"evaluate_h", "coeff_to_extended", "advice_commit_msm", "eval_polynomial", "shplonk_multiopen"} <= set(line["phases_s"])
+    assert line["shplonk"]["queries"] == line["eval_polynomial_count"] and line["shplonk"]["kate_division_calls"] >= 4
+
+
+# ------------------------------------------------------------------------------------------------ SHPLONK opening
+@pytest.mark.parametrize("n,num", [(1, 1), (5, 2), (256, 3), (2049, 7), (70001, 66), (1 << 16, 131)])
+def test_poly_lincomb(ctx, n, num):
+    """sum_k c_k p_k with ragged lengths, odd and even term counts, more terms than one folding interval, aliasing."""
+    rng = np.random.default_rng(n + num)
+    lens = [n if k % 3 != 1 else max(1, n // (k + 1)) for k in range(num)]
+    polys = [rand_fr(rng, l) for l in lens]
+    coeffs = rand_fr(rng, num)
+    if num > 2:
+        coeffs[1] = 0
+        coeffs[2] = fr_arr([P - 1])[0]
+    d_polys = [ctx.upload(p) for p in polys]
+    d_out = ctx.alloc(n * 32)
+    ctx.poly_lincomb_dev(d_polys, lens, coeffs, n, d_out)
+    got = fr_ints(ctx.download(d_out, (n, 4)))
+    cs = fr_ints(coeffs)
+    ps = [fr_ints(p) for p in polys]
+    check = range(n) if n <= 4096 else [0, 1, 2, n // 7, n // 3, n // 2, n - 2, n - 1]
+    for i in check:
+        assert got[i] == sum(c * p[i] for c, p in zip(cs, ps) if i < len(p)) % P, i
+    # in place on the first polynomial (full length)
+    ctx.poly_lincomb_dev(d_polys, lens, coeffs, n, d_polys[0])
+    assert np.array_equal(ctx.download(d_polys[0], (n, 4)), ctx.download(d_out, (n, 4)))
+    for p in d_polys + [d_out]:
+        ctx.free(p)
+
+
+def test_poly_lincomb_empty_and_errors(ctx):
+    d_out = ctx.upload(rand_fr(np.random.default_rng(0), 8))
+    ctx.poly_lincomb_dev([], [], np.zeros((0, 4), np.uint64), 8, d_out)     # empty sum = zero polynomial
+    assert not ctx.download(d_out, (8, 4)).any()
+    with pytest.raises(ffi.ZkhipError):
+        ctx.poly_lincomb_dev([d_out], [9], fr_arr([1]), 8, d_out)           # longer than the output
+    ctx.free(d_out)
+
+
+@pytest.mark.parametrize("n", [2, 3, 8, 9, 2047, 2048, 2049, 70001, 1 << 19, (1 << 20) + 5])
+def test_kate_division(ctx, n):
+    import halo2_model as hm
+    rng = np.random.default_rng(n)
+    a = rand_fr(rng, n)
+    z = rand_fr(rng, 1)[0]
+    d_a, d_q = ctx.upload(a), ctx.alloc(n * 32)
+    ctx.kate_division_dev(d_a, n, z, d_q)
+    q = ctx.download(d_q, (n - 1, 4))
+    zi = fr_ints(z[None])[0]
+    if n <= 70001:
+        assert fr_ints(q) == hm.kate_division(fr_ints(a), zi)
+    else:
+        # a(X) - a(z) = q(X) (X - z) at a random x, and the top / bottom coefficients from the recurrence
+        x = rand_fr(rng, 1)[0]
+        xi = fr_ints(x[None])[0]
+        ax, az = (fr_ints(ctx.eval_polynomial_dev(d_a, n, w)[None])[0] for w in (x, z))
+        qx = fr_ints(ctx.eval_polynomial_dev(d_q, n - 1, x)[None])[0]
+        assert (ax - az) % P == qx * (xi - zi) % P
+        ai, qi = fr_ints(a[-3:]), fr_ints(q[-2:])
+        assert qi[1] == ai[2] and qi[0] == (ai[1] + zi * ai[2]) % P
+        assert (fr_ints(a[:1])[0] + zi * fr_ints(q[:1])[0]) % P == az
+    ctx.free(d_a)
+    ctx.free(d_q)
+
+
+class _ReplayTranscript:
+    """Stands in for the Blake2b transcript: hands out preset challenges, records the points written."""
+
+    def __init__(self, challenges):
+        self.challenges, self.points = list(challenges), []
+
+    def squeeze_challenge(self):
+        return self.challenges.pop(0)
+
+    def write_point(self, jac):
+        self.points.append(np.array(jac, dtype=np.uint64))
+
+
+def _shplonk_case(rng, k, shape):
+    """shape: list of rotation tuples, one per polynomial, as halo2 queries them (advice at 0 / +1 / -1, fixed at 0, a
+    permutation product at 0, +1 and last row ...).  Returns polys (canonical coefficients) and consistent queries."""
+    import halo2_model as hm
+    n = 1 << k
+    dom = hm.EvaluationDomain(3, k)
+    x = int(rng.integers(1, 2 ** 62))
+    polys, queries = {}, []
+    for key, rots in enumerate(shape):
+        polys[key] = fr_ints(rand_fr(rng, n))
+    # halo2 orders queries by argument, not by polynomial: interleave the rotations across polynomials
+    for r_idx in range(max(len(r) for r in shape)):
+        for key, rots in enumerate(shape):
+            if r_idx < len(rots):
+                pt = dom.rotate_omega(x, rots[r_idx])
+                queries.append((key, pt, hm.eval_poly(polys[key], pt)))
+    return polys, queries
+
+
+@pytest.mark.parametrize("k,shape", [
+    (5, [(0,)]),
+    (6, [(0,), (0, 1), (0, 1), (0, -1, 1), (0,), (1,)]),
+    (9, [(0, 1, -1)] * 3 + [(0,)] * 5 + [(0, 1)] * 2 + [(0, 1, -5)] + [(-1, 0)]),
+    (12, [(0,), (0, 1), (0, 1, -3), (0,)]),
+])
+def test_shplonk_create_proof_vs_model(ctx, co, k, shape):
+    """The device SHPLONK prover against the big-int model: both quotient polynomials coefficient by coefficient, and
+    both commitments against the closed form for bases (i+1)G."""
+    import halo2_model as hm
+    from zkevm_circuits_amd import shplonk
+    n = 1 << k
+    rng = np.random.default_rng(k)
+    polys, queries = _shplonk_case(rng, k, shape)
+    y, v, u = (int(c) for c in rng.integers(2, 2 ** 62, size=3))
+    commit = lambda coeffs: bn.g1_mul(bn.G1_GENERATOR, sum(c * (i + 1) for i, c in enumerate(coeffs)) % P)
+    h1, h2, h_x, final = hm.shplonk_create_proof(polys, queries, y, v, u, commit)
+
+    bid = ctx.register_bases(co.g1_bases(n))
+    d_polys = {key: ctx.upload(fr_arr(c)) for key, c in polys.items()}
+    tr = _ReplayTranscript([y, v, u])
+    prover = shplonk.ProverSHPLONK(ctx, bid, n)
+    d_h, d_f = prover.create_proof(d_polys, [shplonk.Query(*q) for q in queries], tr)
+    assert fr_ints(ctx.download(d_h, (n, 4))) == h_x
+    assert fr_ints(ctx.download(d_f, (n, 4))) == final + [0]
+    assert [affine_pt(ctx.g1_to_affine(p)) for p in tr.points] == [h1, h2]
+    assert not tr.challenges
+    # inconsistent evaluation: the linearisation polynomial cannot vanish at u
+    bad = [shplonk.Query(*q) for q in queries]
+    bad[0].eval = (bad[0].eval + 1) % P
+    with pytest.raises(ValueError):
+        prover.create_proof(d_polys, bad, _ReplayTranscript([y, v, u]))
+    for p in list(d_polys.values()) + [d_h, d_f]:
+        ctx.free(p)
+    ctx.release_bases(bid)
+
+
+def test_shplonk_golden(ctx, co):
+    from zkevm_circuits_amd import shplonk
+    g = golden("shplonk.json")
+    for c in g["cases"]:
+        n = 1 << c["k"]
+        bid = ctx.register_bases(co.g1_bases(n))
+        d_polys = {i: ctx.upload(hex_fr(p)) for i, p in enumerate(c["polys"])}
+        tr = _ReplayTranscript([int(c[name], 16) for name in ("y", "v", "u")])
+        queries = [shplonk.Query(key, int(pt, 16), int(ev, 16)) for key, pt, ev in c["queries"]]
+        d_h, d_f = shplonk.ProverSHPLONK(ctx, bid, n).create_proof(d_polys, queries, tr)
+        assert np.array_equal(ctx.download(d_h, (n, 4)), hex_fr(c["h_x"]))
+        assert np.array_equal(ctx.download(d_f, (n - 1, 4)), hex_fr(c["final"]))
+        assert [affine_pt(ctx.g1_to_affine(p)) for p in tr.points] == [hex_pt(c["h1"]), hex_pt(c["h2"])]
+        for p in list(d_polys.values()) + [d_h, d_f]:
+            ctx.free(p)
+        ctx.release_bases(bid)
+    for c in g["kate_division"]:
+        a = hex_fr(c["a"])
+        d_a, d_q = ctx.upload(a), ctx.alloc(len(a) * 32)
+        ctx.kate_division_dev(d_a, len(a), hex_fr([c["point"]])[0], d_q)
+        assert np.array_equal(ctx.download(d_q, (len(a) - 1, 4)), hex_fr(c["q"]))
+        ctx.free(d_a)
+        ctx.free(d_q)
+    for c in g["lincomb"]:
+        d_ps = [ctx.upload(hex_fr(p)) for p in c["polys"]]
+        d_o = ctx.alloc(c["n"] * 32)
+        ctx.poly_lincomb_dev(d_ps, [len(p) for p in c["polys"]], hex_fr(c["coeffs"]), c["n"], d_o)
+        assert np.array_equal(ctx.download(d_o, (c["n"], 4)), hex_fr(c["out"]))
+        for p in d_ps + [d_o]:
+            ctx.free(p)

@@ -122,3 +122,22 @@ def test_partition_helpers():
     for idx in range(1 << ek):
         for rot in (-5, -1, 1, 3):
             assert ((idx + rot * (1 << e)) % (1 << ek)) % (1 << e) == idx % (1 << e)
+
+
+def test_shplonk_intermediate_sets_match_model():
+    import halo2_model as hm
+    from zkevm_circuits_amd import shplonk
+    rng = np.random.default_rng(3)
+    pts = [int(x) for x in rng.integers(1, 2 ** 62, size=4)]
+    queries = [(0, pts[0], 11), (1, pts[0], 12), (1, pts[1], 13), (2, pts[1], 14), (2, pts[0], 15), (3, pts[2], 16),
+               (0, pts[0], 11), (4, pts[3], 17), (4, pts[2], 18), (5, pts[2], 19)]
+    a = hm.construct_intermediate_sets(queries)
+    b = shplonk.construct_intermediate_sets([shplonk.Query(*q) for q in queries])
+    assert a == b
+    sets, sup = b
+    assert sup == sorted(set(pts))
+    assert [[key for key, _ in cs] for _, cs in sets] == [[0], [1, 2], [3, 5], [4]]
+    assert sets[1][0] == sorted([pts[0], pts[1]]) and dict(sets[1][1])[2] == [15, 14] if pts[0] < pts[1] else [14, 15]
+    for points in ([5], [5, 9], [2, 3, 11, 17]):
+        ev = [int(x) for x in rng.integers(0, 2 ** 62, size=len(points))]
+        assert shplonk.lagrange_interpolate(points, ev) == hm.lagrange_interpolate(points, ev)

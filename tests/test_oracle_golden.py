@@ -169,6 +169,23 @@ def test_grand_products_golden():
         assert hm.eval_poly(ints(c["coeff"]), int(c["x"], 16)) == int(c["value"], 16)
 
 
+def test_shplonk_golden():
+    """the model's Kate-division / interpolation formulation of the SHPLONK prover against the long-division derivation
+    stored in shplonk.json"""
+    g = golden("shplonk.json")
+    ints = lambda hs: [int(h, 16) for h in hs]
+    Pm = bn.FR_MODULUS
+    commit = lambda cs: bn.g1_mul(bn.G1_GENERATOR, sum(c * (i + 1) for i, c in enumerate(cs)) % Pm)
+    for c in g["cases"]:
+        polys = {i: ints(p) for i, p in enumerate(c["polys"])}
+        queries = [(key, int(pt, 16), int(ev, 16)) for key, pt, ev in c["queries"]]
+        h1, h2, h_x, fin = hm.shplonk_create_proof(polys, queries, int(c["y"], 16), int(c["v"], 16), int(c["u"], 16), commit)
+        assert h_x == ints(c["h_x"]) and fin == ints(c["final"])
+        assert [h1, h2] == [(int(p[0], 16), int(p[1], 16)) for p in (c["h1"], c["h2"])]
+    for c in g["kate_division"]:
+        assert hm.kate_division(ints(c["a"]), int(c["point"], 16)) == ints(c["q"])
+
+
 def test_model_multiexp_threads_agree():
     rnd = np.random.default_rng(5)
     n = 40

@@ -6,6 +6,9 @@
 //   `plonk::permutation::prover::Argument::commit`     -> zkhip_permutation_product_dev   (one column set)
 //   `plonk::lookup::prover::Permuted::commit_product`  -> zkhip_lookup_product_dev
 //   `arithmetic::eval_polynomial`                      -> zkhip_eval_polynomial_dev
+//   `arithmetic::kate_division`                        -> zkhip_kate_division_dev
+//   sums of scaled polynomials (`poly * scalar`, `+`), as the SHPLONK prover forms them for its quotient and
+//   linearisation polynomials (`poly::kzg::multiopen::shplonk::prover`)   -> zkhip_poly_lincomb_dev
 //
 // The blinding rows are left to the caller: upstream draws them from the prover's RNG in a fixed order, so the host
 // overwrites the last `blinding_factors` rows of z after these calls and reads last_z from row n - blinding - 1.
@@ -15,6 +18,7 @@
 #include <vector>
 #include "common.h"
 #include "domain.h"
+#include "wide.cuh"
 
 using namespace zkhip;
 
@@ -210,6 +214,152 @@ __global__ void __launch_bounds__(PO_THREADS) eval_poly_kernel(const fe* coeff, 
     if (threadIdx.x == 0) store_fe(partial + blockIdx.x, sh[0]);
 }
 
+// ---- sum of scaled polynomials -----------------------------------------------------------------------
+// out[i] = sum_k c_k p_k[i] (p_k zero beyond its own length).  The table holds, per polynomial, its device pointer,
+// its length and the coefficient; all lanes of a launch walk it together, so it is read with scalar loads.  Terms
+// are taken two at a time: two products share one Montgomery reduction in the lazy digit form.
+struct LincombTerm {
+    const fe* poly;
+    uint64_t len;
+    uint32_t coeff[8];
+};
+constexpr int LC_PER = 2;   // elements per lane
+__global__ void __launch_bounds__(PO_THREADS) poly_lincomb_kernel(const LincombTerm* terms_generic, uint32_t num, size_t n, fe* out) {
+    const LincombTerm __attribute__((address_space(4)))* terms =
+        (const LincombTerm __attribute__((address_space(4)))*)(uintptr_t)terms_generic;
+    const size_t i0 = ((size_t)blockIdx.x * PO_THREADS + threadIdx.x) * LC_PER;
+    if (i0 >= n) return;
+    fw acc[LC_PER];
+#pragma unroll
+    for (int e = 0; e < LC_PER; e++) acc[e] = FrW::zero();
+    uint32_t since = 0;
+    for (uint32_t k = 0; k < num; k += 2) {
+        const bool two = k + 1 < num;
+        fe c0, c1;
+#pragma unroll
+        for (int w = 0; w < 8; w++) {
+            c0.l[w] = terms[k].coeff[w];
+            c1.l[w] = two ? terms[k + 1].coeff[w] : 0u;
+        }
+        const fe* p0 = (const fe*)terms[k].poly;
+        const fe* p1 = two ? (const fe*)terms[k + 1].poly : p0;
+        const size_t l0 = terms[k].len, l1 = two ? (size_t)terms[k + 1].len : 0;
+        const fw w0 = FrW::from_fe_shl5(c0), w1 = FrW::from_fe_shl5(c1);
+#pragma unroll
+        for (int e = 0; e < LC_PER; e++) {
+            const size_t i = i0 + e;
+            fe v0 = Fr::zero(), v1 = Fr::zero();
+            if (i < l0) v0 = load_fe(p0 + i);
+            if (i < l1) v1 = load_fe(p1 + i);
+            acc[e] = FrW::norm(FrW::add(acc[e], FrW::mul_add_mul(w0, FrW::from_fe(v0), w1, FrW::from_fe(v1))));
+        }
+        // a pair adds less than 1.5 p; fold the sum back below p long before the 64 p limit of to_fe
+        if (++since == 32) {
+            since = 0;
+#pragma unroll
+            for (int e = 0; e < LC_PER; e++) acc[e] = FrW::from_fe(FrW::to_fe(acc[e]));
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < LC_PER; e++)
+        if (i0 + e < n) store_fe(out + i0 + e, FrW::to_fe(acc[e]));
+}
+
+// ---- division by (X - z) -------------------------------------------------------------------------------
+// q_j = S_(j+1) with S_j = a_j + z S_(j+1) (S_n = 0): a backward Horner recurrence.  A lane owns KD_PER consecutive
+// coefficients; first every lane runs the recurrence from zero, the lane results are chained by a suffix scan with the
+// powers z^(KD_PER 2^d) inside the block and z^(KD_BLOCK 2^d) over the blocks, and a second sweep reruns the recurrence
+// from each lane's true incoming value.  pw: [0..8) = z^(KD_PER 2^d), [8..16) = z^(KD_BLOCK 2^d), [16..272) = z^(KD_PER t).
+constexpr int KD_PER = 8;
+constexpr int KD_BLOCK = PO_THREADS * KD_PER;
+
+// suffix scan over the lanes of a block: on return lane t holds sum_{u >= t} v_u w^(u - t), w = step[0]; step[d] = w^(2^d)
+__device__ __forceinline__ fe block_suffix_horner(fe v, const fe* step, fe* sh /*[PO_THREADS]*/) {
+    const uint32_t tid = threadIdx.x;
+    sh[tid] = v;
+    __syncthreads();
+    int d = 0;
+    for (uint32_t off = 1; off < PO_THREADS; off <<= 1, d++) {
+        fe other;
+        const bool take = tid + off < PO_THREADS;
+        if (take) other = sh[tid + off];
+        __syncthreads();
+        if (take) {
+            v = Fr::add(v, Fr::mul(load_fe(step + d), other));
+            sh[tid] = v;
+        }
+        __syncthreads();
+    }
+    return v;
+}
+
+__global__ void __launch_bounds__(PO_THREADS) kate_local_kernel(const fe* a, size_t n, fe z, const fe* pw, fe* lane_in, fe* block_tot) {
+    __shared__ fe sh[PO_THREADS];
+    const size_t base = (size_t)blockIdx.x * KD_BLOCK + (size_t)threadIdx.x * KD_PER;
+    fe s = Fr::zero();
+#pragma unroll
+    for (int k = KD_PER - 1; k >= 0; k--) {
+        const size_t i = base + k;
+        s = Fr::mul(s, z);
+        if (i < n) s = Fr::add(s, load_fe(a + i));
+    }
+    const fe incl = block_suffix_horner(s, pw, sh);   // value at this lane's first coefficient, zero beyond the block
+    // value entering this lane from above (at the next lane's first coefficient), still without the block's carry
+    __syncthreads();
+    sh[threadIdx.x] = incl;
+    __syncthreads();
+    const fe in = threadIdx.x + 1 < PO_THREADS ? sh[threadIdx.x + 1] : Fr::zero();
+    store_fe(lane_in + (size_t)blockIdx.x * PO_THREADS + threadIdx.x, in);
+    if (threadIdx.x == 0) store_fe(block_tot + blockIdx.x, incl);
+}
+// one block: block_tot[b] <- value entering block b from above = sum_{c > b} tot_c z^(KD_BLOCK (c - b - 1))
+__global__ void __launch_bounds__(PO_THREADS) kate_blocks_kernel(fe* block_tot, size_t nblocks, const fe* pw) {
+    __shared__ fe sh[PO_THREADS];
+    __shared__ fe carry_s;
+    // chunks of PO_THREADS blocks from the top down; carry = value entering the chunk from above
+    fe carry = Fr::zero();
+    const size_t nchunks = (nblocks + PO_THREADS - 1) / PO_THREADS;
+    fe wchunk = load_fe(pw + 8 + 7);   // z^(KD_BLOCK 128)
+    wchunk = Fr::sqr(wchunk);          // z^(KD_BLOCK 256): one chunk further
+    for (size_t ch = nchunks; ch-- > 0;) {
+        const size_t b = ch * PO_THREADS + threadIdx.x;
+        const fe v = b < nblocks ? load_fe(block_tot + b) : Fr::zero();
+        const fe incl = block_suffix_horner(v, pw + 8, sh);   // sum_{c >= b in chunk} tot_c w^(c - b)
+        __syncthreads();
+        sh[threadIdx.x] = incl;
+        __syncthreads();
+        // entering block b: blocks above it in the chunk, plus the carry moved down over the PO_THREADS - 1 - tid
+        // blocks between b and the top of the chunk
+        fe in = threadIdx.x + 1 < PO_THREADS ? sh[threadIdx.x + 1] : Fr::zero();
+        fe p = Fr::one(), bs = load_fe(pw + 8);
+        for (uint32_t e = PO_THREADS - 1 - threadIdx.x; e; e >>= 1) {
+            if (e & 1) p = Fr::mul(p, bs);
+            bs = Fr::sqr(bs);
+        }
+        in = Fr::add(in, Fr::mul(p, carry));
+        if (b < nblocks) store_fe(block_tot + b, in);
+        if (threadIdx.x == 0) carry_s = Fr::add(incl, Fr::mul(wchunk, carry));
+        __syncthreads();
+        carry = carry_s;
+        __syncthreads();
+    }
+}
+__global__ void __launch_bounds__(PO_THREADS) kate_apply_kernel(const fe* a, size_t n, fe z, const fe* pw, const fe* lane_in,
+                                                                const fe* block_in, fe* q) {
+    const size_t base = (size_t)blockIdx.x * KD_BLOCK + (size_t)threadIdx.x * KD_PER;
+    // incoming value: the block-local part plus the block's carry moved down over the lanes above this one
+    fe s = Fr::add(load_fe(lane_in + (size_t)blockIdx.x * PO_THREADS + threadIdx.x),
+                   Fr::mul(load_fe(pw + 16 + (PO_THREADS - 1 - threadIdx.x)), load_fe(block_in + blockIdx.x)));
+#pragma unroll
+    for (int k = KD_PER - 1; k >= 0; k--) {
+        const size_t i = base + k;
+        // here s = S_(i+1); q_i = S_(i+1) for i <= n - 2
+        if (i + 1 < n) store_fe(q + i, s);
+        s = Fr::mul(s, z);
+        if (i < n) s = Fr::add(s, load_fe(a + i));
+    }
+}
+
 // ---- launch helpers ----------------------------------------------------------------------------------
 static fe fe_from(const uint64_t v[4]) {
     fe o;
@@ -374,6 +524,75 @@ int zkhip_eval_polynomial_dev(zkhip_ctx* ctx, const uint64_t* d_coeff, size_t n,
     uint64_t acc[4] = {0, 0, 0, 0};
     for (size_t b = 0; b < nblocks; b++) h_add(HFR, acc, acc, &part[4 * b]);
     memcpy(out, acc, 32);
+    return ZKHIP_OK;
+}
+
+int zkhip_poly_lincomb_dev(zkhip_ctx* ctx, const uint64_t* const* d_polys, const size_t* lens, const uint64_t* coeffs,
+                           uint32_t num, size_t n, uint64_t* d_out) {
+    if (!ctx) return ZKHIP_ERR_INVALID;
+    ZK_CHECK(ctx, (d_polys && lens && coeffs) || num == 0, "poly_lincomb: null table");
+    ZK_CHECK(ctx, d_out || n == 0, "poly_lincomb: null output");
+    if (n == 0) return ZKHIP_OK;
+    for (uint32_t k = 0; k < num; k++) {
+        ZK_CHECK(ctx, d_polys[k] || lens[k] == 0, "poly_lincomb: null polynomial %u", k);
+        ZK_CHECK(ctx, lens[k] <= n, "poly_lincomb: polynomial %u has %zu coefficients, output has %zu", k, lens[k], n);
+    }
+    ZK_HIP(ctx, hipSetDevice(ctx->device));
+    int rc = ensure_scratch(ctx, ((size_t)num + 1) * sizeof(LincombTerm));
+    if (rc) return rc;
+    std::vector<LincombTerm> terms(num);
+    for (uint32_t k = 0; k < num; k++) {
+        terms[k].poly = (const fe*)d_polys[k];
+        terms[k].len = lens[k];
+        memcpy(terms[k].coeff, coeffs + 4 * (size_t)k, 32);
+    }
+    if (num) {
+        ZK_HIP(ctx, hipMemcpyAsync(ctx->scratch, terms.data(), num * sizeof(LincombTerm), hipMemcpyHostToDevice, ctx->stream));
+        // the table is pageable host memory that dies with this call
+        ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    TimedRegion tr(ctx, "poly_lincomb");
+    const size_t lanes = (n + LC_PER - 1) / LC_PER;
+    hipLaunchKernelGGL(poly_lincomb_kernel, dim3((unsigned)((lanes + PO_THREADS - 1) / PO_THREADS)), dim3(PO_THREADS), 0,
+                       ctx->stream, (const LincombTerm*)ctx->scratch, num, n, (fe*)d_out);
+    ZK_HIP(ctx, hipGetLastError());
+    return ZKHIP_OK;
+}
+
+int zkhip_kate_division_dev(zkhip_ctx* ctx, const uint64_t* d_poly, size_t n, const uint64_t point[4], uint64_t* d_out) {
+    if (!ctx) return ZKHIP_ERR_INVALID;
+    ZK_CHECK(ctx, n >= 1, "kate_division: empty polynomial");
+    ZK_CHECK(ctx, d_poly && point && (d_out || n == 1), "kate_division: null pointer");
+    if (n == 1) return ZKHIP_OK;   // the quotient of a constant has no coefficients
+    ZK_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t nblocks = (n + KD_BLOCK - 1) / KD_BLOCK;
+    // scratch: [powers 272][lane_in nblocks * PO_THREADS][block totals nblocks]
+    const size_t npw = 16 + PO_THREADS;
+    int rc = ensure_scratch(ctx, (npw + nblocks * PO_THREADS + nblocks) * 32);
+    if (rc) return rc;
+    std::vector<uint64_t> pw(npw * 4);
+    uint64_t zper[4], zblock[4];
+    h_pow(HFR, zper, point, KD_PER);
+    h_pow(HFR, zblock, point, KD_BLOCK);
+    memcpy(&pw[0], zper, 32);
+    for (int d = 1; d < 8; d++) h_mul(HFR, &pw[4 * d], &pw[4 * (d - 1)], &pw[4 * (d - 1)]);
+    memcpy(&pw[4 * 8], zblock, 32);
+    for (int d = 1; d < 8; d++) h_mul(HFR, &pw[4 * (8 + d)], &pw[4 * (8 + d - 1)], &pw[4 * (8 + d - 1)]);
+    memcpy(&pw[4 * 16], HFR.r, 32);
+    for (int t = 1; t < PO_THREADS; t++) h_mul(HFR, &pw[4 * (16 + t)], &pw[4 * (16 + t - 1)], zper);
+    fe* d_pw = (fe*)ctx->scratch;
+    fe* d_lane_in = d_pw + npw;
+    fe* d_tot = d_lane_in + nblocks * PO_THREADS;
+    ZK_HIP(ctx, hipMemcpyAsync(d_pw, pw.data(), npw * 32, hipMemcpyHostToDevice, ctx->stream));
+    ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    TimedRegion tr(ctx, "kate_division");
+    const fe z = fe_from(point);
+    hipLaunchKernelGGL(kate_local_kernel, dim3((unsigned)nblocks), dim3(PO_THREADS), 0, ctx->stream, (const fe*)d_poly, n, z, d_pw,
+                       d_lane_in, d_tot);
+    hipLaunchKernelGGL(kate_blocks_kernel, dim3(1), dim3(PO_THREADS), 0, ctx->stream, d_tot, nblocks, d_pw);
+    hipLaunchKernelGGL(kate_apply_kernel, dim3((unsigned)nblocks), dim3(PO_THREADS), 0, ctx->stream, (const fe*)d_poly, n, z, d_pw,
+                       d_lane_in, d_tot, (fe*)d_out);
+    ZK_HIP(ctx, hipGetLastError());
     return ZKHIP_OK;
 }
 

@@ -164,6 +164,21 @@ struct Wide {
             for (int j = 0; j < 9; j++) col[i + j] += (int64_t)c.d[i] * nd.d[j];
         return reduce(col);
     }
+    // (a b + c d) / 2^261 with ONE reduction; same operand rule as mul_sub_mul
+    ZK_DEV static fw mul_add_mul(const fw& a, const fw& b, const fw& c, const fw& d) {
+        int64_t col[18];
+#pragma unroll
+        for (int k = 0; k < 18; k++) col[k] = 0;
+#pragma unroll
+        for (int i = 0; i < 9; i++)
+#pragma unroll
+            for (int j = 0; j < 9; j++) col[i + j] += (int64_t)a.d[i] * b.d[j];
+#pragma unroll
+        for (int i = 0; i < 9; i++)
+#pragma unroll
+            for (int j = 0; j < 9; j++) col[i + j] += (int64_t)c.d[i] * d.d[j];
+        return reduce(col);
+    }
     // operand digits must stay below 2^29 in magnitude (the doubled cross terms use 2 a_i)
     ZK_DEV static fw sqr(const fw& a) {
         int64_t col[18];

@@ -29,7 +29,7 @@ EXPORTS = [
     "zkhip_extended_to_coeff_dev", "zkhip_divide_by_vanishing_poly_dev",
     "zkhip_evaluate_h", "zkhip_evaluate_h_last_stats",
     "zkhip_batch_invert_dev", "zkhip_prefix_product_dev", "zkhip_permutation_product_dev", "zkhip_lookup_product_dev",
-    "zkhip_eval_polynomial_dev",
+    "zkhip_eval_polynomial_dev", "zkhip_poly_lincomb_dev", "zkhip_kate_division_dev",
     "zkhip_timing_enable", "zkhip_timing_reset", "zkhip_timing_get",
 ]
 
@@ -283,6 +283,19 @@ class Context:
         out = np.zeros(4, dtype=np.uint64)
         self._ck(self._l.zkhip_eval_polynomial_dev(self.h, C.c_void_p(d_coeff), C.c_size_t(n), _p(x), _p(out)))
         return out
+
+    def poly_lincomb_dev(self, d_polys, lens, coeffs, n: int, d_out: int):
+        """d_out[i] = sum_k coeffs[k] * d_polys[k][i]; d_polys: device pointers, lens: their lengths (<= n),
+        coeffs: (num, 4) Montgomery limbs."""
+        num = len(d_polys)
+        ptrs = (C.c_void_p * max(num, 1))(*[C.c_void_p(int(p)) for p in d_polys])
+        ls = (C.c_size_t * max(num, 1))(*[int(x) for x in lens])
+        cf = np.ascontiguousarray(np.asarray(coeffs, dtype=np.uint64).reshape(num, 4)) if num else np.zeros((1, 4), np.uint64)
+        self._ck(self._l.zkhip_poly_lincomb_dev(self.h, ptrs, ls, _p(cf), C.c_uint32(num), C.c_size_t(n), C.c_void_p(d_out)))
+
+    def kate_division_dev(self, d_poly: int, n: int, point, d_out: int):
+        point = u64(point)
+        self._ck(self._l.zkhip_kate_division_dev(self.h, C.c_void_p(d_poly), C.c_size_t(n), _p(point), C.c_void_p(d_out)))
 
     def evaluate_h_last_stats(self):
         out = np.zeros(4, dtype=np.uint64)
