@@ -172,6 +172,11 @@ typedef struct {
     const uint64_t* const* perm_product_cosets;  /* permutation_product_coset per set (extended) */
     uint32_t perm_chunk_len;               /* cs.degree() - 2                          */
     uint32_t blinding_factors;             /* cs.blinding_factors()                    */
+    /* Multi-GPU split (no reference counterpart: upstream splits rows over rayon threads): num_cosets = 0 evaluates the
+     * whole extended domain.  Otherwise only the listed cosets (see zkhip_coeff_to_cosets_dev) are evaluated; every
+     * "extended" vector above and `out` are then in the compact layout of that list, 2^k * num_cosets rows.         */
+    uint32_t num_cosets;
+    const uint32_t* cosets;                /* host, num_cosets distinct values < 2^(extended_k - k) */
 } zkhip_evalh_desc;
 
 /* out: 2^ext_k x 4 (host or device per desc->mem) = numerator of the quotient on the extended coset. */
@@ -219,6 +224,26 @@ int zkhip_eval_polynomial_dev(zkhip_ctx* ctx, const uint64_t* d_coeff, size_t n,
 int zkhip_poly_lincomb_dev(zkhip_ctx* ctx, const uint64_t* const* d_polys, const size_t* lens, const uint64_t* coeffs,
                            uint32_t num, size_t n, uint64_t* d_out);
 int zkhip_kate_division_dev(zkhip_ctx* ctx, const uint64_t* d_poly, size_t n, const uint64_t point[4], uint64_t* d_out);
+
+/* ------------------------------------------------------------------ coset subsets (multi-GPU evaluate_h) ---
+ * The extended domain zeta * <extended_omega> is the union of the 2^e cosets zeta * extended_omega^j * <omega>,
+ * e = extended_k - k: extended row idx belongs to coset idx mod 2^e, and a rotation by r rows of the circuit moves
+ * r * 2^e extended rows, i.e. stays inside its coset.  A GPU that owns whole cosets therefore evaluates its rows of h
+ * without any exchange of neighbouring rows.  (Upstream's evaluate_h splits contiguous row ranges over rayon threads
+ * in shared memory; this is the same computation partitioned so that it needs no shared memory.)
+ * A "compact" vector for a list of num_cosets cosets (a power of two, distinct) has 2^k * num_cosets rows:
+ * compact row q * num_cosets + s  =  extended row q * 2^e + cosets[s].
+ * zkhip_coeff_to_cosets_dev     coefficients (2^k per member) -> compact values on the listed cosets: per coset one
+ *                               size-2^k NTT of c_i (zeta extended_omega^j)^i instead of the size-2^extended_k transform.
+ * zkhip_extended_to_cosets_dev  extended vector -> compact (gather; for pk.fixed_cosets, l0, ... computed at keygen).
+ * zkhip_cosets_to_extended_dev  compact -> rows of the listed cosets in an extended vector (other rows untouched): how
+ *                               the pieces of h from all GPUs are put together before divide_by_vanishing_poly. */
+int zkhip_coeff_to_cosets_dev(zkhip_domain* dom, const uint64_t* d_coeff, const uint32_t* cosets, uint32_t num_cosets,
+                              uint64_t* d_out, size_t batch);
+int zkhip_extended_to_cosets_dev(zkhip_domain* dom, const uint64_t* d_ext, const uint32_t* cosets, uint32_t num_cosets,
+                                 uint64_t* d_out);
+int zkhip_cosets_to_extended_dev(zkhip_domain* dom, const uint64_t* d_compact, const uint32_t* cosets, uint32_t num_cosets,
+                                 uint64_t* d_ext);
 
 /* Kernel timing hook: average duration in microseconds of the launches of the named kernel family issued on
  * this context since the last zkhip_timing_reset (measured with HIP events on the launch stream).

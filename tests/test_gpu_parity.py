@@ -690,3 +690,94 @@ def test_shplonk_golden(ctx, co):
         assert np.array_equal(ctx.download(d_o, (c["n"], 4)), hex_fr(c["out"]))
         for p in d_ps + [d_o]:
             ctx.free(p)
+
+
+# ------------------------------------------------------------------------------------------------ coset split (multi-GPU)
+def _compact(a, cosets, e):
+    """extended vector -> compact layout of the listed cosets (row q * m + s = extended row q * 2^e + cosets[s])"""
+    a = np.asarray(a)
+    out = np.empty((a.shape[0] // (1 << e) * len(cosets), 4), dtype=np.uint64)
+    for s, j in enumerate(cosets):
+        out[s::len(cosets)] = a[j::1 << e]
+    return out
+
+
+@pytest.mark.parametrize("j,k", [(3, 6), (5, 9), (9, 11), (17, 8)])
+def test_coset_subsets_of_the_extended_domain(ctx, co, j, k):
+    """coeff_to_cosets = the listed rows of coeff_to_extended; gather / scatter between the two layouts"""
+    d, od = zk.Domain(ctx, j, k), co.Domain(j, k, threads=4)
+    e, n, en = d.extended_k - k, d.n, d.extended_len
+    rng = np.random.default_rng(j * 100 + k)
+    batch = 3
+    coeff = rand_fr(rng, batch * n)
+    full = [od.coeff_to_extended(coeff[b * n:(b + 1) * n]) for b in range(batch)]
+    d_c = ctx.upload(coeff)
+    lists = [list(range(1 << e)), [(1 << e) - 1], list(range(1, 1 << e, 2)) or [0], [0]]
+    if e >= 2:
+        lists.append([3, 0])
+    for cosets in lists:
+        m = len(cosets)
+        d_o = ctx.alloc(batch * n * m * 32)
+        d.coeff_to_cosets_dev(d_c, cosets, d_o, batch)
+        got = ctx.download(d_o, (batch * n * m, 4))
+        for b in range(batch):
+            assert np.array_equal(got[b * n * m:(b + 1) * n * m], _compact(full[b], cosets, e)), (cosets, b)
+        ctx.free(d_o)
+        d_e, d_m, d_back = ctx.upload(full[0]), ctx.alloc(n * m * 32), ctx.upload(np.zeros((en, 4), np.uint64))
+        d.extended_to_cosets_dev(d_e, cosets, d_m)
+        assert np.array_equal(ctx.download(d_m, (n * m, 4)), _compact(full[0], cosets, e))
+        d.cosets_to_extended_dev(d_m, cosets, d_back)
+        back = ctx.download(d_back, (en, 4))
+        keep = np.zeros(en, bool)
+        for jj in cosets:
+            keep[jj::1 << e] = True
+        assert np.array_equal(back[keep], full[0][keep]) and not back[~keep].any()
+        for p in (d_e, d_m, d_back):
+            ctx.free(p)
+    with pytest.raises(ffi.ZkhipError):
+        d.coeff_to_cosets_dev(d_c, [0, 0], d_c, 1)               # repeated coset
+    with pytest.raises(ffi.ZkhipError):
+        d.coeff_to_cosets_dev(d_c, [1 << e], d_c, 1)             # out of range
+    ctx.free(d_c)
+    d.close()
+
+
+@pytest.mark.parametrize("k,kw", [
+    (7, dict()),
+    (9, dict(num_advice=12, num_gate_polys=40, num_lookups=3, num_perm_cols=7, rotations=(-5, -1, 0, 1, 3))),
+    (8, dict(num_advice=20, num_fixed=8, num_gate_polys=100, max_degree=9, num_lookups=2, num_perm_cols=11)),
+])
+def test_evaluate_h_split_by_coset_matches_whole(ctx, co, k, kw):
+    """what each GPU of a 1 / 2 / 4 / 8-way split computes (its cosets only, compact columns) put back together equals
+    the single-GPU evaluate_h, in extended and in coefficient form"""
+    from zkevm_circuits_amd import sharding
+    cs = synthetic.synthetic_cs(**kw)
+    d, od = zk.Domain(ctx, cs.degree(), k), co.Domain(cs.degree(), k, threads=8)
+    e = d.extended_k - k
+    rng = np.random.default_rng(k + 50)
+    call, coeff, ext = _random_call(cs, rng, d.n, d.extended_len, od)
+    call.advice, call.instance, call.lookups = ext["advice"], ext["instance"], ext["lookups"]
+    whole = d.evaluate_h(call.build(ffi.MEM_HOST, ffi.FORM_EXTENDED))
+    pk = dict(fixed=call.fixed, l0=call.l0, l_last=call.l_last, l_active=call.l_active, perm_sigma=call.perm_sigma,
+              perm_z=call.perm_z)
+    for world in [w for w in (1, 2, 4, 8) if w <= (1 << e)]:
+        for form in (ffi.FORM_EXTENDED, ffi.FORM_COEFF):
+            back = np.zeros_like(whole)
+            for rank in range(world):
+                cosets = sharding.cosets_for_rank(d.extended_k, k, rank, world)
+                c = lambda a: _compact(a, cosets, e)
+                call.cosets = cosets
+                call.fixed = [c(a) for a in pk["fixed"]]
+                call.l0, call.l_last, call.l_active = c(pk["l0"]), c(pk["l_last"]), c(pk["l_active"])
+                call.perm_sigma, call.perm_z = [c(a) for a in pk["perm_sigma"]], [c(a) for a in pk["perm_z"]]
+                if form == ffi.FORM_EXTENDED:
+                    call.advice, call.instance = [c(a) for a in ext["advice"]], [c(a) for a in ext["instance"]]
+                    call.lookups = [tuple(c(p) for p in t) for t in ext["lookups"]]
+                else:
+                    call.advice, call.instance, call.lookups = coeff["advice"], coeff["instance"], coeff["lookups"]
+                part = d.evaluate_h(call.build(ffi.MEM_HOST, form))
+                assert part.shape[0] == d.n * len(cosets)
+                for s, j in enumerate(cosets):
+                    back[j::1 << e] = part[s::len(cosets)]
+            assert np.array_equal(back, whole), (world, form)
+    d.close()

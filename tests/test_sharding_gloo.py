@@ -39,6 +39,25 @@ def _worker(rank, world, port, n, ncols, q):
     # (2) column-sharded commitments gathered in column order
     mine = {c: co.best_multiexp(scal[c], bases) for c in sharding.columns_for_rank(ncols, rank, world)}
     allc = sharding.gather_commitments(mine, ncols, dist)
+    # (3) evaluate_h split by coset: every rank evaluates its cosets (here: reads them out of a stand-in h that all
+    # ranks derive from the same seed), one all-gather, and the pieces are put back in extended order
+    import torch
+    k, ek = 4, 6
+    h_full = np.random.default_rng(7).integers(0, 2 ** 63, size=(1 << ek, 4), dtype=np.int64)
+
+    def evaluate(cosets):
+        m = len(cosets)
+        out = np.zeros(((1 << k) * m, 4), dtype=np.int64)
+        for s_, j in enumerate(cosets):
+            out[s_::m] = h_full[j::1 << (ek - k)] if m else 0
+        return torch.from_numpy(out)
+    pieces = sharding.evaluate_h_by_cosets(ek, k, evaluate, dist)
+    h_back = np.zeros_like(h_full)
+    for cosets, rows in pieces:
+        for s_, j in enumerate(cosets):
+            h_back[j::1 << (ek - k)] = rows.numpy()[s_::len(cosets)]
+    assert np.array_equal(h_back, h_full)
+    assert sorted(j for cosets, _ in pieces for j in cosets) == list(range(1 << (ek - k)))
     q.put((rank, co.g1_to_affine(full), np.stack([co.g1_to_affine(j) for j in allc])))
     dist.barrier()
     dist.destroy_process_group()

@@ -15,6 +15,18 @@ struct zkhip_domain {
 };
 
 namespace zkhip {
+// A subset of the 2^(extended_k - k) cosets zeta * extended_omega^j * <omega> that make up the extended domain
+// (extended row idx lies in coset idx mod 2^e).  "Compact" vectors hold only these cosets, interleaved the same way:
+// compact row q * num + s is extended row q * 2^e + j[s].  num is a power of two.
+struct CosetList {
+    uint32_t num;
+    uint32_t j[16];
+};
+int coset_list_check(zkhip_domain* dom, const uint32_t* cosets, uint32_t num, CosetList* out);
+// coeff (2^k, device) -> its values on the listed cosets, compact layout (2^k * num); tmp: 4 * 2^k elements
+int domain_coeff_to_cosets(zkhip_domain* dom, const fe* d_coeff, const CosetList& cl, fe* d_out, fe* tmp);
+// x[q * num + s] = zeta * extended_omega^(q * 2^e + j[s])
+int domain_coset_xpoints(zkhip_domain* dom, const CosetList& cl, fe* d_x);
 // coeff (2^k per member, stride 2^k) -> extended coset (2^extended_k per member); tmp0/tmp1: batch * 2^extended_k each
 int domain_coeff_to_extended(zkhip_domain* dom, const fe* d_coeff, fe* d_out, size_t batch, fe* tmp0, fe* tmp1);
 }  // namespace zkhip

@@ -19,6 +19,97 @@ int domain_coeff_to_extended(zkhip_domain* dom, const fe* d_coeff, fe* d_out, si
     return ntt_run(dom->ctx, dom->plan_ext_fwd, d_coeff, n, (uint32_t)n, d_out, en, (uint32_t)en, batch, fuse, tmp0, tmp1);
 }
 
+// ---- coset subsets (the unit of the multi-GPU split of evaluate_h) -------------------------------------------
+// t[i] = c[i] * zeta^(i mod 3) * extended_omega^(j i): the coefficients of p(zeta extended_omega^j X)
+__global__ void __launch_bounds__(256) coset_prescale_kernel(const fe* c, fe* t, uint32_t n, uint32_t j, fe zeta, fe zeta2,
+                                                             const fe* om_lo, const fe* om_hi, uint32_t h) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    fe v = load_fe(c + i);
+    const uint32_t e = i * j;   // < 2^extended_k
+    if (e) {
+        fe om = load_fe(om_lo + (e & ((1u << h) - 1)));
+        if (e >> h) om = Fr::mul(om, load_fe(om_hi + (e >> h)));
+        v = Fr::mul(v, om);
+    }
+    const uint32_t r = i % 3;
+    if (r == 1) v = Fr::mul(v, zeta);
+    else if (r == 2) v = Fr::mul(v, zeta2);
+    store_fe(t + i, v);
+}
+__global__ void __launch_bounds__(256) coset_interleave_kernel(const fe* src, fe* dst, uint32_t n, uint32_t num, uint32_t s) {
+    const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q < n) store_fe(dst + (size_t)q * num + s, load_fe(src + q));
+}
+// to_compact: dst[q * num + s] = src[q * 2^e + j[s]]; otherwise the reverse (rows of other cosets are left alone)
+__global__ void __launch_bounds__(256) coset_gather_kernel(const fe* src, fe* dst, size_t rows, CosetList cl, uint32_t e, int to_compact) {
+    const size_t c = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= rows) return;
+    const size_t q = c / cl.num, full = (q << e) + cl.j[c % cl.num];
+    if (to_compact) store_fe(dst + c, load_fe(src + full));
+    else store_fe(dst + full, load_fe(src + c));
+}
+__global__ void __launch_bounds__(256) coset_xpoints_kernel(fe* x, size_t rows, CosetList cl, uint32_t e, const fe* om_lo,
+                                                            const fe* om_hi, uint32_t h) {
+    const size_t c = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= rows) return;
+    const uint32_t idx = (uint32_t)(((c / cl.num) << e) + cl.j[c % cl.num]);
+    fe zeta;
+#pragma unroll
+    for (int i = 0; i < 8; i++) zeta.l[i] = FrParams::ZETA[i];
+    fe om = load_fe(om_lo + (idx & ((1u << h) - 1)));
+    if (idx >> h) om = Fr::mul(om, load_fe(om_hi + (idx >> h)));
+    store_fe(x + c, Fr::mul(om, zeta));
+}
+
+int coset_list_check(zkhip_domain* dom, const uint32_t* cosets, uint32_t num, CosetList* out) {
+    zkhip_ctx* ctx = dom->ctx;
+    const uint32_t e = dom->extended_k - dom->k;
+    ZK_CHECK(ctx, cosets && num >= 1 && num <= (1u << e) && (num & (num - 1)) == 0,
+             "coset list: %u cosets of %u (a power of two, at most all of them)", num, 1u << e);
+    ZK_CHECK(ctx, e <= 4, "coset list: 2^%u cosets", e);
+    uint32_t seen = 0;
+    out->num = num;
+    for (uint32_t s = 0; s < 16; s++) out->j[s] = 0;
+    for (uint32_t s = 0; s < num; s++) {
+        ZK_CHECK(ctx, cosets[s] < (1u << e) && !((seen >> cosets[s]) & 1), "coset list: coset %u out of range or repeated", cosets[s]);
+        seen |= 1u << cosets[s];
+        out->j[s] = cosets[s];
+    }
+    return ZKHIP_OK;
+}
+
+int domain_coeff_to_cosets(zkhip_domain* dom, const fe* d_coeff, const CosetList& cl, fe* d_out, fe* tmp) {
+    zkhip_ctx* ctx = dom->ctx;
+    const uint32_t n = 1u << dom->k;
+    fe zeta, zeta2;
+    to_fe(zeta, dom->g_coset);
+    to_fe(zeta2, dom->g_coset_inv);   // zeta^2 = zeta^-1
+    fe *t_in = tmp, *t_out = tmp + n, *t0 = tmp + 2 * (size_t)n, *t1 = tmp + 3 * (size_t)n;
+    const dim3 grid((n + 255) / 256);
+    NttFuse fuse;
+    for (uint32_t s = 0; s < cl.num; s++) {
+        hipLaunchKernelGGL(coset_prescale_kernel, grid, dim3(256), 0, ctx->stream, d_coeff, t_in, n, cl.j[s], zeta, zeta2,
+                           (const fe*)dom->plan_ext_fwd->d_lo, (const fe*)dom->plan_ext_fwd->d_hi, dom->plan_ext_fwd->h);
+        ZK_HIP(ctx, hipGetLastError());
+        int rc = ntt_run(ctx, dom->plan_fwd, t_in, n, n, t_out, n, n, 1, fuse, t0, t1);
+        if (rc) return rc;
+        hipLaunchKernelGGL(coset_interleave_kernel, grid, dim3(256), 0, ctx->stream, (const fe*)t_out, d_out, n, cl.num, s);
+        ZK_HIP(ctx, hipGetLastError());
+    }
+    return ZKHIP_OK;
+}
+
+int domain_coset_xpoints(zkhip_domain* dom, const CosetList& cl, fe* d_x) {
+    zkhip_ctx* ctx = dom->ctx;
+    const size_t rows = ((size_t)1 << dom->k) * cl.num;
+    hipLaunchKernelGGL(coset_xpoints_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, ctx->stream, d_x, rows, cl,
+                       dom->extended_k - dom->k, (const fe*)dom->plan_ext_fwd->d_lo, (const fe*)dom->plan_ext_fwd->d_hi,
+                       dom->plan_ext_fwd->h);
+    ZK_HIP(ctx, hipGetLastError());
+    return ZKHIP_OK;
+}
+
 }  // namespace zkhip
 
 extern "C" {
@@ -186,6 +277,50 @@ int zkhip_divide_by_vanishing_poly_dev(zkhip_domain* dom, uint64_t* d_ext, size_
     ZK_HIP(ctx, hipSetDevice(ctx->device));
     const size_t en = (size_t)1 << dom->extended_k;
     return scale_periodic(ctx, (fe*)d_ext, (const fe*)dom->d_t_evaluations, 1u << (dom->extended_k - dom->k), batch * en);
+}
+
+// ---- coset subsets ------------------------------------------------------------------------------------
+int zkhip_coeff_to_cosets_dev(zkhip_domain* dom, const uint64_t* d_coeff, const uint32_t* cosets, uint32_t num_cosets,
+                              uint64_t* d_out, size_t batch) {
+    if (!dom) return ZKHIP_ERR_INVALID;
+    zkhip_ctx* ctx = dom->ctx;
+    ZK_CHECK(ctx, d_coeff && d_out && batch >= 1, "coeff_to_cosets: null pointer or empty batch");
+    CosetList cl;
+    int rc = coset_list_check(dom, cosets, num_cosets, &cl);
+    if (rc) return rc;
+    ZK_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t n = (size_t)1 << dom->k;
+    rc = ensure_scratch(ctx, 4 * n * 32);
+    if (rc) return rc;
+    for (size_t b = 0; b < batch; b++) {
+        rc = domain_coeff_to_cosets(dom, (const fe*)d_coeff + b * n, cl, (fe*)d_out + b * n * cl.num, (fe*)ctx->scratch);
+        if (rc) return rc;
+    }
+    return ZKHIP_OK;
+}
+
+static int coset_copy(zkhip_domain* dom, const uint64_t* d_src, const uint32_t* cosets, uint32_t num_cosets, uint64_t* d_dst,
+                      int to_compact, const char* what) {
+    if (!dom) return ZKHIP_ERR_INVALID;
+    zkhip_ctx* ctx = dom->ctx;
+    ZK_CHECK(ctx, d_src && d_dst && (const void*)d_src != (const void*)d_dst, "%s: null or overlapping pointers", what);
+    CosetList cl;
+    int rc = coset_list_check(dom, cosets, num_cosets, &cl);
+    if (rc) return rc;
+    ZK_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t rows = ((size_t)1 << dom->k) * cl.num;
+    hipLaunchKernelGGL(coset_gather_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, ctx->stream, (const fe*)d_src,
+                       (fe*)d_dst, rows, cl, dom->extended_k - dom->k, to_compact);
+    ZK_HIP(ctx, hipGetLastError());
+    return ZKHIP_OK;
+}
+int zkhip_extended_to_cosets_dev(zkhip_domain* dom, const uint64_t* d_ext, const uint32_t* cosets, uint32_t num_cosets,
+                                 uint64_t* d_out) {
+    return coset_copy(dom, d_ext, cosets, num_cosets, d_out, 1, "extended_to_cosets");
+}
+int zkhip_cosets_to_extended_dev(zkhip_domain* dom, const uint64_t* d_compact, const uint32_t* cosets, uint32_t num_cosets,
+                                 uint64_t* d_ext) {
+    return coset_copy(dom, d_compact, cosets, num_cosets, d_ext, 0, "cosets_to_extended");
 }
 
 // ---- host variants: upload, run, download ---------------------------------------------------------

@@ -611,16 +611,25 @@ extern "C" int zkhip_evaluate_h(zkhip_domain* dom, const zkhip_evalh_desc* desc,
     }
     ZK_HIP(ctx, hipSetDevice(ctx->device));
     const uint32_t ek = dom->extended_k, k = dom->k;
-    const size_t size = (size_t)1 << ek, n = (size_t)1 << k;
+    const size_t n = (size_t)1 << k;
     const bool host = desc->mem == ZKHIP_MEM_HOST;
     const bool coeff = desc->poly_form == ZKHIP_FORM_COEFF;
     Arena ar{ctx, {}};
     int rc;
+    // Rows evaluated: the whole extended domain, or a subset of its cosets in compact layout.  A rotation by r moves
+    // r * 2^e extended rows and so stays inside a coset; in the compact layout it moves r * num_cosets rows.
+    const bool compact = desc->num_cosets != 0;
+    CosetList cl;
+    cl.num = 1u << (ek - k);
+    if (compact && (rc = coset_list_check(dom, desc->cosets, desc->num_cosets, &cl))) return rc;
+    uint32_t log_rows = k;
+    while ((1u << (log_rows - k)) < cl.num) log_rows++;
+    const size_t size = (size_t)1 << log_rows;
 
     // Bring one polynomial to an extended coset on the device.  `ext_in`: already extended.
     fe *tmp0 = nullptr, *tmp1 = nullptr;
     if (coeff) {
-        rc = ensure_scratch(ctx, 2 * size * 32);
+        rc = ensure_scratch(ctx, (compact ? 4 * n : 2 * size) * 32);
         if (rc) return rc;
         tmp0 = (fe*)ctx->scratch;
         tmp1 = tmp0 + size;
@@ -645,7 +654,8 @@ extern "C" int zkhip_evaluate_h(zkhip_domain* dom, const zkhip_evalh_desc* desc,
         void* d_ext;
         int r = ar.alloc(size * 32, &d_ext);
         if (r) return r;
-        r = domain_coeff_to_extended(dom, d_coeff, (fe*)d_ext, 1, tmp0, tmp1);
+        r = compact ? domain_coeff_to_cosets(dom, d_coeff, cl, (fe*)d_ext, tmp0)
+                    : domain_coeff_to_extended(dom, d_coeff, (fe*)d_ext, 1, tmp0, tmp1);
         if (r) return r;
         *outp = (const fe*)d_ext;
         return ZKHIP_OK;
@@ -686,15 +696,23 @@ extern "C" int zkhip_evaluate_h(zkhip_domain* dom, const zkhip_evalh_desc* desc,
     std::vector<uint64_t> extra_scalars;   // after the challenges: beta * delta^c per permutation column
     const uint32_t sc_perm0 = SC_CHALLENGE0 + desc->num_challenges;
     if (desc->num_perm_sets) {
-        if (!dom->d_xpoints) {
-            ZK_HIP(ctx, hipMalloc(&dom->d_xpoints, size * 32));
-            hipLaunchKernelGGL(xpoints_kernel, dim3((unsigned)((size + 255) / 256)), dim3(256), 0, ctx->stream,
-                               (fe*)dom->d_xpoints, (const fe*)dom->plan_ext_fwd->d_lo, (const fe*)dom->plan_ext_fwd->d_hi,
-                               dom->plan_ext_fwd->h, (uint32_t)size);
-            ZK_HIP(ctx, hipGetLastError());
+        const fe* d_x;
+        if (compact) {
+            void* xp;
+            if ((rc = ar.alloc(size * 32, &xp)) || (rc = domain_coset_xpoints(dom, cl, (fe*)xp))) return rc;
+            d_x = (const fe*)xp;
+        } else {
+            if (!dom->d_xpoints) {
+                ZK_HIP(ctx, hipMalloc(&dom->d_xpoints, size * 32));
+                hipLaunchKernelGGL(xpoints_kernel, dim3((unsigned)((size + 255) / 256)), dim3(256), 0, ctx->stream,
+                                   (fe*)dom->d_xpoints, (const fe*)dom->plan_ext_fwd->d_lo, (const fe*)dom->plan_ext_fwd->d_hi,
+                                   dom->plan_ext_fwd->h, (uint32_t)size);
+                ZK_HIP(ctx, hipGetLastError());
+            }
+            d_x = (const fe*)dom->d_xpoints;
         }
         const uint32_t c_x = (uint32_t)cols.size();
-        cols.push_back((const fe*)dom->d_xpoints);
+        cols.push_back(d_x);
         const uint32_t c_z0 = (uint32_t)cols.size();
         for (uint32_t s = 0; s < desc->num_perm_sets; s++)
             if ((rc = push(desc->perm_product_cosets[s], true))) return rc;
@@ -830,7 +848,7 @@ extern "C" int zkhip_evaluate_h(zkhip_domain* dom, const zkhip_evalh_desc* desc,
     if ((rc = ar.upload((const fe*)scal.data(), scal.size() / 4, &d_scal))) return rc;
     if ((rc = ar.upload((const fe*)b.consts.data(), b.consts.size() / 4, &d_consts))) return rc;
     // link: operand words -> (header, device pointer)
-    const int32_t rot_scale = 1 << (ek - k);
+    const int32_t rot_scale = (int32_t)cl.num;
     auto link = [&](uint32_t w, uint32_t* o) {
         const uint32_t kind = w >> 28, pl = w & 0x0fffffffu;
         uint64_t ptr = 0;
@@ -883,7 +901,7 @@ extern "C" int zkhip_evaluate_h(zkhip_domain* dom, const zkhip_evalh_desc* desc,
         if ((rc = ar.alloc((size_t)(n_slots - lds_slots) * size * 36, &sp))) return rc;
         a.spill = (int32_t*)sp;
     }
-    a.log_size = ek;
+    a.log_size = log_rows;
     a.out = d_out;
     const size_t lds_bytes = (size_t)(lds_slots > 1 ? lds_slots - 1 : 1) * EV_THREADS * 36;
     ZK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(evalh_interp_kernel),

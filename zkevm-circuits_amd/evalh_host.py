@@ -37,6 +37,7 @@ class EvalhCall:
         self.l0 = self.l_last = self.l_active = None
         self.lookups = []        # [(product, permuted_input, permuted_table)]
         self.perm_sigma, self.perm_z = [], []
+        self.cosets = None       # list of coset indices: evaluate only these, every extended vector in compact layout
 
     def build(self, mem=ffi.MEM_HOST, form=ffi.FORM_EXTENDED):
         cs, ev = self.cs, self.ev
@@ -84,5 +85,9 @@ class EvalhCall:
         d.perm_product_cosets = ptrs(self.perm_z)
         d.perm_chunk_len = cs.permutation_chunk_len()
         d.blinding_factors = cs.blinding_factors()
+        if self.cosets is not None:
+            cl = np.ascontiguousarray(np.asarray(self.cosets, dtype=np.uint32))
+            b.keep.append(cl)
+            d.num_cosets, d.cosets = len(cl), C.c_void_p(cl.ctypes.data)
         self._keep = b
         return d

@@ -28,6 +28,7 @@ EXPORTS = [
     "zkhip_lagrange_to_coeff_dev", "zkhip_coeff_to_lagrange_dev", "zkhip_coeff_to_extended_dev",
     "zkhip_extended_to_coeff_dev", "zkhip_divide_by_vanishing_poly_dev",
     "zkhip_evaluate_h", "zkhip_evaluate_h_last_stats",
+    "zkhip_coeff_to_cosets_dev", "zkhip_extended_to_cosets_dev", "zkhip_cosets_to_extended_dev",
     "zkhip_batch_invert_dev", "zkhip_prefix_product_dev", "zkhip_permutation_product_dev", "zkhip_lookup_product_dev",
     "zkhip_eval_polynomial_dev", "zkhip_poly_lincomb_dev", "zkhip_kate_division_dev",
     "zkhip_timing_enable", "zkhip_timing_reset", "zkhip_timing_get",
@@ -81,7 +82,8 @@ class EvalhDesc(C.Structure):
                 ("num_perm_columns", C.c_uint32), ("perm_column_kind", C.c_void_p),
                 ("perm_column_index", C.c_void_p), ("perm_sigma_cosets", C.POINTER(C.c_void_p)),
                 ("num_perm_sets", C.c_uint32), ("perm_product_cosets", C.POINTER(C.c_void_p)),
-                ("perm_chunk_len", C.c_uint32), ("blinding_factors", C.c_uint32)]
+                ("perm_chunk_len", C.c_uint32), ("blinding_factors", C.c_uint32),
+                ("num_cosets", C.c_uint32), ("cosets", C.c_void_p)]
 
 
 MEM_HOST, MEM_DEVICE = 0, 1
@@ -395,6 +397,22 @@ class Domain:
     def divide_by_vanishing_poly_dev(self, d_ext: int, batch: int = 1):
         self.ctx._ck(self._l.zkhip_divide_by_vanishing_poly_dev(self.h, C.c_void_p(d_ext), C.c_size_t(batch)))
 
+    def _cosets(self, cosets):
+        return np.ascontiguousarray(np.asarray(cosets, dtype=np.uint32))
+
+    def coeff_to_cosets_dev(self, d_coeff: int, cosets, d_out: int, batch: int = 1):
+        cs = self._cosets(cosets)
+        self.ctx._ck(self._l.zkhip_coeff_to_cosets_dev(self.h, C.c_void_p(d_coeff), _p(cs), C.c_uint32(len(cs)),
+                                                       C.c_void_p(d_out), C.c_size_t(batch)))
+
+    def extended_to_cosets_dev(self, d_ext: int, cosets, d_out: int):
+        cs = self._cosets(cosets)
+        self.ctx._ck(self._l.zkhip_extended_to_cosets_dev(self.h, C.c_void_p(d_ext), _p(cs), C.c_uint32(len(cs)), C.c_void_p(d_out)))
+
+    def cosets_to_extended_dev(self, d_compact: int, cosets, d_ext: int):
+        cs = self._cosets(cosets)
+        self.ctx._ck(self._l.zkhip_cosets_to_extended_dev(self.h, C.c_void_p(d_compact), _p(cs), C.c_uint32(len(cs)), C.c_void_p(d_ext)))
+
     def permutation_product_dev(self, d_values, d_sigmas, beta, gamma, delta_start, z0, d_z: int):
         """One column set of `permutation::prover::Argument::commit` (all n rows; blinding rows are the caller's)."""
         assert len(d_values) == len(d_sigmas) and d_values
@@ -415,7 +433,8 @@ class Domain:
     def evaluate_h(self, desc: EvalhDesc, out_dev: int | None = None):
         """`Evaluator::evaluate_h`.  Host descriptor -> numpy result; device descriptor -> writes out_dev."""
         if desc.mem == MEM_HOST:
-            out = np.empty((self.extended_len, 4), dtype=np.uint64)
+            rows = self.n * desc.num_cosets if desc.num_cosets else self.extended_len
+            out = np.empty((rows, 4), dtype=np.uint64)
             self.ctx._ck(self._l.zkhip_evaluate_h(self.h, C.byref(desc), _p(out)))
             return out
         assert out_dev is not None

@@ -75,3 +75,31 @@ def msm_base_split(n: int, msm_range, fold, dist=None, device=None):
     dist.all_gather(gathered, t)
     parts = np.stack([g.cpu().numpy().view(np.uint64) for g in gathered])
     return fold(parts)
+
+
+def evaluate_h_by_cosets(extended_k: int, k: int, evaluate, dist=None):
+    """evaluate_h split by coset.  evaluate(cosets) -> torch tensor (2^k * len(cosets), 4) int64: the compact rows of
+    h on the listed cosets (compact row q * len(cosets) + s = extended row q * 2^e + cosets[s]), on the device the
+    process group communicates on.  Returns [(cosets of rank r, its rows)] for every rank that owns cosets, on every
+    rank: one all-gather of the pieces of h (2^extended_k x 32 bytes in total), the only exchange this phase needs.
+    With more ranks than cosets the surplus ranks own nothing (splitting a coset further by row ranges would need the
+    rotation halos this partition exists to avoid)."""
+    e = extended_k - k
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        cosets = list(range(1 << e))
+        return [(cosets, evaluate(cosets))]
+    import torch
+    rank, world = dist.get_rank(), dist.get_world_size()
+    owners = min(world, 1 << e)
+    mine = cosets_for_rank(extended_k, k, rank, owners) if rank < owners else []
+    per = (1 << e) // owners
+    rows = (1 << k) * per
+    if mine:
+        piece = evaluate(mine)
+        assert tuple(piece.shape) == (rows, 4), (tuple(piece.shape), rows)
+    else:
+        ref = evaluate([])            # an empty tensor on the right device, for the collective's shape
+        piece = torch.zeros((rows, 4), dtype=torch.int64, device=ref.device)
+    gathered = [torch.empty_like(piece) for _ in range(world)]
+    dist.all_gather(gathered, piece.contiguous())
+    return [(cosets_for_rank(extended_k, k, r, owners), gathered[r]) for r in range(owners)]
