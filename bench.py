@@ -91,11 +91,12 @@ def cpu_baseline(steps_hint):
             "msm_s": t_msm, "coset_ntt_s": t_ntt, "coset_ntt_GBps": 32.0 * (n + (1 << LOG_EXT)) / t_ntt / 1e9}
 
 
-def build_evalh(ctx, dom, gen, k):
+def build_evalh(ctx, dom, gen, k, cosets=None):
     cs = synthetic.synthetic_cs(num_advice=64, num_fixed=16, num_instance=1, num_gate_polys=256, max_degree=5,
                                 rotations=(-2, -1, 0, 1), num_lookups=16, lookup_width=3, num_perm_cols=8)
     assert cs.degree() == 5
-    en = dom.extended_len
+    # all cosets: the whole extended domain; a subset: the compact layout of those cosets (2^k rows each)
+    en = dom.extended_len if cosets is None else dom.n * len(cosets)
     keep = []
 
     def col():
@@ -104,6 +105,7 @@ def build_evalh(ctx, dom, gen, k):
         return t.data_ptr()
 
     call = evalh_host.EvalhCall(cs)
+    call.cosets = cosets
     call.fixed = [col() for _ in range(cs.num_fixed_columns)]
     call.advice = [col() for _ in range(cs.num_advice_columns)]
     call.instance = [col() for _ in range(cs.num_instance_columns)]
@@ -212,6 +214,10 @@ def main():
     evalh = None
     if not args.skip_evalh and not args.skip_extras:
         evalh = measure_evalh(ctx, dom, stream, gen, args.evalh_k)
+        if world > 1:
+            split = measure_evalh_split(ctx, dom, stream, gen, world, rank)
+            if evalh is not None:
+                evalh["split_by_coset"] = split
     finish(args, ctx, dist, world, rank, device_index, bid, scalars, n, en, elapsed, msm_ms, ntt_ms, acc_us, acc_launches, sort_us,
            merge_us, reduce_us, ntt_us, extra, evalh)
 
@@ -319,6 +325,37 @@ def measure_evalh(ctx, dom, stream, gen, evalh_k):
     return {"program": prog, "valu_mads": mads, "valu_frac": mads / (k_us * 1e-6) / VALU_MAD_PEAK if k_us else 0.0,"k": evalh_k, "extended_k": kdom.extended_k, "seconds": ev_s, "algorithmic_GB": bytes_alg / 1e9,
             "GBps": bytes_alg / ev_s / 1e9, "frac_of_hbm_peak": bytes_alg / ev_s / 1e9 / HBM_PEAK,
             "calculations": n_calc, "kernel_ms": k_us / 1e3, "columns_read": c_read}
+
+
+def measure_evalh_split(ctx, dom, stream, gen, world, rank):
+    """evaluate_h of the bench configuration split by coset over the ranks (strong scaling of ONE evaluation): every
+    owner evaluates its cosets on compact columns, one all-gather moves the pieces of h.  Reported next to the
+    per-rank figures; the headline value does not include it."""
+    owners = min(world, 1 << (dom.extended_k - dom.k))
+    cosets = sharding.cosets_for_rank(dom.extended_k, dom.k, rank, owners) if rank < owners else []
+    built = None
+    if cosets:
+        with torch.cuda.stream(stream):
+            built = build_evalh(ctx, dom, gen, dom.k, cosets)
+        stream.synchronize()
+
+    def evaluate(cs_):
+        if not cs_:
+            return torch.empty((0, 4), dtype=torch.int64, device="cuda")
+        dom.evaluate_h(built[0], built[1].data_ptr())
+        return built[1]
+    sharding.evaluate_h_by_cosets(dom.extended_k, dom.k, evaluate, dist)      # warm-up
+    torch.cuda.synchronize()
+    dist.barrier()
+    t0 = time.perf_counter()
+    pieces = sharding.evaluate_h_by_cosets(dom.extended_k, dom.k, evaluate, dist)
+    torch.cuda.synchronize()
+    dist.barrier()
+    dt = time.perf_counter() - t0
+    t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return {"ranks": world, "ranks_with_cosets": owners, "cosets_per_owner": (1 << (dom.extended_k - dom.k)) // owners,
+            "seconds_including_all_gather": float(t.cpu()[0]), "rows_gathered": int(sum(p.shape[0] for _, p in pieces))}
 
 
 def finish(args, ctx, dist, world, rank, local_rank, bid, scalars, n, en, elapsed, msm_ms, ntt_ms, acc_us, acc_launches, sort_us,
