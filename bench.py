@@ -300,6 +300,23 @@ def measure_extras(ctx, dom, bid, stream, gen, n, en, extra):
         lambda: dom.permutation_product_dev(ptr[0:3], ptr[3:6], sc[0], sc[1], sc[2], sc[3], ptr[6]))
     extra["lookup_product_2p19_ms"] = timed(lambda: dom.lookup_product_dev(ptr[0], ptr[1], ptr[2], ptr[3], sc[0], sc[1], ptr[6]))
     extra["eval_polynomial_2p19_ms"] = timed(lambda: ctx.eval_polynomial_dev(ptr[0], n, sc[0]))
+    # SHPLONK building blocks: a 64-term combination (2 GiB read) and one division by (X - z)
+    lens = [n] * 64
+    cf = rand_fr_device(64, gen).cpu().numpy().view(np.uint64)
+    lc_ptrs = [ptr[i % len(ptr)] for i in range(64)]
+    extra["poly_lincomb_64x2p19_ms"] = timed(lambda: ctx.poly_lincomb_dev(lc_ptrs, lens, cf, n, ptr[-1]))
+    # seven distinct polynomials are cycled, so most of this traffic is served by the 256 MB Infinity Cache, not HBM
+    extra["poly_lincomb_cached_GBps"] = 65 * n * 32 / (extra["poly_lincomb_64x2p19_ms"] * 1e-3) / 1e9
+    extra["kate_division_2p19_ms"] = timed(lambda: ctx.kate_division_dev(ptr[0], n, sc[0], ptr[-1]))
+    # the sort behind the permuted lookup columns: table = random column, input = values drawn from it
+    usable = n - 6
+    with torch.cuda.stream(stream):
+        table = rand_fr_device(n, gen)
+        inputs = table[torch.randint(0, usable, (n,), device="cuda", generator=gen)].contiguous()
+        pa, ps = torch.empty_like(table), torch.empty_like(table)
+    stream.synchronize()
+    extra["lookup_permute_2p19_ms"] = timed(lambda: dom.lookup_permute_dev(inputs.data_ptr(), table.data_ptr(), usable,
+                                                                          pa.data_ptr(), ps.data_ptr()))
     del cols
 
 

@@ -35,7 +35,8 @@ typedef enum {
     ZKHIP_ERR_INVALID = -1,   /* bad argument (null pointer, size mismatch, unsupported log_n ...) */
     ZKHIP_ERR_HIP = -2,       /* HIP runtime failure, text in zkhip_last_error */
     ZKHIP_ERR_OOM = -3,       /* device allocation failed */
-    ZKHIP_ERR_UNSUPPORTED = -4
+    ZKHIP_ERR_UNSUPPORTED = -4,
+    ZKHIP_ERR_CONSTRAINT = -5 /* the witness violates a constraint the call depends on (upstream: Error::ConstraintSystemFailure) */
 } zkhip_status;
 
 typedef struct zkhip_ctx zkhip_ctx;
@@ -221,6 +222,13 @@ int zkhip_lookup_product_dev(zkhip_domain* dom, const uint64_t* d_compressed_inp
                              const uint64_t* d_permuted_input, const uint64_t* d_permuted_table, const uint64_t beta[4],
                              const uint64_t gamma[4], uint64_t* d_z);
 int zkhip_eval_polynomial_dev(zkhip_ctx* ctx, const uint64_t* d_coeff, size_t n, const uint64_t x[4], uint64_t out[4]);
+/* `plonk::lookup::prover::permute_expression_pair`: rows [0, usable_rows) of the permuted input A' (the compressed input
+ * sorted by canonical value) and of the permuted table S' (S'[i] = A'[i] where A'[i] first occurs; the table values left
+ * over, ascending, fill the repeated rows from the last one backwards).  usable_rows = n - (blinding_factors + 1); the
+ * remaining rows are upstream's blinding rows, drawn from the prover's RNG by the caller.  Returns ZKHIP_ERR_CONSTRAINT
+ * when an input value is missing from the table (upstream: Error::ConstraintSystemFailure).  Synchronises. */
+int zkhip_lookup_permute_dev(zkhip_domain* dom, const uint64_t* d_compressed_input, const uint64_t* d_compressed_table,
+                             uint32_t usable_rows, uint64_t* d_permuted_input, uint64_t* d_permuted_table);
 int zkhip_poly_lincomb_dev(zkhip_ctx* ctx, const uint64_t* const* d_polys, const size_t* lens, const uint64_t* coeffs,
                            uint32_t num, size_t n, uint64_t* d_out);
 int zkhip_kate_division_dev(zkhip_ctx* ctx, const uint64_t* d_poly, size_t n, const uint64_t point[4], uint64_t* d_out);
@@ -248,7 +256,7 @@ int zkhip_cosets_to_extended_dev(zkhip_domain* dom, const uint64_t* d_compact, c
 /* Kernel timing hook: average duration in microseconds of the launches of the named kernel family issued on
  * this context since the last zkhip_timing_reset (measured with HIP events on the launch stream).
  * families: "ntt", "msm_sort", "msm_accumulate", "msm_merge", "msm_reduce", "evalh", "batch_invert",
- * "prefix_product", "grand_product", "eval_polynomial", "poly_lincomb", "kate_division".  A family brackets every launch of its stage in one call (e.g. the passes of one NTT). */
+ * "prefix_product", "grand_product", "eval_polynomial", "poly_lincomb", "kate_division", "lookup_permute".  A family brackets every launch of its stage in one call (e.g. the passes of one NTT). */
 int zkhip_timing_enable(zkhip_ctx* ctx, int on);
 int zkhip_timing_reset(zkhip_ctx* ctx);
 int zkhip_timing_get(zkhip_ctx* ctx, const char* family, double* avg_us, uint64_t* launches);

@@ -536,3 +536,32 @@ def shplonk_create_proof(polys, queries, y: int, v: int, u: int, commit):
     final = [c * z0_inv % P for c in final]
     h2 = commit(final)
     return h1, h2, h_x, final
+
+
+# ---------------------------------------------------------------------------------------------
+# plonk::lookup::prover::permute_expression_pair (the sort behind the permuted lookup columns), restated step by
+# step from the published upstream algorithm; the blinding rows (prover RNG) are left out.
+# ---------------------------------------------------------------------------------------------
+def permute_expression_pair(input_expression, table_expression, usable_rows: int):
+    """Returns (permuted_input, permuted_table) over the first usable_rows rows, or raises ValueError where upstream
+    returns Error::ConstraintSystemFailure."""
+    permuted_input = sorted(v % P for v in input_expression[:usable_rows])
+    leftover = {}
+    for v in table_expression[:usable_rows]:
+        leftover[v % P] = leftover.get(v % P, 0) + 1
+    permuted_table = [0] * usable_rows
+    repeated_rows = []
+    for row, value in enumerate(permuted_input):
+        if row == 0 or value != permuted_input[row - 1]:
+            permuted_table[row] = value
+            if leftover.get(value, 0) > 0:
+                leftover[value] -= 1
+            else:
+                raise ValueError("input value not in table")
+        else:
+            repeated_rows.append(row)
+    for value in sorted(leftover):            # BTreeMap iteration: ascending
+        for _ in range(leftover[value]):
+            permuted_table[repeated_rows.pop()] = value
+    assert not repeated_rows
+    return permuted_input, permuted_table

@@ -6,8 +6,8 @@ script runs the *operator multiset* that `create_proof` issues for a constraint 
 columns, in upstream's phase order:
 
   1. advice:        commit_lagrange (MSM) and lagrange_to_coeff (iNTT) for every advice column
-  2. lookups:       per lookup two commitments of the permuted columns, the grand product z and its commitment,
-                    three iNTTs   (the host-side sort that builds the permuted columns is NOT replayed)
+  2. lookups:       per lookup the sort that builds the permuted columns (permute_expression_pair), two commitments
+                    of the permuted columns, the grand product z and its commitment, three iNTTs
   3. permutation:   per column set the grand product z, its commitment and iNTT
   4. quotient:      coeff_to_extended of every advice / instance / lookup polynomial, evaluate_h,
                     divide_by_vanishing_poly, extended_to_coeff, commitments of the d-1 pieces of h
@@ -131,6 +131,21 @@ def main():
     dom.lagrange_to_coeff_dev(instance.data_ptr(), I)
 
     # ---- 2. lookups -------------------------------------------------------------------------------------
+    # permuted columns a', s' from (compressed input, compressed table): the table column is random and the input column
+    # draws its values from the table, as a satisfied lookup does
+    usable = n - (cs.blinding_factors() + 1)
+
+    def lookup_permute():
+        for i in range(L):
+            dom.lookup_permute_dev(colptr(lk_cols, 4 * i, n), colptr(lk_cols, 4 * i + 1, n), usable,
+                                   colptr(lk_cols, 4 * i + 2, n), colptr(lk_cols, 4 * i + 3, n))
+    with torch.cuda.stream(stream):
+        view = lk_cols.view(L, 4, n, 4)
+        pick = torch.randint(0, usable, (n,), device="cuda", generator=gen)
+        for i in range(L):
+            view[i, 0] = view[i, 1][pick]
+    stream.synchronize()
+    ph.run("lookup_permute", lookup_permute)
     # commitments of a' and s' (2L MSMs), then z from (input, table, a', s') and its commitment, then 3L iNTTs
     ph.run("lookup_commit_msm", lambda: batched(
         lambda s, c: ctx.msm_batch_dev(bid, [colptr(lk_cols, 4 * (s + i) + 2 + j, n) for i in range(c) for j in range(2)], n), L))
@@ -256,7 +271,7 @@ def main():
     n_msm = A + 3 * L + sets + 1 + pieces
     line = {
         "what": "replay of the create_proof polynomial pipeline on synthetic columns (one MI355X); host-side witness "
-                "generation, lookup sorting and transcript hashing are not included",
+                "generation and transcript hashing are not included",
         "shape": {"k": k, "extended_k": ek, "advice": A, "fixed": F, "instance": I, "lookups": L,
                   "lookup_width": args.lookup_width, "permutation_columns": len(pcols), "permutation_sets": sets,
                   "degree": d, "gate_polynomials": args.gate_polys},

@@ -500,6 +500,37 @@ def gen_shplonk():
     dump("shplonk.json", out)
 
 
+def gen_lookup_permute():
+    """permute_expression_pair from its specification rather than upstream's loop: A' is A sorted; among all S' that are
+    permutations of S with S'[i] = A'[i] on first occurrences, upstream's is the one whose remaining rows, read from the
+    last repeated row backwards, are ascending.  Built here by multiset subtraction with collections.Counter."""
+    import collections
+    rnd = random.Random(SEED + 13)
+    out = {"comment": "canonical hex; rows [0, usable_rows) only", "cases": []}
+    for k, usable, tsize in [(3, 5, 3), (5, 26, 9), (6, 58, 58)]:
+        n = 1 << k
+        tvals = [rnd.randrange(P) for _ in range(tsize - 1)] + [0]
+        table = [tvals[i % tsize] if i >= tsize else tvals[i] for i in range(n)]
+        rnd.shuffle(table)
+        present = sorted(set(table[:usable]))
+        inputs = [rnd.choice(present[:max(1, len(present) // 2)]) for _ in range(n)]
+        a_sorted = sorted(inputs[:usable])
+        firsts = [i for i in range(usable) if i == 0 or a_sorted[i] != a_sorted[i - 1]]
+        rest = collections.Counter(table[:usable]) - collections.Counter(a_sorted[i] for i in firsts)
+        left = sorted(rest.elements())
+        repeated = [i for i in range(usable) if i not in set(firsts)]
+        assert len(left) == len(repeated)
+        s_perm = [None] * usable
+        for i in firsts:
+            s_perm[i] = a_sorted[i]
+        for v, row in zip(left, reversed(repeated)):
+            s_perm[row] = v
+        assert hm.permute_expression_pair(inputs, table, usable) == (a_sorted, s_perm)
+        out["cases"].append({"k": k, "usable_rows": usable, "input": [hx(v) for v in inputs], "table": [hx(v) for v in table],
+                             "permuted_input": [hx(v) for v in a_sorted], "permuted_table": [hx(v) for v in s_perm]})
+    dump("lookup_permute.json", out)
+
+
 if __name__ == "__main__":
     bn.self_check()
     gen_field()
@@ -511,3 +542,4 @@ if __name__ == "__main__":
     gen_evalh()
     gen_products()
     gen_shplonk()
+    gen_lookup_permute()

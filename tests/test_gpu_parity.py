@@ -781,3 +781,96 @@ def test_evaluate_h_split_by_coset_matches_whole(ctx, co, k, kw):
                     back[j::1 << e] = part[s::len(cosets)]
             assert np.array_equal(back, whole), (world, form)
     d.close()
+
+
+# ------------------------------------------------------------------------------------------------ lookup permutation
+def _lookup_pair(rng, n, usable, table_size, distinct_inputs):
+    """table column: `table_size` distinct values padded with repeats of the first one (as halo2 tables are padded);
+    input column: draws from a subset of the table"""
+    table_vals = [int(v) for v in rng.integers(1, 2 ** 62, size=table_size)] + [0, P - 1]
+    table = [table_vals[i] if i < len(table_vals) else table_vals[0] for i in range(n)]
+    order = rng.permutation(usable)
+    table[:usable] = [table[i] for i in order]
+    pool = [table_vals[int(i)] for i in rng.integers(0, len(table_vals), size=distinct_inputs)]
+    inputs = [pool[int(i)] for i in rng.integers(0, len(pool), size=n)]
+    return inputs, table
+
+
+@pytest.mark.parametrize("k,blinding,table_size,distinct", [(4, 5, 6, 3), (7, 5, 100, 100), (10, 6, 300, 17),
+                                                            (12, 5, 4000, 4000), (16, 7, 1 << 15, 5000)])
+def test_lookup_permute_vs_model(ctx, k, blinding, table_size, distinct):
+    import halo2_model as hm
+    n = 1 << k
+    usable = n - (blinding + 1)
+    table_size = min(table_size, usable - 2)
+    rng = np.random.default_rng(k)
+    inputs, table = _lookup_pair(rng, n, usable, table_size, distinct)
+    exp_a, exp_s = hm.permute_expression_pair(inputs, table, usable)
+    d = zk.Domain(ctx, 3, k)
+    d_a, d_s = ctx.upload(fr_arr(inputs)), ctx.upload(fr_arr(table))
+    marker = rand_fr(rng, n)
+    d_pa, d_ps = ctx.upload(marker), ctx.upload(marker)
+    d.lookup_permute_dev(d_a, d_s, usable, d_pa, d_ps)
+    got_a, got_s = ctx.download(d_pa, (n, 4)), ctx.download(d_ps, (n, 4))
+    assert fr_ints(got_a[:usable]) == exp_a
+    assert fr_ints(got_s[:usable]) == exp_s
+    # the blinding rows belong to the caller
+    assert np.array_equal(got_a[usable:], marker[usable:]) and np.array_equal(got_s[usable:], marker[usable:])
+    # the lookup argument's row conditions hold: A'[i] = S'[i] or A'[i] = A'[i-1], and A'[0] = S'[0]
+    assert exp_a[0] == exp_s[0] and all(a == s or a == p_ for a, s, p_ in zip(exp_a[1:], exp_s[1:], exp_a[:-1]))
+    # an input value outside the table is the constraint-system failure upstream reports
+    bad = list(inputs)
+    bad[3] = 12345678901234567890123
+    ctx.upload(fr_arr(bad), d_a)
+    with pytest.raises(ffi.ZkhipError):
+        d.lookup_permute_dev(d_a, d_s, usable, d_pa, d_ps)
+    with pytest.raises(ValueError):
+        hm.permute_expression_pair(bad, table, usable)
+    for p_ in (d_a, d_s, d_pa, d_ps):
+        ctx.free(p_)
+    d.close()
+
+
+def test_lookup_permute_full_size_feeds_the_grand_product(ctx):
+    """k = 19: permuted columns from the device sort, then the lookup grand product over them telescopes to one on the
+    last usable row (the property the verifier's l_last check relies on)"""
+    k, blinding = 19, 5
+    n = 1 << k
+    usable = n - (blinding + 1)
+    rng = np.random.default_rng(19)
+    table = rand_fr(rng, n)
+    pick = rng.integers(0, usable, size=n)
+    inputs = table[pick]
+    d = zk.Domain(ctx, 3, k)
+    d_a, d_s, d_pa, d_ps, d_z = (ctx.upload(x) for x in (inputs, table, inputs, table, table))
+    d.lookup_permute_dev(d_a, d_s, usable, d_pa, d_ps)
+    pa, ps = ctx.download(d_pa, (n, 4)), ctx.download(d_ps, (n, 4))
+    # sortedness of A' (canonical order) at sampled positions and the row conditions everywhere, on limbs
+    same_as = (pa[1:usable] == ps[1:usable]).all(axis=1)
+    same_prev = (pa[1:usable] == pa[:usable - 1]).all(axis=1)
+    assert (same_as | same_prev).all() and (pa[0] == ps[0]).all()
+    idx = rng.integers(0, usable - 1, size=2000)
+    vals = fr_ints(pa[idx]), fr_ints(pa[idx + 1])
+    assert all(a <= b for a, b in zip(*vals))
+    beta, gamma = rand_fr(rng, 2)
+    d.lookup_product_dev(d_a, d_s, d_pa, d_ps, beta, gamma, d_z)
+    z = ctx.download(d_z, (n, 4))
+    one = fr_arr([1])[0]
+    assert np.array_equal(z[0], one) and np.array_equal(z[usable], one)
+    for p_ in (d_a, d_s, d_pa, d_ps, d_z):
+        ctx.free(p_)
+    d.close()
+
+
+def test_lookup_permute_golden(ctx):
+    for c in golden("lookup_permute.json")["cases"]:
+        n, usable = 1 << c["k"], c["usable_rows"]
+        d = zk.Domain(ctx, 3, c["k"])
+        d_a, d_s = ctx.upload(hex_fr(c["input"])), ctx.upload(hex_fr(c["table"]))
+        d_pa, d_ps = ctx.alloc(n * 32), ctx.alloc(n * 32)
+        d.lookup_permute_dev(d_a, d_s, usable, d_pa, d_ps)
+        assert np.array_equal(ctx.download(d_pa, (usable, 4)), hex_fr(c["permuted_input"]))
+        assert np.array_equal(ctx.download(d_ps, (usable, 4)), hex_fr(c["permuted_table"]))
+        for p_ in (d_a, d_s, d_pa, d_ps):
+            ctx.free(p_)
+        d.close()

@@ -186,6 +186,14 @@ def test_shplonk_golden():
         assert hm.kate_division(ints(c["a"]), int(c["point"], 16)) == ints(c["q"])
 
 
+def test_lookup_permute_golden():
+    g = golden("lookup_permute.json")
+    ints = lambda hs: [int(h, 16) for h in hs]
+    for c in g["cases"]:
+        a, s_ = hm.permute_expression_pair(ints(c["input"]), ints(c["table"]), c["usable_rows"])
+        assert a == ints(c["permuted_input"]) and s_ == ints(c["permuted_table"])
+
+
 def test_model_multiexp_threads_agree():
     rnd = np.random.default_rng(5)
     n = 40
