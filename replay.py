@@ -212,6 +212,7 @@ def main():
     ctx.timing_reset()
     ph.run("evaluate_h", lambda: dom.evaluate_h(desc, h.data_ptr()))
     evalh_kernel_ms = ctx.timing_get("evalh")[0] / 1e3
+    evalh_program = ctx.evaluate_h_last_stats()
     ctx.timing_enable(False)
     ph.run("divide_by_vanishing_poly", lambda: dom.divide_by_vanishing_poly_dev(h.data_ptr()))
     ph.run("extended_to_coeff", lambda: dom.extended_to_coeff_dev(h.data_ptr(), h_coeff.data_ptr()))
@@ -276,7 +277,7 @@ def main():
                   "lookup_width": args.lookup_width, "permutation_columns": len(pcols), "permutation_sets": sets,
                   "degree": d, "gate_polynomials": args.gate_polys},
         "total_s": total, "phases_s": ph.t, "msm_count": n_msm, "msm_total_s": msm_s, "msm_ms_each": msm_s / n_msm * 1e3,
-        "coset_ntt_count": A + I + 3 * L + sets, "evalh_kernel_ms": evalh_kernel_ms, "eval_polynomial_count": n_queries,
+        "coset_ntt_count": A + I + 3 * L + sets, "evalh_kernel_ms": evalh_kernel_ms, "evalh_program": evalh_program, "eval_polynomial_count": n_queries,
         "shplonk": {"polynomials": len(shapes), "queries": n_queries, "poly_lincomb_calls": lincomb_n,
                     "poly_lincomb_avg_us": lincomb_us, "kate_division_calls": kate_n, "kate_division_avg_us": kate_us},
         "host_program_build_s": host_setup_s,

@@ -17,9 +17,10 @@
 //                           the chip.  Each lane gathers its table points and folds them with XYZZ mixed additions
 //   5. merge              : per bucket, two lanes fold the slot sums and join by a shuffle (heavy buckets of skewed
 //                           scalars first pass through serial pre-levels of 16 sums per lane)
-//   6. reduce             : sum (b + 1) S_b without scalar multiplications: per wave of 64 buckets a suffix scan by
-//                           shuffles gives sum P_i and sum i P_i in 12 additions; a second level does the same for
-//                           the 512 wave sums and the host joins the 24 leftover points
+//   6. reduce             : sum (b + 1) S_b without scalar multiplications: per wave of 64 buckets six rounds of
+//                           shuffles and additions give the total and the six "bit sums" (sum of the buckets whose
+//                           index has bit j set); a second level folds those over the waves in nine more rounds and
+//                           the host joins the 16 leftover points by Horner in powers of two
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
@@ -563,62 +564,61 @@ __global__ void __launch_bounds__(256) merge_final_kernel(const g1_xyzz* in, con
 }
 
 // ---- reduce ----------------------------------------------------------------------------------------
-// sum over b of (b + 1) * S_b.  Within a wave of 64 consecutive points P_0..P_63 a suffix scan T_i = sum_{k >= i} P_k
-// gives A = T_0 = sum P_i and V = sum_{i >= 1} T_i = sum i * P_i in 12 point additions, with no scalar multiplication.
-// Level 1 does this for every 64 buckets, level 2 for the A's of 64 waves; the host joins the <= 24 leftovers.
-__device__ __forceinline__ void wave_weighted_sum(g1_xyzz_w p, uint32_t lane, g1_xyzz_w& a_out, g1_xyzz_w& v_out) {
-    for (int d = 1; d < 64; d <<= 1) {
-        g1_xyzz_w o = xyzz_w_shfl(p, (int)((lane + d) & 63));
-        if (lane + d >= 64) o.inf = true;
+// sum over b of (b + 1) * S_b without scalar multiplications and with a short dependency chain.  For 2^NB points P_l
+// held one per lane, NB rounds of one point addition each leave in lane 0 the total A = sum P_l and in lane 2^j the
+// "bit sum" B_j = sum of the P_l with bit j of l set, so that sum l * P_l = sum_j 2^j B_j:
+//   round r: every lane whose bit r is clear adds the value of lane l | 2^r.
+// The lanes with low r bits clear carry the running totals of their 2^r-blocks; the upper half of each pair keeps its
+// total U, which from then on is only summed over the higher bits (it sits in the lanes with lowest set bit r).
+// A lone wave needs ~8 us per dependent point addition, so the chain length is what this phase costs: 6 additions in
+// level 1 and 9 in level 2, against 12 + 12 for a suffix-scan formulation.
+template <int NB>
+__device__ __forceinline__ g1_xyzz_w lanes_bit_sums(g1_xyzz_w p, uint32_t lane) {
+#pragma unroll 1
+    for (int r = 0; r < NB; r++) {
+        g1_xyzz_w o = xyzz_w_shfl(p, (int)(lane | (1u << r)));
+        // a lane whose bit r is set would read itself: give it the identity, or the whole wave walks through the
+        // doubling branch of the addition for nothing
+        if ((lane >> r) & 1u) o.inf = true;
         p = xyzz_w_add(p, o);
     }
-    a_out = xyzz_w_shfl(p, 0);
-    g1_xyzz_w v = p;
-    if (lane == 0) v.inf = true;
-    for (int d = 32; d >= 1; d >>= 1) {
-        const g1_xyzz_w o = xyzz_w_shfl(v, (int)(lane ^ d));
-        v = xyzz_w_add(v, o);
-    }
-    v_out = v;
+    return p;
 }
-__device__ __forceinline__ g1_xyzz_w wave_sum_xyzz(g1_xyzz_w v, uint32_t lane) {
-    for (int d = 32; d >= 1; d >>= 1) {
-        const g1_xyzz_w o = xyzz_w_shfl(v, (int)(lane ^ d));
-        v = xyzz_w_add(v, o);
-    }
-    return v;
-}
+constexpr uint32_t RED_STREAMS = 7;    // the total and six bit sums of every wave of level 1
+constexpr size_t REDUCE_OUT = 16;      // [0] total, [1 + i] D_i (i < 9), [10 + j] sum over the waves of B_j (j < 6)
 
-// level 1: sums[b] for b < B (B a multiple of 64) -> a1[j], v1[j] for wave j = b / 64.  (Running the plain sums and
-// the weighted sums as two concurrent kernels would shorten the dependency chain from 24 to 18 additions, but the
-// co-scheduled waves slow each other down by more than that: measured 250 us against 213 us.)
-__global__ void __launch_bounds__(256) reduce_level1_kernel(const g1_xyzz* sums, uint32_t B, g1_xyzz* a1, g1_xyzz* v1) {
+// level 1: sums[b] for b < B (B a multiple of 64) -> l1[0][h] = A_h, l1[1 + j][h] = B_{h,j} for wave h = b / 64
+// (J = number of waves = row stride of l1)
+__global__ void __launch_bounds__(256) reduce_level1_kernel(const g1_xyzz* sums, uint32_t B, uint32_t J, g1_xyzz* l1) {
     const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x, lane = threadIdx.x & 63;
     g1_xyzz_w p = b < B ? xyzz_w_load(sums + b) : xyzz_w_identity();
-    g1_xyzz_w a, v;
-    wave_weighted_sum(p, lane, a, v);
-    if (lane == 0) {
-        xyzz_w_store(a1 + (b >> 6), a);
-        xyzz_w_store(v1 + (b >> 6), v);
+    p = lanes_bit_sums<6>(p, lane);
+    if (b < B && (lane & (lane - 1)) == 0) {   // lanes 0, 1, 2, 4, 8, 16, 32
+        const uint32_t stream = lane ? 1u + (uint32_t)__builtin_ctz(lane) : 0u;
+        xyzz_w_store(l1 + (size_t)stream * J + (b >> 6), p);
     }
 }
-// level 2 (16 blocks of one wave, J <= 512): blocks h < 8 take a1[64 h + lane] -> out[h] = sum, out[8 + h] = sum of
-// lane * a1[64 h + lane]; blocks 8 + h take v1[64 h + lane] -> out[16 + h] = sum.
-__global__ void __launch_bounds__(64) reduce_level2_kernel(const g1_xyzz* a1, const g1_xyzz* v1, uint32_t J, g1_xyzz* out) {
-    const uint32_t lane = threadIdx.x, h = blockIdx.x & 7;
-    const uint32_t j = h * 64 + lane;
-    if (blockIdx.x < 8) {
-        g1_xyzz_w p = j < J ? xyzz_w_load(a1 + j) : xyzz_w_identity();
-        g1_xyzz_w a, v;
-        wave_weighted_sum(p, lane, a, v);
-        if (lane == 0) {
-            xyzz_w_store(out + h, a);
-            xyzz_w_store(out + 8 + h, v);
-        }
-    } else {
-        g1_xyzz_w p = j < J ? xyzz_w_load(v1 + j) : xyzz_w_identity();
-        p = wave_sum_xyzz(p, lane);
-        if (lane == 0) xyzz_w_store(out + 16 + h, p);
+// level 2: workgroup `stream` (eight waves) folds l1[stream][0 .. J), J <= 512.  Wave w takes the waves h = 64 w + lane
+// of level 1; then one wave folds the eight results.  Stream 0 (the totals A_h) keeps its bit sums: over the lane bits
+// they are D_0..D_5, over the wave index D_6..D_8, with D_i = sum of the A_h with bit i of h set.
+__global__ void __launch_bounds__(512) reduce_level2_kernel(const g1_xyzz* l1, uint32_t J, g1_xyzz* out) {
+    __shared__ g1_xyzz_w ex[8][RED_STREAMS];
+    const uint32_t stream = blockIdx.x, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const uint32_t h = w * 64 + lane;
+    g1_xyzz_w p = h < J ? xyzz_w_load(l1 + (size_t)stream * J + h) : xyzz_w_identity();
+    p = lanes_bit_sums<6>(p, lane);
+    if ((lane & (lane - 1)) == 0) ex[w][lane ? 1 + __builtin_ctz(lane) : 0] = p;
+    __syncthreads();
+    if (w != 0) return;
+    // lane 8 g + u: element u (the wave index of above) of group g; group 0 = totals, group 1 + j = bit sums j
+    const uint32_t g = lane >> 3, u = lane & 7;
+    g1_xyzz_w q = g < RED_STREAMS ? ex[u][g] : xyzz_w_identity();
+    q = lanes_bit_sums<3>(q, lane);
+    if (stream == 0) {
+        if (g == 0 && (u & (u - 1)) == 0) xyzz_w_store(out + (u ? 7 + __builtin_ctz(u) : 0), q);   // total, D_6..D_8
+        else if (g >= 1 && g < RED_STREAMS && u == 0) xyzz_w_store(out + g, q);                     // D_0..D_5
+    } else if (lane == 0) {
+        xyzz_w_store(out + 9 + stream, q);                                                          // sum of B_{.,stream-1}
     }
 }
 
@@ -707,9 +707,8 @@ struct MsmWorkspace {
     bool nonzero = false;
     uint32_t *counts, *entries, *start, *cnt, *offA, *cntA, *offB, *cntB, *info, *plan, *cur, *bincount;
     uint2* tmp;
-    g1_xyzz *itemsA, *itemsB, *sums, *a1, *v1, *out2;
+    g1_xyzz *itemsA, *itemsB, *sums, *l1, *out2;
 };
-constexpr size_t REDUCE_OUT = 24;
 
 static int ws_prepare(zkhip_ctx* ctx, MsmWorkspace& ws, const MsmTables& tb, size_t n) {
     const uint32_t B = 1u << (tb.c - 1), W = tb.W;
@@ -735,7 +734,7 @@ static int ws_prepare(zkhip_ctx* ctx, MsmWorkspace& ws, const MsmTables& tb, siz
                  o_offB = take(((size_t)B + 1) * 4), o_cntB = take((size_t)B * 4), o_info = take(64),
                  o_plan = take((size_t)ws.plan_blocks * PLAN_STRIDE * 4), o_itemsA = take(T1_max * sizeof(g1_xyzz)),
                  o_itemsB = take((T1_max / MERGE_F + B + 1) * sizeof(g1_xyzz)), o_sums = take((size_t)B * sizeof(g1_xyzz)),
-                 o_a1 = take((J + 4) * sizeof(g1_xyzz)), o_v1 = take((J + 4) * sizeof(g1_xyzz)),
+                 o_l1 = take((size_t)RED_STREAMS * J * sizeof(g1_xyzz)),
                  o_out2 = take(REDUCE_OUT * sizeof(g1_xyzz));
     if (off > ws.bytes) {
         if (ws.base) {
@@ -768,8 +767,7 @@ static int ws_prepare(zkhip_ctx* ctx, MsmWorkspace& ws, const MsmTables& tb, siz
     ws.itemsA = (g1_xyzz*)(p + o_itemsA);
     ws.itemsB = (g1_xyzz*)(p + o_itemsB);
     ws.sums = (g1_xyzz*)(p + o_sums);
-    ws.a1 = (g1_xyzz*)(p + o_a1);
-    ws.v1 = (g1_xyzz*)(p + o_v1);
+    ws.l1 = (g1_xyzz*)(p + o_l1);
     ws.out2 = (g1_xyzz*)(p + o_out2);
     return ZKHIP_OK;
 }
@@ -874,42 +872,31 @@ static int msm_phase2(zkhip_ctx* ctx, MsmWorkspace& ws, const MsmTables& tb, boo
     }
     {
         TimedRegion tr(ctx, timed ? "msm_reduce" : nullptr, st);
-        const uint32_t blocks1 = (B + 255) / 256, J = blocks1 * 4;
-        hipLaunchKernelGGL(reduce_level1_kernel, dim3(blocks1), dim3(256), 0, st, ws.sums, B, ws.a1, ws.v1);
-        hipLaunchKernelGGL(reduce_level2_kernel, dim3(16), dim3(64), 0, st, ws.a1, ws.v1, J, ws.out2);
+        const uint32_t blocks1 = (B + 255) / 256, J = B / 64;   // B is a multiple of 128
+        hipLaunchKernelGGL(reduce_level1_kernel, dim3(blocks1), dim3(256), 0, st, ws.sums, B, J, ws.l1);
+        hipLaunchKernelGGL(reduce_level2_kernel, dim3(RED_STREAMS), dim3(512), 0, st, ws.l1, J, ws.out2);
         ZK_HIP(ctx, hipGetLastError());
     }
     ZK_HIP(ctx, hipMemcpyAsync(ws.h_sums, ws.out2, REDUCE_OUT * sizeof(g1_xyzz), hipMemcpyDeviceToHost, st));
     return ZKHIP_OK;
 }
 
-// phase 3: waits for the leftover sums of the reduce and joins them on the host.  With a_h, v_h, s_h (h < 8) the three
-// groups of level 2:  result = sum s_h + sum a_h + 64 * (sum v_h + 64 * sum h * a_h)
+// phase 3: waits for the leftover sums of the reduce and joins them on the host:
+//   result = total + sum_{t < 15} 2^t X_t,  X_t = sum over the waves of B_t for t < 6, D_(t - 6) for t >= 6
+// (bucket b = 64 h + l weighs b + 1 = 64 h + l + 1), by Horner: 14 doublings and 15 additions.
 static int msm_phase3(zkhip_ctx* ctx, MsmWorkspace& ws, uint64_t out_jacobian[12]) {
     ZK_HIP(ctx, hipStreamSynchronize(ws.stream));
     memset(out_jacobian, 0, 96);
     if (!ws.nonzero) return ZKHIP_OK;
-    uint64_t a[8][12], t[12], run[12], ha[12], acc[12];
-    memset(run, 0, sizeof run);
-    memset(ha, 0, sizeof ha);
-    for (int h = 0; h < 8; h++) xyzz_to_jacobian_host(a[h], ws.h_sums + 16 * h);
-    for (int h = 7; h >= 1; h--) {   // sum h * a_h by running sums
-        h_g1_add(run, run, a[h]);
-        h_g1_add(ha, ha, run);
-    }
-    h_g1_add(run, run, a[0]);        // run = sum a_h
-    for (int k = 0; k < 6; k++) h_g1_double(ha, ha);
-    for (int h = 0; h < 8; h++) {
-        xyzz_to_jacobian_host(t, ws.h_sums + 16 * (8 + h));
-        h_g1_add(ha, ha, t);
-    }
-    for (int k = 0; k < 6; k++) h_g1_double(ha, ha);
-    memcpy(acc, ha, sizeof acc);
-    h_g1_add(acc, acc, run);
-    for (int h = 0; h < 8; h++) {
-        xyzz_to_jacobian_host(t, ws.h_sums + 16 * (16 + h));
+    uint64_t acc[12], t[12];
+    memset(acc, 0, sizeof acc);
+    for (int k = 14; k >= 0; k--) {
+        h_g1_double(acc, acc);
+        xyzz_to_jacobian_host(t, ws.h_sums + 16 * (k < 6 ? 10 + k : 1 + (k - 6)));
         h_g1_add(acc, acc, t);
     }
+    xyzz_to_jacobian_host(t, ws.h_sums);
+    h_g1_add(acc, acc, t);
     memcpy(out_jacobian, acc, 96);
     return ZKHIP_OK;
 }
