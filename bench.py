@@ -413,15 +413,18 @@ def finish(args, ctx, dist, world, rank, local_rank, bid, scalars, n, en, elapse
                          "peak": VALU_MAD_PEAK / 1e12, "unit": "Tmad/s", "frac": achieved / VALU_MAD_PEAK,
                          "avg_launch_us": acc_us, "launches": acc_launches,
                          # HBM bytes per launch from separate rocprofv3 --pmc passes over this same command
-                         # (profiles/r01_pmc_summary_v3.txt: FETCH_SIZE 630.8e3 KiB, WRITE_SIZE 57.1e3 KiB); the
+                         # (profiles/r01_pmc_summary_v5.txt: FETCH_SIZE 667.4e3 KiB, WRITE_SIZE 69.6e3 KiB); the
                          # algorithmic gather is n*W 64-byte points + 4-byte entries = 571 MB
-                         "traffic": 704.4e6, "traffic_unit": "bytes per launch (FETCH_SIZE + WRITE_SIZE, measured offline)",
+                         "traffic": 754.7e6, "traffic_unit": "bytes per launch (FETCH_SIZE + WRITE_SIZE, measured offline)",
                          "algorithmic": f"{n}*{W} mixed adds * {MADS_PER_MADD} multiply-adds"},
             "roofline_ntt": {"bound": "hbm", "kernel": "ntt_tile_kernel (3 passes)", "achieved": ntt_bytes / (ntt_us * 1e-6) / 1e9 if ntt_us else 0.0,
                              "peak": HBM_PEAK, "unit": "GB/s", "frac": (ntt_bytes / (ntt_us * 1e-6) / 1e9 / HBM_PEAK) if ntt_us else 0.0,
                              "avg_launch_us": ntt_us,
                              # three passes: each reads and writes the 2^21-element buffer once (first pass reads 2^19)
-                             "traffic": 345.0e6, "traffic_unit": "bytes per transform (FETCH_SIZE x2 + WRITE_SIZE over its 3 launches, measured offline)",
+                             # and the last two read boundary twiddle tables (8 MB and 64 MB) by gather; the doubling of
+                             # FETCH_SIZE that gfx950 needs for streaming reads over-counts those gathers, so this is an
+                             # upper bound (profiles/r01_pmc_summary_v5.txt: 61.9e3 KiB read, 65.6e3 KiB written per launch)
+                             "traffic": 581.0e6, "traffic_unit": "bytes per transform (FETCH_SIZE x2 + WRITE_SIZE over its 3 launches, measured offline)",
                              "algorithmic_bytes": ntt_bytes,
                              # the transform is multiplier-bound, not HBM-bound: (M/2) log2 M butterfly products, two
                              # twiddle products per element between passes, the zeta scaling of 2/3 of the inputs
