@@ -148,6 +148,7 @@ typedef struct {
 
 enum { ZKHIP_MEM_HOST = 0, ZKHIP_MEM_DEVICE = 1 };
 enum { ZKHIP_FORM_COEFF = 0, ZKHIP_FORM_EXTENDED = 1 };
+enum { ZKHIP_BASIS_EXTENDED = 0, ZKHIP_BASIS_LAGRANGE = 1 };
 
 typedef struct {
     uint32_t mem;            /* where every polynomial pointer below (and `out`) lives */
@@ -178,6 +179,10 @@ typedef struct {
      * "extended" vector above and `out` are then in the compact layout of that list, 2^k * num_cosets rows.         */
     uint32_t num_cosets;
     const uint32_t* cosets;                /* host, num_cosets distinct values < 2^(extended_k - k) */
+    /* ZKHIP_BASIS_LAGRANGE: evaluate `custom_gates` alone over the 2^k rows of the circuit (every column given with 2^k
+     * rows, rotations move single rows, out has 2^k rows): `plonk::lookup::prover::Argument::commit_permuted`'s
+     * compress_expressions, with the theta-Horner of the expressions as the graph's last calculation.                 */
+    uint32_t basis;
 } zkhip_evalh_desc;
 
 /* out: 2^ext_k x 4 (host or device per desc->mem) = numerator of the quotient on the extended coset. */

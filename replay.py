@@ -6,7 +6,8 @@ script runs the *operator multiset* that `create_proof` issues for a constraint 
 columns, in upstream's phase order:
 
   1. advice:        commit_lagrange (MSM) and lagrange_to_coeff (iNTT) for every advice column
-  2. lookups:       per lookup the sort that builds the permuted columns (permute_expression_pair), two commitments
+  2. lookups:       per lookup the theta-compression of its input and table expressions over the Lagrange-basis columns,
+                    the sort that builds the permuted columns (permute_expression_pair), two commitments
                     of the permuted columns, the grand product z and its commitment, three iNTTs
   3. permutation:   per column set the grand product z, its commitment and iNTT
   4. quotient:      coeff_to_extended of every advice / instance / lookup polynomial, evaluate_h,
@@ -127,6 +128,24 @@ def main():
     # ---- 1. advice --------------------------------------------------------------------------------------
     ph.run("advice_commit_msm", lambda: batched(
         lambda s, c: ctx.msm_batch_dev(bid, [colptr(advice, s + i, n) for i in range(c)], n), A))
+    # lookup expressions are compressed over the Lagrange-basis columns, i.e. before the columns go to coefficient form
+    # (upstream keeps both forms); the results are stand-ins only: a satisfied lookup is constructed below
+    t0 = time.perf_counter()
+    lag_fixed = [colptr(fixed_ext, i, n) for i in range(F)]
+    lag_advice = [colptr(advice, i, n) for i in range(A)]
+    lag_instance = [colptr(instance, i, n) for i in range(I)]
+    ch_limbs = rand_fr_device(cs.num_challenges, gen).cpu().numpy().view(np.uint64)
+    compress_descs = []
+    for lk in cs.lookups:
+        for exprs in (lk.input_expressions, lk.table_expressions):
+            c = evalh_host.lookup_compress_call(cs, exprs, lag_fixed, lag_advice, lag_instance, ch_limbs, theta)
+            compress_descs.append((c, c.build(ffi.MEM_DEVICE, ffi.FORM_EXTENDED)))
+    host_setup_s += time.perf_counter() - t0
+
+    def lookup_compress():
+        for j, (_, desc_) in enumerate(compress_descs):
+            dom.evaluate_h(desc_, colptr(lk_cols, 4 * (j // 2) + (j % 2), n))
+    ph.run("lookup_compress", lookup_compress)
     ph.run("advice_lagrange_to_coeff", lambda: batched(lambda s, c: dom.lagrange_to_coeff_dev(colptr(advice, s, n), c), A))
     dom.lagrange_to_coeff_dev(instance.data_ptr(), I)
 

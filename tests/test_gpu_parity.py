@@ -874,3 +874,68 @@ def test_lookup_permute_golden(ctx):
         for p_ in (d_a, d_s, d_pa, d_ps):
             ctx.free(p_)
         d.close()
+
+
+# ------------------------------------------------------------------------------------------------ lookup compression
+def _direct_expr(e, cols, ch, idx, size):
+    t = e[0]
+    if t == "const":
+        return e[1]
+    if t in ("fixed", "advice", "instance"):
+        return cols[t][e[1]][(idx + e[2]) % size]
+    if t == "challenge":
+        return ch[e[1]]
+    if t == "neg":
+        return (-_direct_expr(e[1], cols, ch, idx, size)) % P
+    if t == "sum":
+        return (_direct_expr(e[1], cols, ch, idx, size) + _direct_expr(e[2], cols, ch, idx, size)) % P
+    if t == "prod":
+        return _direct_expr(e[1], cols, ch, idx, size) * _direct_expr(e[2], cols, ch, idx, size) % P
+    return _direct_expr(e[1], cols, ch, idx, size) * e[2] % P
+
+
+@pytest.mark.parametrize("k,kw", [(6, dict()), (9, dict(num_advice=12, num_fixed=5, num_lookups=4, lookup_width=4,
+                                                        rotations=(-3, -1, 0, 1, 2)))])
+def test_lookup_compress_expressions_on_lagrange_basis(ctx, k, kw):
+    """compress_expressions: each lookup side folded in theta over the 2^k rows, against direct evaluation of the
+    expression trees; host and device memory"""
+    cs = synthetic.synthetic_cs(**kw)
+    d = zk.Domain(ctx, cs.degree(), k)
+    n = d.n
+    rng = np.random.default_rng(k)
+    cols = {"fixed": [rand_fr(rng, n) for _ in range(cs.num_fixed_columns)],
+            "advice": [rand_fr(rng, n) for _ in range(cs.num_advice_columns)],
+            "instance": [rand_fr(rng, n) for _ in range(cs.num_instance_columns)]}
+    ints = {t: [fr_ints(c) for c in v] for t, v in cols.items()}
+    challenges = rand_fr(rng, cs.num_challenges)
+    ch = fr_ints(challenges)
+    theta = rand_fr(rng, 1)[0]
+    th = fr_ints(theta[None])[0]
+    for lk in cs.lookups:
+        for exprs in (lk.input_expressions, lk.table_expressions):
+            exp = []
+            for row in range(n):
+                acc = 0
+                for e in exprs:
+                    acc = (acc * th + _direct_expr(e, ints, ch, row, n)) % P
+                exp.append(acc)
+            call = evalh_host.lookup_compress_call(cs, exprs, cols["fixed"], cols["advice"], cols["instance"], challenges, theta)
+            got = d.evaluate_h(call.build(ffi.MEM_HOST, ffi.FORM_EXTENDED))
+            assert got.shape[0] == n and fr_ints(got) == exp
+    # device-resident columns
+    dev = {t: [ctx.upload(c) for c in v] for t, v in cols.items()}
+    d_out = ctx.alloc(n * 32)
+    call = evalh_host.lookup_compress_call(cs, cs.lookups[0].input_expressions, dev["fixed"], dev["advice"], dev["instance"],
+                                           challenges, theta)
+    d.evaluate_h(call.build(ffi.MEM_DEVICE, ffi.FORM_EXTENDED), d_out)
+    call_h = evalh_host.lookup_compress_call(cs, cs.lookups[0].input_expressions, cols["fixed"], cols["advice"],
+                                             cols["instance"], challenges, theta)
+    assert np.array_equal(ctx.download(d_out, (n, 4)), d.evaluate_h(call_h.build(ffi.MEM_HOST, ffi.FORM_EXTENDED)))
+    # the Lagrange basis takes neither lookups nor coefficient form
+    with pytest.raises(ffi.ZkhipError):
+        d.evaluate_h(call_h.build(ffi.MEM_HOST, ffi.FORM_COEFF))
+    for v in dev.values():
+        for p_ in v:
+            ctx.free(p_)
+    ctx.free(d_out)
+    d.close()

@@ -595,7 +595,17 @@ extern "C" int zkhip_evaluate_h(zkhip_domain* dom, const zkhip_evalh_desc* desc,
     zkhip_ctx* ctx = dom->ctx;
     ZK_CHECK(ctx, desc && out, "evaluate_h: null descriptor or output");
     ZK_CHECK(ctx, desc->mem <= 1 && desc->poly_form <= 1, "evaluate_h: bad mem / poly_form");
-    ZK_CHECK(ctx, desc->l0 && desc->l_last && desc->l_active_row, "evaluate_h: l0 / l_last / l_active_row missing");
+    const bool lagrange = desc->basis == ZKHIP_BASIS_LAGRANGE;
+    ZK_CHECK(ctx, desc->basis <= 1, "evaluate_h: basis %u", desc->basis);
+    if (lagrange) {
+        // a graph evaluated over the 2^k rows of the circuit itself (rotations move single rows): what the prover does
+        // with the lookup expressions before it sorts them
+        ZK_CHECK(ctx, desc->custom_gates && !desc->num_lookups && !desc->num_perm_sets && !desc->num_cosets &&
+                          desc->poly_form == ZKHIP_FORM_EXTENDED,
+                 "evaluate_h: the Lagrange basis takes one graph, columns as given, no lookup / permutation / coset arguments");
+    } else {
+        ZK_CHECK(ctx, desc->l0 && desc->l_last && desc->l_active_row, "evaluate_h: l0 / l_last / l_active_row missing");
+    }
     ZK_CHECK(ctx, !desc->num_fixed || desc->fixed_cosets, "evaluate_h: fixed_cosets missing");
     ZK_CHECK(ctx, !desc->num_advice || desc->advice, "evaluate_h: advice missing");
     ZK_CHECK(ctx, !desc->num_instance || desc->instance, "evaluate_h: instance missing");
@@ -622,6 +632,7 @@ extern "C" int zkhip_evaluate_h(zkhip_domain* dom, const zkhip_evalh_desc* desc,
     CosetList cl;
     cl.num = 1u << (ek - k);
     if (compact && (rc = coset_list_check(dom, desc->cosets, desc->num_cosets, &cl))) return rc;
+    if (lagrange) cl.num = 1;
     uint32_t log_rows = k;
     while ((1u << (log_rows - k)) < cl.num) log_rows++;
     const size_t size = (size_t)1 << log_rows;
@@ -677,7 +688,8 @@ extern "C" int zkhip_evaluate_h(zkhip_domain* dom, const zkhip_evalh_desc* desc,
     for (uint32_t i = 0; i < desc->num_instance; i++)
         if ((rc = push(desc->instance[i], !coeff))) return rc;
     const uint32_t c_l0 = (uint32_t)cols.size();
-    if ((rc = push(desc->l0, true)) || (rc = push(desc->l_last, true)) || (rc = push(desc->l_active_row, true))) return rc;
+    if (!lagrange && ((rc = push(desc->l0, true)) || (rc = push(desc->l_last, true)) || (rc = push(desc->l_active_row, true))))
+        return rc;
     const uint32_t c_last = c_l0 + 1, c_active = c_l0 + 2;
 
     Builder b;

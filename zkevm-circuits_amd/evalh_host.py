@@ -38,6 +38,8 @@ class EvalhCall:
         self.lookups = []        # [(product, permuted_input, permuted_table)]
         self.perm_sigma, self.perm_z = [], []
         self.cosets = None       # list of coset indices: evaluate only these, every extended vector in compact layout
+        self.graph = None        # with basis = BASIS_LAGRANGE: the graph evaluated over the 2^k rows of the circuit
+        self.basis = ffi.BASIS_EXTENDED
 
     def build(self, mem=ffi.MEM_HOST, form=ffi.FORM_EXTENDED):
         cs, ev = self.cs, self.ev
@@ -63,8 +65,10 @@ class EvalhCall:
         d.challenges = C.c_void_p(ch.ctypes.data) if len(ch) else None
         d.y, d.beta, d.gamma, d.theta = (b.limbs(self.y), b.limbs(self.beta), b.limbs(self.gamma),
                                          b.limbs(self.theta))
-        d.l0, d.l_last, d.l_active_row = ptr(self.l0), ptr(self.l_last), ptr(self.l_active)
-        gates = b.graph(ev.custom_gates, fr_to_mont_limbs)
+        if self.basis == ffi.BASIS_EXTENDED:
+            d.l0, d.l_last, d.l_active_row = ptr(self.l0), ptr(self.l_last), ptr(self.l_active)
+        d.basis = self.basis
+        gates = b.graph(self.graph if self.graph is not None else ev.custom_gates, fr_to_mont_limbs)
         b.keep.append(gates)
         d.custom_gates = C.pointer(gates)
         lk_arr = (ffi.Lookup * max(len(self.lookups), 1))()
@@ -91,3 +95,31 @@ class EvalhCall:
             d.num_cosets, d.cosets = len(cl), C.c_void_p(cl.ctypes.data)
         self._keep = b
         return d
+
+
+def compress_graph(expressions):
+    """The graph of `compress_expressions` in `plonk::lookup::prover::Argument::commit_permuted`: the expressions of one
+    side of a lookup folded by Horner in theta (first expression = highest power), as upstream's Evaluator builds it for
+    the extended domain."""
+    from .plonk import GraphEvaluator, OP_HORNER, VS_CONSTANT, VS_THETA
+    g = GraphEvaluator()
+    parts = tuple(g.add_expression(x) for x in expressions)
+    g.add_calculation((OP_HORNER, (VS_CONSTANT, 0, 0), parts, (VS_THETA, 0, 0)))
+    return g
+
+
+def lookup_compress_call(cs: ConstraintSystem, expressions, fixed, advice, instance, challenges, theta):
+    """EvalhCall that evaluates theta-compressed `expressions` over the Lagrange-basis columns (2^k rows each)."""
+    call = EvalhCall(cs, ev=_NoGraphs())
+    call.basis = ffi.BASIS_LAGRANGE
+    call.graph = compress_graph(expressions)
+    call.fixed, call.advice, call.instance = fixed, advice, instance
+    call.challenges = challenges
+    call.y = call.beta = call.gamma = np.zeros(4, dtype=np.uint64)
+    call.theta = theta
+    return call
+
+
+class _NoGraphs:
+    custom_gates = None
+    lookups = ()

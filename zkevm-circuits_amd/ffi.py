@@ -83,11 +83,12 @@ class EvalhDesc(C.Structure):
                 ("perm_column_index", C.c_void_p), ("perm_sigma_cosets", C.POINTER(C.c_void_p)),
                 ("num_perm_sets", C.c_uint32), ("perm_product_cosets", C.POINTER(C.c_void_p)),
                 ("perm_chunk_len", C.c_uint32), ("blinding_factors", C.c_uint32),
-                ("num_cosets", C.c_uint32), ("cosets", C.c_void_p)]
+                ("num_cosets", C.c_uint32), ("cosets", C.c_void_p), ("basis", C.c_uint32)]
 
 
 MEM_HOST, MEM_DEVICE = 0, 1
 FORM_COEFF, FORM_EXTENDED = 0, 1
+BASIS_EXTENDED, BASIS_LAGRANGE = 0, 1
 
 
 def _p(a):
@@ -437,7 +438,7 @@ class Domain:
     def evaluate_h(self, desc: EvalhDesc, out_dev: int | None = None):
         """`Evaluator::evaluate_h`.  Host descriptor -> numpy result; device descriptor -> writes out_dev."""
         if desc.mem == MEM_HOST:
-            rows = self.n * desc.num_cosets if desc.num_cosets else self.extended_len
+            rows = self.n if desc.basis else (self.n * desc.num_cosets if desc.num_cosets else self.extended_len)
             out = np.empty((rows, 4), dtype=np.uint64)
             self.ctx._ck(self._l.zkhip_evaluate_h(self.h, C.byref(desc), _p(out)))
             return out
