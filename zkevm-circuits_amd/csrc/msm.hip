@@ -519,19 +519,80 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))
 }
 
 // ---- merge -----------------------------------------------------------------------------------------
-// pre-level for very heavy buckets: one lane folds up to F consecutive items of one bucket
-__global__ void __launch_bounds__(256) merge_kernel(const g1_xyzz* in, const uint32_t* off_in, const uint32_t* cnt_in,
-                                                    const uint32_t* off_out, uint32_t B, uint32_t F, g1_xyzz* out) {
-    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= off_out[B]) return;
-    const uint32_t b = find_bucket(off_out, B, t);
-    const uint32_t j = t - off_out[b];
-    const uint32_t lo = off_in[b] + j * F;
-    const uint32_t end = off_in[b] + cnt_in[b];
-    const uint32_t hi = lo + F < end ? lo + F : end;
-    g1_xyzz_w acc = xyzz_w_load(in + lo);
-    for (uint32_t k = lo + 1; k < hi; k++) acc = xyzz_w_add(acc, xyzz_w_load(in + k));
-    xyzz_w_store(out + t, acc);
+// Pre-levels for heavy buckets (skewed scalars: half of all 16-bit scalars carry a digit +1 into window 1, so bucket 0
+// can hold hundreds of thousands of entries and thousands of slot sums).  A bucket with more than MERGE_DIRECT_MAX
+// items folds them 64 at a time, one WAVE per output item: a butterfly of six dependent additions, where a lane folding
+// items one after the other would need one addition per item.  Light buckets are left where they are: the bucket view
+// (offset, count) of the next level points either at the old items or at the new ones; both live in one array.
+constexpr uint32_t MERGE_DIRECT_MAX = 32;   // the final merge level takes buckets of up to this many partial sums
+constexpr uint32_t MERGE_WAVE = 64;
+
+__device__ __forceinline__ g1_xyzz_w wave_sum_xyzz(g1_xyzz_w v, uint32_t lane) {
+    for (int d = 32; d >= 1; d >>= 1) {
+        const g1_xyzz_w o = xyzz_w_shfl(v, (int)(lane ^ d));
+        v = xyzz_w_add(v, o);
+    }
+    return v;
+}
+
+// one block: hoff = exclusive scan of f(b) = cnt > MERGE_DIRECT_MAX ? ceil(cnt / 64) : 0 (hoff[B] = total), and the
+// bucket view after the level: heavy buckets at out_base + hoff[b] with f(b) items, light buckets unchanged
+__global__ void __launch_bounds__(1024) heavy_scan_kernel(const uint32_t* off_in, const uint32_t* cnt_in, uint32_t B,
+                                                          uint32_t out_base, uint32_t* hoff, uint32_t* off_out, uint32_t* cnt_out) {
+    // wave w scans the segment [w S, (w + 1) S) of the buckets, 64 consecutive buckets per step (coalesced), with a
+    // running carry and no barrier; the sixteen segment totals then give every wave its base
+    __shared__ uint32_t seg_tot[16];
+    constexpr int STEPS = 32;   // 32768 buckets at most = 16 waves x 32 steps x 64 lanes
+    const uint32_t w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const uint32_t S = B / 16 > 64 ? B / 16 : 64;   // B is a power of two >= 128
+    uint32_t ex[STEPS], cs[STEPS];
+    uint32_t run = 0;
+#pragma unroll
+    for (int i = 0; i < STEPS; i++) {
+        const uint32_t b = w * S + i * 64 + lane;
+        const bool in = (uint32_t)(i * 64) < S && b < B;
+        const uint32_t c = in ? cnt_in[b] : 0;
+        const uint32_t f = c > MERGE_DIRECT_MAX ? (c + MERGE_WAVE - 1) / MERGE_WAVE : 0;
+        uint32_t inc = f;
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t t = __shfl_up(inc, d, 64);
+            if ((int)lane >= d) inc += t;
+        }
+        cs[i] = c;
+        ex[i] = run + inc - f;
+        run += __shfl(inc, 63, 64);
+    }
+    if (lane == 0) seg_tot[w] = run;
+    __syncthreads();
+    uint32_t base = 0, total = 0;
+    for (uint32_t k = 0; k < 16; k++) {
+        if (k < w) base += seg_tot[k];
+        total += seg_tot[k];
+    }
+#pragma unroll
+    for (int i = 0; i < STEPS; i++) {
+        const uint32_t b = w * S + i * 64 + lane;
+        if ((uint32_t)(i * 64) < S && b < B) {
+            const uint32_t c = cs[i], at = base + ex[i];
+            const bool heavy = c > MERGE_DIRECT_MAX;
+            hoff[b] = at;
+            off_out[b] = heavy ? out_base + at : off_in[b];
+            cnt_out[b] = heavy ? (c + MERGE_WAVE - 1) / MERGE_WAVE : c;
+        }
+    }
+    if (threadIdx.x == 0) hoff[B] = total;
+}
+
+// wave t of the launch folds items [lo, lo + 64) of its heavy bucket into items[out_base + t]
+__global__ void __launch_bounds__(256) merge_wave_kernel(g1_xyzz* items, const uint32_t* off_in, const uint32_t* cnt_in,
+                                                         const uint32_t* hoff, uint32_t B, uint32_t out_base) {
+    const uint32_t t = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+    if (t >= hoff[B]) return;
+    const uint32_t b = find_bucket(hoff, B, t);
+    const uint32_t lo = off_in[b] + (t - hoff[b]) * MERGE_WAVE, end = off_in[b] + cnt_in[b];
+    g1_xyzz_w p = lo + lane < end ? xyzz_w_load(items + lo + lane) : xyzz_w_identity();
+    p = wave_sum_xyzz(p, lane);
+    if (lane == 0) xyzz_w_store(items + out_base + t, p);
 }
 
 // final level: MERGE_P neighbouring lanes share one bucket; lane r folds items r, r + P, ... and a shuffle tree joins
@@ -688,8 +749,6 @@ static uint32_t env_u32(const char* name, uint32_t dflt) {
 }
 // experiments: force the slot length (0 = planned per MSM) / items folded per lane in a merge pre-level
 static const uint32_t FORCE_L = env_u32("ZKHIP_SLOT_L", 0);
-static const uint32_t MERGE_F = 16;
-constexpr uint32_t MERGE_DIRECT_MAX = 32;   // the final merge level takes buckets of up to this many partial sums
 
 // Buffers of one in-flight MSM.  A workspace is bound to a stream; several workspaces let the latency-bound tail of
 // one MSM (merge, reduce, host fold) overlap the accumulate phase of the next.
@@ -705,7 +764,7 @@ struct MsmWorkspace {
     const fe* d_scalars = nullptr;
     uint32_t G = 0, l_min = 0, plan_blocks = 0, acc_blocks = 0;
     bool nonzero = false;
-    uint32_t *counts, *entries, *start, *cnt, *offA, *cntA, *offB, *cntB, *info, *plan, *cur, *bincount;
+    uint32_t *counts, *entries, *start, *cnt, *offA, *cntA, *offB, *cntB, *info, *plan, *cur, *bincount, *hoff;
     uint2* tmp;
     g1_xyzz *itemsA, *itemsB, *sums, *l1, *out2;
 };
@@ -733,7 +792,7 @@ static int ws_prepare(zkhip_ctx* ctx, MsmWorkspace& ws, const MsmTables& tb, siz
                  o_cnt = take((size_t)B * 4), o_offA = take(((size_t)B + 1) * 4), o_cntA = take((size_t)B * 4),
                  o_offB = take(((size_t)B + 1) * 4), o_cntB = take((size_t)B * 4), o_info = take(64),
                  o_plan = take((size_t)ws.plan_blocks * PLAN_STRIDE * 4), o_itemsA = take(T1_max * sizeof(g1_xyzz)),
-                 o_itemsB = take((T1_max / MERGE_F + B + 1) * sizeof(g1_xyzz)), o_sums = take((size_t)B * sizeof(g1_xyzz)),
+                 o_itemsB = take((T1_max / 16 + B + 1) * sizeof(g1_xyzz)), o_hoff = take(((size_t)B + 1) * 4), o_sums = take((size_t)B * sizeof(g1_xyzz)),
                  o_l1 = take((size_t)RED_STREAMS * J * sizeof(g1_xyzz)),
                  o_out2 = take(REDUCE_OUT * sizeof(g1_xyzz));
     if (off > ws.bytes) {
@@ -768,6 +827,7 @@ static int ws_prepare(zkhip_ctx* ctx, MsmWorkspace& ws, const MsmTables& tb, siz
     ws.itemsB = (g1_xyzz*)(p + o_itemsB);
     ws.sums = (g1_xyzz*)(p + o_sums);
     ws.l1 = (g1_xyzz*)(p + o_l1);
+    ws.hoff = (uint32_t*)(p + o_hoff);
     ws.out2 = (g1_xyzz*)(p + o_out2);
     return ZKHIP_OK;
 }
@@ -848,26 +908,30 @@ static int msm_phase2(zkhip_ctx* ctx, MsmWorkspace& ws, const MsmTables& tb, boo
         fprintf(stderr, "[zkhip] msm n=%zu: slots=%u max_cnt=%u L=%u entries=%u\n", ws.n, total_slots, max_cnt, L,
                 ws.h_info[INFO_ENTRIES]);
     if (!ws.nonzero) return ZKHIP_OK;   // every scalar is zero
-    g1_xyzz *cur_items = ws.itemsA, *nxt_items = ws.itemsB;
+    // all items live in one array: itemsA (the slot sums) followed by itemsB (the outputs of the pre-levels, appended
+    // level after level); bucket views index it from itemsA
+    g1_xyzz* items = ws.itemsA;
+    uint32_t out_base = (uint32_t)(ws.itemsB - ws.itemsA);
     uint32_t *cur_off = ws.offA, *cur_cnt = ws.cntA, *nxt_off = ws.offB, *nxt_cnt = ws.cntB;
     {
         TimedRegion tr(ctx, timed ? "msm_merge" : nullptr, st);
         uint32_t level_max = (max_cnt + L - 1) / L, level_total = total_slots;
         while (level_max > MERGE_DIRECT_MAX) {
-            hipLaunchKernelGGL(bucket_scan_kernel, dim3(1), dim3(1024), 0, st, cur_cnt, B, MERGE_F, nxt_cnt, nxt_off,
-                               (uint32_t*)nullptr, (uint32_t*)nullptr, (const uint32_t*)nullptr, 0u, 0u, 0u, 0u, (uint32_t*)nullptr);
-            const uint32_t bound = level_total / MERGE_F + B + 1;
-            hipLaunchKernelGGL(merge_kernel, dim3((bound + 255) / 256), dim3(256), 0, st, cur_items, cur_off, cur_cnt, nxt_off,
-                               B, MERGE_F, nxt_items);
+            hipLaunchKernelGGL(heavy_scan_kernel, dim3(1), dim3(1024), 0, st, (const uint32_t*)cur_off, (const uint32_t*)cur_cnt, B,
+                               out_base, ws.hoff, nxt_off, nxt_cnt);
+            // a heavy bucket has more than 32 items and yields at most cnt / 64 + 1 <= cnt / 32 outputs
+            const uint32_t bound = level_total / MERGE_DIRECT_MAX + 1;
+            hipLaunchKernelGGL(merge_wave_kernel, dim3((bound + 3) / 4), dim3(256), 0, st, items, (const uint32_t*)cur_off,
+                               (const uint32_t*)cur_cnt, (const uint32_t*)ws.hoff, B, out_base);
             ZK_HIP(ctx, hipGetLastError());
-            std::swap(cur_items, nxt_items);
             std::swap(cur_off, nxt_off);
             std::swap(cur_cnt, nxt_cnt);
-            level_max = (level_max + MERGE_F - 1) / MERGE_F;
+            out_base += bound;
+            level_max = (level_max + MERGE_WAVE - 1) / MERGE_WAVE;
             level_total = bound;
         }
-        hipLaunchKernelGGL(merge_final_kernel, dim3((B * MERGE_P + 255) / 256), dim3(256), 0, st, cur_items, cur_off, cur_cnt, B,
-                           ws.sums);
+        hipLaunchKernelGGL(merge_final_kernel, dim3((B * MERGE_P + 255) / 256), dim3(256), 0, st, (const g1_xyzz*)items,
+                           (const uint32_t*)cur_off, (const uint32_t*)cur_cnt, B, ws.sums);
         ZK_HIP(ctx, hipGetLastError());
     }
     {
