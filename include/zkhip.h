@@ -234,6 +234,12 @@ int zkhip_eval_polynomial_dev(zkhip_ctx* ctx, const uint64_t* d_coeff, size_t n,
  * when an input value is missing from the table (upstream: Error::ConstraintSystemFailure).  Synchronises. */
 int zkhip_lookup_permute_dev(zkhip_domain* dom, const uint64_t* d_compressed_input, const uint64_t* d_compressed_table,
                              uint32_t usable_rows, uint64_t* d_permuted_input, uint64_t* d_permuted_table);
+/* One permutation polynomial of `plonk::permutation::keygen::Assembly::build_pk` (key generation, reached from
+ * zkevm-circuits/benches/benchmark_list/main.rs:132 `keygen_pk`): d_out[i] = delta^(col[i]) * omega^(row[i]) for the
+ * 2^k rows of a column, (col[i], row[i]) = the cell that the copy-constraint cycles map row i of this column to
+ * (device arrays of 2^k words each; every col[i] < num_cols, every row[i] < 2^k; Lagrange basis).  Synchronises. */
+int zkhip_permutation_sigma_dev(zkhip_domain* dom, const uint32_t* d_map_col, const uint32_t* d_map_row, uint32_t num_cols,
+                                uint64_t* d_out);
 int zkhip_poly_lincomb_dev(zkhip_ctx* ctx, const uint64_t* const* d_polys, const size_t* lens, const uint64_t* coeffs,
                            uint32_t num, size_t n, uint64_t* d_out);
 int zkhip_kate_division_dev(zkhip_ctx* ctx, const uint64_t* d_poly, size_t n, const uint64_t point[4], uint64_t* d_out);

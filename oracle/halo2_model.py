@@ -565,3 +565,28 @@ def permute_expression_pair(input_expression, table_expression, usable_rows: int
             permuted_table[repeated_rows.pop()] = value
     assert not repeated_rows
     return permuted_input, permuted_table
+
+
+# ---------------------------------------------------------------------------------------------
+# plonk::keygen::keygen_pk pieces: permutation polynomials from the cycle mapping, Lagrange selectors
+# (restated from the published upstream algorithm; reached from the reference at
+# /root/reference/zkevm-circuits/benches/benchmark_list/main.rs:121-138)
+# ---------------------------------------------------------------------------------------------
+def permutation_sigmas(omega: int, mapping):
+    """mapping[c][r] = (column, row) the cycles send cell (c, r) to; returns sigma[c][r] = delta^column * omega^row."""
+    return [[pow(FR_DELTA, mc, P) * pow(omega, mr, P) % P for mc, mr in col] for col in mapping]
+
+
+def lagrange_selectors(dom: "EvaluationDomain", blinding_factors: int):
+    """(l0, l_last, l_active_row) on the extended domain, as keygen_pk builds them."""
+    n = dom.n
+    l0 = [0] * n
+    l0[0] = 1
+    l_blind = [0] * n
+    for i in range(n - blinding_factors, n):
+        l_blind[i] = 1
+    l_last = [0] * n
+    l_last[n - blinding_factors - 1] = 1
+    ext = [dom.coeff_to_extended(dom.lagrange_to_coeff(v)) for v in (l0, l_blind, l_last)]
+    l_active = [(1 - (a + b)) % P for a, b in zip(ext[2], ext[1])]
+    return ext[0], ext[2], l_active

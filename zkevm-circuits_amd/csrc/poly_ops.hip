@@ -360,6 +360,19 @@ __global__ void __launch_bounds__(PO_THREADS) kate_apply_kernel(const fe* a, siz
     }
 }
 
+// ---- permutation polynomials at key generation ----------------------------------------------------------
+// sigma[i] = delta^(col[i]) * omega^(row[i]): the Lagrange-basis values of one permutation polynomial from the cycle
+// mapping of its column (`plonk::permutation::keygen::Assembly::build_pk`).  dpow: delta^c for c < num_cols.
+__global__ void __launch_bounds__(PO_THREADS) perm_sigma_kernel(const uint32_t* col, const uint32_t* row, size_t n, const fe* dpow,
+                                                                const fe* om_lo, const fe* om_hi, uint32_t h, fe* out) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t r = row[i];
+    fe om = load_fe(om_lo + (r & ((1u << h) - 1)));
+    if (r >> h) om = Fr::mul(om, load_fe(om_hi + (r >> h)));
+    store_fe(out + i, Fr::mul(om, load_fe(dpow + col[i])));
+}
+
 // ---- launch helpers ----------------------------------------------------------------------------------
 static fe fe_from(const uint64_t v[4]) {
     fe o;
@@ -593,6 +606,32 @@ int zkhip_kate_division_dev(zkhip_ctx* ctx, const uint64_t* d_poly, size_t n, co
     hipLaunchKernelGGL(kate_apply_kernel, dim3((unsigned)nblocks), dim3(PO_THREADS), 0, ctx->stream, (const fe*)d_poly, n, z, d_pw,
                        d_lane_in, d_tot, (fe*)d_out);
     ZK_HIP(ctx, hipGetLastError());
+    return ZKHIP_OK;
+}
+
+int zkhip_permutation_sigma_dev(zkhip_domain* dom, const uint32_t* d_map_col, const uint32_t* d_map_row, uint32_t num_cols,
+                                uint64_t* d_out) {
+    if (!dom) return ZKHIP_ERR_INVALID;
+    zkhip_ctx* ctx = dom->ctx;
+    ZK_CHECK(ctx, d_map_col && d_map_row && d_out, "permutation_sigma: null pointer");
+    ZK_CHECK(ctx, num_cols >= 1 && num_cols <= 4096, "permutation_sigma: %u columns", num_cols);
+    ZK_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t n = (size_t)1 << dom->k;
+    int rc = ensure_scratch(ctx, (size_t)num_cols * 32);
+    if (rc) return rc;
+    std::vector<uint64_t> dpow((size_t)num_cols * 4);
+    memcpy(&dpow[0], HFR.r, 32);
+    uint64_t delta[4];
+    memcpy(delta, FrParams::DELTA, 32);
+    for (uint32_t c = 1; c < num_cols; c++) h_mul(HFR, &dpow[4 * c], &dpow[4 * (c - 1)], delta);
+    ZK_HIP(ctx, hipMemcpyAsync(ctx->scratch, dpow.data(), dpow.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+    ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));   // the table is pageable host memory that dies with this call
+    hipLaunchKernelGGL(perm_sigma_kernel, dim3((unsigned)((n + PO_THREADS - 1) / PO_THREADS)), dim3(PO_THREADS), 0, ctx->stream,
+                       d_map_col, d_map_row, n, (const fe*)ctx->scratch, (const fe*)dom->plan_fwd->d_lo,
+                       (const fe*)dom->plan_fwd->d_hi, dom->plan_fwd->h, (fe*)d_out);
+    ZK_HIP(ctx, hipGetLastError());
+    // the kernel reads the table from the scratch buffer: finish before another call may overwrite it
+    ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return ZKHIP_OK;
 }
 

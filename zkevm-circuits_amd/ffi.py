@@ -30,7 +30,7 @@ EXPORTS = [
     "zkhip_evaluate_h", "zkhip_evaluate_h_last_stats",
     "zkhip_coeff_to_cosets_dev", "zkhip_extended_to_cosets_dev", "zkhip_cosets_to_extended_dev",
     "zkhip_batch_invert_dev", "zkhip_prefix_product_dev", "zkhip_permutation_product_dev", "zkhip_lookup_product_dev",
-    "zkhip_eval_polynomial_dev", "zkhip_poly_lincomb_dev", "zkhip_kate_division_dev", "zkhip_lookup_permute_dev",
+    "zkhip_eval_polynomial_dev", "zkhip_poly_lincomb_dev", "zkhip_kate_division_dev", "zkhip_lookup_permute_dev", "zkhip_permutation_sigma_dev",
     "zkhip_timing_enable", "zkhip_timing_reset", "zkhip_timing_get",
 ]
 
@@ -422,6 +422,10 @@ class Domain:
         beta, gamma, delta_start, z0 = u64(beta), u64(gamma), u64(delta_start), u64(z0)
         self.ctx._ck(self._l.zkhip_permutation_product_dev(self.h, vals, sigs, C.c_uint32(len(d_values)), _p(beta), _p(gamma),
                                                            _p(delta_start), _p(z0), C.c_void_p(d_z)))
+
+    def permutation_sigma_dev(self, d_map_col: int, d_map_row: int, num_cols: int, d_out: int):
+        self.ctx._ck(self._l.zkhip_permutation_sigma_dev(self.h, C.c_void_p(d_map_col), C.c_void_p(d_map_row),
+                                                         C.c_uint32(num_cols), C.c_void_p(d_out)))
 
     def lookup_permute_dev(self, d_input: int, d_table: int, usable_rows: int, d_permuted_input: int, d_permuted_table: int):
         self.ctx._ck(self._l.zkhip_lookup_permute_dev(self.h, C.c_void_p(d_input), C.c_void_p(d_table), C.c_uint32(usable_rows),
