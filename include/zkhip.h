@@ -234,6 +234,12 @@ int zkhip_eval_polynomial_dev(zkhip_ctx* ctx, const uint64_t* d_coeff, size_t n,
  * when an input value is missing from the table (upstream: Error::ConstraintSystemFailure).  Synchronises. */
 int zkhip_lookup_permute_dev(zkhip_domain* dom, const uint64_t* d_compressed_input, const uint64_t* d_compressed_table,
                              uint32_t usable_rows, uint64_t* d_permuted_input, uint64_t* d_permuted_table);
+/* `arithmetic::best_fft` on G1 points (host pointers, n = 2^log_n affine points in and out): out[i] = scale * sum_j
+ * omega^(i j) in[j].  `poly::kzg::commitment::ParamsKZG::setup` / `g_to_lagrange` obtain `g_lagrange` from `g` this way with
+ * omega = omega_n^-1 and scale = n^-1 (parameters are built at zkevm-circuits/benches/benchmark_list/main.rs:184).
+ * scale may be NULL (no scaling).  Synchronises. */
+int zkhip_g1_fft(zkhip_ctx* ctx, const uint64_t* affine_xy, uint32_t log_n, const uint64_t omega[4], const uint64_t* scale,
+                 uint64_t* out_xy);
 /* One permutation polynomial of `plonk::permutation::keygen::Assembly::build_pk` (key generation, reached from
  * zkevm-circuits/benches/benchmark_list/main.rs:132 `keygen_pk`): d_out[i] = delta^(col[i]) * omega^(row[i]) for the
  * 2^k rows of a column, (col[i], row[i]) = the cell that the copy-constraint cycles map row i of this column to

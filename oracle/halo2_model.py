@@ -590,3 +590,16 @@ def lagrange_selectors(dom: "EvaluationDomain", blinding_factors: int):
     ext = [dom.coeff_to_extended(dom.lagrange_to_coeff(v)) for v in (l0, l_blind, l_last)]
     l_active = [(1 - (a + b)) % P for a, b in zip(ext[2], ext[1])]
     return ext[0], ext[2], l_active
+
+
+def g1_fft(points, omega: int, log_n: int):
+    """arithmetic::best_fft over G1 points (None = identity): out[i] = sum_j omega^(i j) points[j], by definition."""
+    from bn254 import g1_mul
+    n = 1 << log_n
+    out = []
+    for i in range(n):
+        acc = None
+        for j, pt in enumerate(points):
+            acc = g1_add(acc, g1_mul(pt, pow(omega, i * j, P)) if pt is not None else None)
+        out.append(acc)
+    return out

@@ -1017,3 +1017,42 @@ def test_keygen_sigmas_feed_the_permutation_product(ctx):
     for p_ in pk.pointers() + d_vals + [d_z]:
         ctx.free(p_)
     d.close()
+
+
+@pytest.mark.parametrize("k", [1, 3, 5])
+def test_g1_fft_vs_definition(ctx, co, k):
+    """the G1-valued transform behind g_lagrange against its O(n^2) definition, with and without the n^-1 scaling, and
+    with an identity point among the inputs"""
+    import halo2_model as hm
+    n = 1 << k
+    omega_inv = pow(bn.FR_ROOT_OF_UNITY, (1 << (bn.FR_S - k)) * ((1 << k) - 1), P)
+    pts = [bn.g1_mul(bn.G1_GENERATOR, 3 * i + 1) for i in range(n)]
+    if n >= 4:
+        pts[2] = None
+    n_inv = pow(n, P - 2, P)
+    exp = hm.g1_fft(pts, omega_inv, k)
+    got = ctx.g1_fft(affine_arr(pts), k, fr_arr([omega_inv])[0])
+    assert [affine_pt(r) for r in got] == exp
+    got = ctx.g1_fft(affine_arr(pts), k, fr_arr([omega_inv])[0], fr_arr([n_inv])[0])
+    assert [affine_pt(r) for r in got] == [bn.g1_mul(e, n_inv) if e is not None else None for e in exp]
+    with pytest.raises(ffi.ZkhipError):
+        ctx.g1_fft(affine_arr(pts), k, fr_arr([5])[0])          # not a 2^k-th root of unity
+
+
+@pytest.mark.parametrize("k", [8, 13])
+def test_g_to_lagrange_commits_like_the_monomial_basis(ctx, co, k):
+    """commit_lagrange(values) with the device-built g_lagrange equals commit(lagrange_to_coeff(values)) with g: the
+    identity that makes the two bases interchangeable in create_proof"""
+    from zkevm_circuits_amd import keygen
+    n = 1 << k
+    d = zk.Domain(ctx, 3, k)
+    g = co.g1_bases(n)
+    g_lagrange = keygen.g_to_lagrange(ctx, d, g)
+    rng = np.random.default_rng(k)
+    values = rand_fr(rng, n)
+    coeff = d.lagrange_to_coeff(values)
+    b_g, b_l = ctx.register_bases(g), ctx.register_bases(g_lagrange)
+    assert np.array_equal(ctx.g1_to_affine(ctx.msm(b_l, values)), ctx.g1_to_affine(ctx.msm(b_g, coeff)))
+    ctx.release_bases(b_g)
+    ctx.release_bases(b_l)
+    d.close()

@@ -9,7 +9,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libzkhip.so")
-SOURCES = ["api.hip", "ntt.hip", "domain.hip", "msm.hip", "evalh.hip", "poly_ops.hip", "lookup_permute.hip", "host_math.cpp"]
+SOURCES = ["api.hip", "ntt.hip", "domain.hip", "msm.hip", "evalh.hip", "poly_ops.hip", "lookup_permute.hip", "g1_fft.hip", "host_math.cpp"]
 
 
 def _newer(target, deps):

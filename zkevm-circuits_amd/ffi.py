@@ -19,7 +19,7 @@ EXPORTS = [
     "zkhip_dev_alloc", "zkhip_dev_free", "zkhip_upload", "zkhip_download",
     "zkhip_field_binop", "zkhip_field_batch_invert", "zkhip_g1_add_affine", "zkhip_g1_multiples", "zkhip_probe_mad_rate",
     "zkhip_register_bases", "zkhip_release_bases", "zkhip_msm", "zkhip_msm_batch_dev", "zkhip_msm_range_dev",
-    "zkhip_g1_sum_jacobian", "zkhip_g1_to_affine",
+    "zkhip_g1_sum_jacobian", "zkhip_g1_to_affine", "zkhip_g1_fft",
     "zkhip_ntt", "zkhip_ntt_dev",
     "zkhip_domain_create", "zkhip_domain_destroy", "zkhip_domain_k", "zkhip_domain_extended_k",
     "zkhip_domain_quotient_poly_degree", "zkhip_domain_constant",
@@ -211,6 +211,16 @@ class Context:
         base = u64(base)
         out = np.empty((n, 8), dtype=np.uint64)
         self._ck(self._l.zkhip_g1_multiples(self.h, _p(base), C.c_uint64(first), C.c_size_t(n), _p(out)))
+        return out
+
+    def g1_fft(self, affine_xy, log_n: int, omega, scale=None):
+        """best_fft over G1 points: (2^log_n, 8) affine limbs in, same shape out"""
+        pts = u64(affine_xy)
+        assert pts.size == 8 << log_n
+        out = np.empty((1 << log_n, 8), dtype=np.uint64)
+        om = u64(omega)
+        sc = u64(scale) if scale is not None else None
+        self._ck(self._l.zkhip_g1_fft(self.h, _p(pts), C.c_uint32(log_n), _p(om), _p(sc) if sc is not None else None, _p(out)))
         return out
 
     def probe_mad_rate(self, iters=2048):

@@ -133,3 +133,9 @@ def keygen_polys(ctx, dom, fixed_values, assembly: Assembly | None, blinding_fac
         ctx.free(d)
     pk.l0, pk.l_last, pk.l_active_row = outs
     return pk
+
+
+def g_to_lagrange(ctx, dom, g_affine):
+    """`poly::kzg::commitment::g_to_lagrange`: the SRS in the Lagrange basis, g_lagrange[i] = n^-1 sum_j omega^(-i j) g[j]
+    (a G1-valued inverse FFT).  g_affine: (2^k, 8) affine limbs; returns the same shape."""
+    return ctx.g1_fft(g_affine, dom.k, dom.constant(1), dom.constant(6))   # omega_inv, ifft_divisor = n^-1
