@@ -975,6 +975,14 @@ def test_keygen_polys_vs_model(ctx, k, j, blinding, ncols):
         coeff = md.lagrange_to_coeff(sig[c])
         assert fr_ints(ctx.download(pk.permutation_polys[c], (n, 4))) == coeff
         assert fr_ints(ctx.download(pk.permutation_cosets[c], (en, 4))) == md.coeff_to_extended(coeff)
+    # a mapping entry outside the argument is an error, not an out-of-bounds read
+    bad_col = asm.map_col[0].copy()
+    bad_col[1] = ncols
+    d_bc, d_br = keygen._upload_words(ctx, bad_col), keygen._upload_words(ctx, asm.map_row[0])
+    with pytest.raises(ffi.ZkhipError):
+        d.permutation_sigma_dev(d_bc, d_br, ncols, pk.permutations[0])
+    ctx.free(d_bc)
+    ctx.free(d_br)
     l0, l_last, l_active = hm.lagrange_selectors(md, blinding)
     assert fr_ints(ctx.download(pk.l0, (en, 4))) == l0
     assert fr_ints(ctx.download(pk.l_last, (en, 4))) == l_last

@@ -363,11 +363,17 @@ __global__ void __launch_bounds__(PO_THREADS) kate_apply_kernel(const fe* a, siz
 // ---- permutation polynomials at key generation ----------------------------------------------------------
 // sigma[i] = delta^(col[i]) * omega^(row[i]): the Lagrange-basis values of one permutation polynomial from the cycle
 // mapping of its column (`plonk::permutation::keygen::Assembly::build_pk`).  dpow: delta^c for c < num_cols.
-__global__ void __launch_bounds__(PO_THREADS) perm_sigma_kernel(const uint32_t* col, const uint32_t* row, size_t n, const fe* dpow,
-                                                                const fe* om_lo, const fe* om_hi, uint32_t h, fe* out) {
+__global__ void __launch_bounds__(PO_THREADS) perm_sigma_kernel(const uint32_t* col, const uint32_t* row, size_t n, uint32_t num_cols,
+                                                                const fe* dpow, const fe* om_lo, const fe* om_hi, uint32_t h,
+                                                                fe* out, uint32_t* bad) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const uint32_t r = row[i];
+    if (r >= n || col[i] >= num_cols) {   // a cell outside the argument: report it instead of reading past the tables
+        atomicOr(bad, 1u);
+        store_fe(out + i, Fr::zero());
+        return;
+    }
     fe om = load_fe(om_lo + (r & ((1u << h) - 1)));
     if (r >> h) om = Fr::mul(om, load_fe(om_hi + (r >> h)));
     store_fe(out + i, Fr::mul(om, load_fe(dpow + col[i])));
@@ -617,8 +623,10 @@ int zkhip_permutation_sigma_dev(zkhip_domain* dom, const uint32_t* d_map_col, co
     ZK_CHECK(ctx, num_cols >= 1 && num_cols <= 4096, "permutation_sigma: %u columns", num_cols);
     ZK_HIP(ctx, hipSetDevice(ctx->device));
     const size_t n = (size_t)1 << dom->k;
-    int rc = ensure_scratch(ctx, (size_t)num_cols * 32);
+    int rc = ensure_scratch(ctx, ((size_t)num_cols + 1) * 32);
     if (rc) return rc;
+    uint32_t* d_bad = (uint32_t*)((fe*)ctx->scratch + num_cols);
+    ZK_HIP(ctx, hipMemsetAsync(d_bad, 0, 4, ctx->stream));
     std::vector<uint64_t> dpow((size_t)num_cols * 4);
     memcpy(&dpow[0], HFR.r, 32);
     uint64_t delta[4];
@@ -627,11 +635,14 @@ int zkhip_permutation_sigma_dev(zkhip_domain* dom, const uint32_t* d_map_col, co
     ZK_HIP(ctx, hipMemcpyAsync(ctx->scratch, dpow.data(), dpow.size() * 8, hipMemcpyHostToDevice, ctx->stream));
     ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));   // the table is pageable host memory that dies with this call
     hipLaunchKernelGGL(perm_sigma_kernel, dim3((unsigned)((n + PO_THREADS - 1) / PO_THREADS)), dim3(PO_THREADS), 0, ctx->stream,
-                       d_map_col, d_map_row, n, (const fe*)ctx->scratch, (const fe*)dom->plan_fwd->d_lo,
-                       (const fe*)dom->plan_fwd->d_hi, dom->plan_fwd->h, (fe*)d_out);
+                       d_map_col, d_map_row, n, num_cols, (const fe*)ctx->scratch, (const fe*)dom->plan_fwd->d_lo,
+                       (const fe*)dom->plan_fwd->d_hi, dom->plan_fwd->h, (fe*)d_out, d_bad);
     ZK_HIP(ctx, hipGetLastError());
     // the kernel reads the table from the scratch buffer: finish before another call may overwrite it
+    uint32_t h_bad = 0;
+    ZK_HIP(ctx, hipMemcpyAsync(&h_bad, d_bad, 4, hipMemcpyDeviceToHost, ctx->stream));
     ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ZK_CHECK(ctx, !h_bad, "permutation_sigma: a mapping entry points outside the %u columns x %zu rows", num_cols, n);
     return ZKHIP_OK;
 }
 
