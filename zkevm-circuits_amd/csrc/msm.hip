@@ -146,8 +146,7 @@ constexpr int FINE_PER_LANE = FINE_SLICE / FINE_THREADS;
 // deterministic and no global atomics are needed.
 template <uint32_t C>
 __global__ void __launch_bounds__(COARSE_THREADS) scatter_coarse_kernel(const fe* scalars, size_t n, size_t chunk, uint32_t T,
-                                                                        const uint32_t* bincount, const uint32_t* start,
-                                                                        uint2* tmp) {
+                                                                        const uint32_t* bincount, uint2* tmp) {
     extern __shared__ __align__(16) unsigned char smem_sc[];
     uint32_t* hist = reinterpret_cast<uint32_t*>(smem_sc);        // [256] records of this round per bin
     uint32_t* roff = hist + 256;                                  // [256] exclusive scan of hist
@@ -158,17 +157,42 @@ __global__ void __launch_bounds__(COARSE_THREADS) scatter_coarse_kernel(const fe
     __shared__ uint32_t total_s;
     constexpr uint32_t W = windows_for(C), NB = (1u << (C - 1)) >> BIN_LOG;
     const uint32_t tid = threadIdx.x, g = blockIdx.x;
+    // cursor[q] = first record of bin q (the bins before it, over all workgroups) + the records of bin q that the
+    // workgroups before this one hold.  Both follow from the per-workgroup bin counts alone.  (Running the column sums and
+    // the plan beside this kernel on a second stream was measured: no gain, the sort phase stayed at 150 us.)
     if (tid < 256) {
-        cursor[tid] = tid < NB ? start[tid << BIN_LOG] : 0;
+        cursor[tid] = 0;
+        hist[tid] = 0;
         fill[tid] = 0;
     }
     __syncthreads();
     {
-        const uint32_t q = tid & 255, part = tid >> 8;            // four lanes share the rows before g of one bin
-        uint32_t sum = 0;
-        for (uint32_t r = part; r < g; r += COARSE_THREADS / 256) sum += bincount[(size_t)r * 256 + q];
-        if (sum) atomicAdd(&cursor[q], sum);
+        const uint32_t q = tid & 255, part = tid >> 8;            // four lanes share the rows of one bin
+        uint32_t before = 0, all = 0;
+        for (uint32_t r = part; r < gridDim.x; r += COARSE_THREADS / 256) {
+            const uint32_t v = bincount[(size_t)r * 256 + q];
+            all += v;
+            if (r < g) before += v;
+        }
+        if (before) atomicAdd(&cursor[q], before);
+        if (all) atomicAdd(&hist[q], all);                         // hist doubles as the bin totals until the scan below
     }
+    __syncthreads();
+    if (tid < 64) {   // exclusive scan of the 256 bin totals, four per lane
+        const uint32_t h0 = hist[4 * tid], h1 = hist[4 * tid + 1], h2 = hist[4 * tid + 2], h3 = hist[4 * tid + 3];
+        const uint32_t sum = h0 + h1 + h2 + h3;
+        uint32_t inc = sum;
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t t = __shfl_up(inc, o, 64);
+            if ((int)tid >= o) inc += t;
+        }
+        const uint32_t e = inc - sum;
+        cursor[4 * tid] += e;
+        cursor[4 * tid + 1] += e + h0;
+        cursor[4 * tid + 2] += e + h0 + h1;
+        cursor[4 * tid + 3] += e + h0 + h1 + h2;
+    }
+    __syncthreads();
     const size_t lo = (size_t)g * chunk, hi = lo + chunk < n ? lo + chunk : n;
     for (size_t r0 = lo; r0 < hi; r0 += T) {
         if (tid < 256) hist[tid] = 0;
@@ -297,7 +321,8 @@ __global__ void __launch_bounds__(FINE_THREADS) scatter_fine_kernel(const uint2*
 // per MSM from a ladder of candidates (2.5 % apart) so that the slots just fill a whole number of rounds.
 constexpr uint32_t L_MAX = 256;
 constexpr uint32_t PLAN_STRIDE = 128;   // words per block in the plan statistics: [0] max cnt, [1] entries, [2 + i] slots(L_i)
-enum { INFO_SLOTS = 0, INFO_MAXCNT = 1, INFO_L = 2, INFO_ENTRIES = 3 };
+enum { INFO_SLOTS = 0, INFO_MAXCNT = 1, INFO_L = 2, INFO_ENTRIES = 3, INFO_HEAVY = 4 };   // HEAVY: slots in buckets of > 32
+constexpr uint32_t MERGE_DIRECT_MAX = 32;   // the final merge level takes buckets of up to this many partial sums
 ZK_DEV uint32_t next_slot_len(uint32_t L) { return L + (L < 40 ? 1 : L / 40); }
 
 __device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {
@@ -375,7 +400,7 @@ __global__ void __launch_bounds__(1024) bucket_scan_kernel(const uint32_t* cnt, 
                                                            const uint32_t* plan,
                                                            uint32_t plan_blocks, uint32_t l_min, uint32_t round_lanes,
                                                            uint32_t force_L, uint32_t* info) {
-    __shared__ uint32_t wsum[2][16];
+    __shared__ uint32_t wsum[3][16];
     __shared__ uint32_t best;
     const uint32_t tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     if (D == 0) {
@@ -422,7 +447,7 @@ __global__ void __launch_bounds__(1024) bucket_scan_kernel(const uint32_t* cnt, 
     const uint32_t per = B >= 1024 ? B / 1024 : 1;
     const uint32_t base = wv * per * 64 + lane;
     uint32_t offf[32], offc[32];
-    uint32_t carry_f = 0, carry_c = 0;
+    uint32_t carry_f = 0, carry_c = 0, heavy = 0;
 #pragma unroll
     for (uint32_t r = 0; r < 32; r++) {
         offf[r] = offc[r] = 0;
@@ -431,6 +456,7 @@ __global__ void __launch_bounds__(1024) bucket_scan_kernel(const uint32_t* cnt, 
             const uint32_t c = idx < B ? cnt[idx] : 0;
             const uint32_t f = (c + D - 1) / D;
             if (idx < B) f_out[idx] = f;
+            heavy += f > MERGE_DIRECT_MAX ? f : 0;
             uint32_t inf = f, inc = c;
             for (int d = 1; d < 64; d <<= 1) {
                 const uint32_t tf = __shfl_up(inf, d, 64), tc = __shfl_up(inc, d, 64);
@@ -445,12 +471,14 @@ __global__ void __launch_bounds__(1024) bucket_scan_kernel(const uint32_t* cnt, 
             carry_c += __shfl(inc, 63, 64);
         }
     }
+    heavy = wave_sum_u32(heavy);
     if (lane == 0) {
         wsum[0][wv] = carry_f;
         wsum[1][wv] = carry_c;
+        wsum[2][wv] = heavy;
     }
     __syncthreads();
-    uint32_t bs = 0, be = 0, total = 0;
+    uint32_t bs = 0, be = 0, total = 0, heavy_total = 0;
     for (uint32_t k = 0; k < 16; k++) {
         const uint32_t a = wsum[0][k];
         if (k < wv) {
@@ -458,6 +486,7 @@ __global__ void __launch_bounds__(1024) bucket_scan_kernel(const uint32_t* cnt, 
             be += wsum[1][k];
         }
         total += a;
+        heavy_total += wsum[2][k];
     }
 #pragma unroll
     for (uint32_t r = 0; r < 32; r++) {
@@ -474,7 +503,10 @@ __global__ void __launch_bounds__(1024) bucket_scan_kernel(const uint32_t* cnt, 
     }
     if (tid == 0) {
         off_out[B] = total;
-        if (info) info[INFO_SLOTS] = total;
+        if (info) {
+            info[INFO_SLOTS] = total;
+            info[INFO_HEAVY] = heavy_total;
+        }
     }
 }
 
@@ -524,8 +556,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))
 // items folds them 64 at a time, one WAVE per output item: a butterfly of six dependent additions, where a lane folding
 // items one after the other would need one addition per item.  Light buckets are left where they are: the bucket view
 // (offset, count) of the next level points either at the old items or at the new ones; both live in one array.
-constexpr uint32_t MERGE_DIRECT_MAX = 32;   // the final merge level takes buckets of up to this many partial sums
-constexpr uint32_t MERGE_WAVE = 64;
+constexpr uint32_t MERGE_WAVE = 64;    // items one wave folds in a pre-level for few, very heavy buckets
+constexpr uint32_t MERGE_LANE = 16;    // items one lane folds in a pre-level for many heavy buckets
 
 __device__ __forceinline__ g1_xyzz_w wave_sum_xyzz(g1_xyzz_w v, uint32_t lane) {
     for (int d = 32; d >= 1; d >>= 1) {
@@ -535,10 +567,10 @@ __device__ __forceinline__ g1_xyzz_w wave_sum_xyzz(g1_xyzz_w v, uint32_t lane) {
     return v;
 }
 
-// one block: hoff = exclusive scan of f(b) = cnt > MERGE_DIRECT_MAX ? ceil(cnt / 64) : 0 (hoff[B] = total), and the
+// one block: hoff = exclusive scan of f(b) = cnt > direct_max ? ceil(cnt / fold) : 0 (hoff[B] = total), and the
 // bucket view after the level: heavy buckets at out_base + hoff[b] with f(b) items, light buckets unchanged
-__global__ void __launch_bounds__(1024) heavy_scan_kernel(const uint32_t* off_in, const uint32_t* cnt_in, uint32_t B,
-                                                          uint32_t out_base, uint32_t* hoff, uint32_t* off_out, uint32_t* cnt_out) {
+__global__ void __launch_bounds__(1024) heavy_scan_kernel(const uint32_t* off_in, const uint32_t* cnt_in, uint32_t B, uint32_t fold,
+                                                          uint32_t direct_max, uint32_t out_base, uint32_t* hoff, uint32_t* off_out, uint32_t* cnt_out) {
     // wave w scans the segment [w S, (w + 1) S) of the buckets, 64 consecutive buckets per step (coalesced), with a
     // running carry and no barrier; the sixteen segment totals then give every wave its base
     __shared__ uint32_t seg_tot[16];
@@ -552,7 +584,7 @@ __global__ void __launch_bounds__(1024) heavy_scan_kernel(const uint32_t* off_in
         const uint32_t b = w * S + i * 64 + lane;
         const bool in = (uint32_t)(i * 64) < S && b < B;
         const uint32_t c = in ? cnt_in[b] : 0;
-        const uint32_t f = c > MERGE_DIRECT_MAX ? (c + MERGE_WAVE - 1) / MERGE_WAVE : 0;
+        const uint32_t f = c > direct_max ? (c + fold - 1) / fold : 0;
         uint32_t inc = f;
         for (int d = 1; d < 64; d <<= 1) {
             const uint32_t t = __shfl_up(inc, d, 64);
@@ -574,10 +606,10 @@ __global__ void __launch_bounds__(1024) heavy_scan_kernel(const uint32_t* off_in
         const uint32_t b = w * S + i * 64 + lane;
         if ((uint32_t)(i * 64) < S && b < B) {
             const uint32_t c = cs[i], at = base + ex[i];
-            const bool heavy = c > MERGE_DIRECT_MAX;
+            const bool heavy = c > direct_max;
             hoff[b] = at;
             off_out[b] = heavy ? out_base + at : off_in[b];
-            cnt_out[b] = heavy ? (c + MERGE_WAVE - 1) / MERGE_WAVE : c;
+            cnt_out[b] = heavy ? (c + fold - 1) / fold : c;
         }
     }
     if (threadIdx.x == 0) hoff[B] = total;
@@ -593,6 +625,20 @@ __global__ void __launch_bounds__(256) merge_wave_kernel(g1_xyzz* items, const u
     g1_xyzz_w p = lo + lane < end ? xyzz_w_load(items + lo + lane) : xyzz_w_identity();
     p = wave_sum_xyzz(p, lane);
     if (lane == 0) xyzz_w_store(items + out_base + t, p);
+}
+
+// the same level for MANY heavy buckets (large uniform MSMs: every bucket holds a hundred slot sums): lane t folds
+// MERGE_LANE consecutive items of its bucket one after the other, which costs a sixth of the additions of the wave form
+__global__ void __launch_bounds__(256) merge_lane_kernel(g1_xyzz* items, const uint32_t* off_in, const uint32_t* cnt_in,
+                                                         const uint32_t* hoff, uint32_t B, uint32_t out_base) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= hoff[B]) return;
+    const uint32_t b = find_bucket(hoff, B, t);
+    const uint32_t lo = off_in[b] + (t - hoff[b]) * MERGE_LANE, end = off_in[b] + cnt_in[b];
+    const uint32_t hi = lo + MERGE_LANE < end ? lo + MERGE_LANE : end;
+    g1_xyzz_w acc = xyzz_w_load(items + lo);
+    for (uint32_t k = lo + 1; k < hi; k++) acc = xyzz_w_add(acc, xyzz_w_load(items + k));
+    xyzz_w_store(items + out_base + t, acc);
 }
 
 // final level: MERGE_P neighbouring lanes share one bucket; lane r folds items r, r + P, ... and a shuffle tree joins
@@ -792,7 +838,7 @@ static int ws_prepare(zkhip_ctx* ctx, MsmWorkspace& ws, const MsmTables& tb, siz
                  o_cnt = take((size_t)B * 4), o_offA = take(((size_t)B + 1) * 4), o_cntA = take((size_t)B * 4),
                  o_offB = take(((size_t)B + 1) * 4), o_cntB = take((size_t)B * 4), o_info = take(64),
                  o_plan = take((size_t)ws.plan_blocks * PLAN_STRIDE * 4), o_itemsA = take(T1_max * sizeof(g1_xyzz)),
-                 o_itemsB = take((T1_max / 16 + B + 1) * sizeof(g1_xyzz)), o_hoff = take(((size_t)B + 1) * 4), o_sums = take((size_t)B * sizeof(g1_xyzz)),
+                 o_itemsB = take((T1_max / 8 + 2 * (size_t)B + 64) * sizeof(g1_xyzz)), o_hoff = take(((size_t)B + 1) * 4), o_sums = take((size_t)B * sizeof(g1_xyzz)),
                  o_l1 = take((size_t)RED_STREAMS * J * sizeof(g1_xyzz)),
                  o_out2 = take(REDUCE_OUT * sizeof(g1_xyzz));
     if (off > ws.bytes) {
@@ -865,7 +911,7 @@ static int msm_phase1(zkhip_ctx* ctx, MsmWorkspace& ws, const MsmTables& tb, siz
     hipLaunchKernelGGL(bucket_scan_kernel, dim3(1), dim3(1024), 0, st, ws.cnt, B, 0u, ws.cntA, ws.offA, ws.start, ws.cur, ws.plan,
                        ws.plan_blocks, ws.l_min, (uint32_t)ctx->num_cus * 256u, FORCE_L, ws.info);
     // the plan travels to the host while scatter and accumulate run
-    ZK_HIP(ctx, hipMemcpyAsync(ws.h_info, ws.info, 16, hipMemcpyDeviceToHost, st));
+    ZK_HIP(ctx, hipMemcpyAsync(ws.h_info, ws.info, 32, hipMemcpyDeviceToHost, st));
     ZK_HIP(ctx, hipEventRecord(ws.ev_info, st));
     {
         const size_t lds_coarse = 5 * 256 * 4 + (size_t)COARSE_ROUND * 8;
@@ -875,7 +921,7 @@ static int msm_phase1(zkhip_ctx* ctx, MsmWorkspace& ws, const MsmTables& tb, siz
         const uint32_t parts = (uint32_t)std::max<size_t>(1, (n * W / NB * 5 / 4 + FINE_SLICE - 1) / FINE_SLICE);
 #define ZK_LAUNCH_COARSE(C)                                                                                              \
     hipLaunchKernelGGL(scatter_coarse_kernel<C>, dim3(G), dim3(COARSE_THREADS), lds_coarse, st, d_scalars, n, chunk, T, \
-                       ws.bincount, ws.start, ws.tmp)
+                       ws.bincount, ws.tmp)
         ZK_FOR_WINDOW_WIDTH(ZK_LAUNCH_COARSE)
 #undef ZK_LAUNCH_COARSE
 #undef ZK_FOR_WINDOW_WIDTH
@@ -905,8 +951,8 @@ static int msm_phase2(zkhip_ctx* ctx, MsmWorkspace& ws, const MsmTables& tb, boo
     ws.nonzero = total_slots != 0;
     static const bool debug = getenv("ZKHIP_DEBUG") != nullptr;
     if (debug)
-        fprintf(stderr, "[zkhip] msm n=%zu: slots=%u max_cnt=%u L=%u entries=%u\n", ws.n, total_slots, max_cnt, L,
-                ws.h_info[INFO_ENTRIES]);
+        fprintf(stderr, "[zkhip] msm n=%zu: slots=%u max_cnt=%u L=%u entries=%u heavy=%u\n", ws.n, total_slots, max_cnt, L,
+                ws.h_info[INFO_ENTRIES], ws.h_info[INFO_HEAVY]);
     if (!ws.nonzero) return ZKHIP_OK;   // every scalar is zero
     // all items live in one array: itemsA (the slot sums) followed by itemsB (the outputs of the pre-levels, appended
     // level after level); bucket views index it from itemsA
@@ -915,20 +961,33 @@ static int msm_phase2(zkhip_ctx* ctx, MsmWorkspace& ws, const MsmTables& tb, boo
     uint32_t *cur_off = ws.offA, *cur_cnt = ws.cntA, *nxt_off = ws.offB, *nxt_cnt = ws.cntB;
     {
         TimedRegion tr(ctx, timed ? "msm_merge" : nullptr, st);
-        uint32_t level_max = (max_cnt + L - 1) / L, level_total = total_slots;
-        while (level_max > MERGE_DIRECT_MAX) {
+        // level_heavy: (a bound on) the items in buckets of more than MERGE_DIRECT_MAX items.  Few of them (one or
+        // two huge buckets of skewed scalars): one wave folds 64, six dependent additions per level.  Many (every
+        // bucket of a large uniform MSM): one lane folds 16, a sixth of the work.
+        // The final level folds a bucket with two lanes, so what it costs is its largest bucket: a pre-level pays only
+        // where some buckets are far above the average (a large uniform MSM has ~30 slot sums in every bucket).
+        uint32_t level_max = (max_cnt + L - 1) / L, level_heavy = ws.h_info[INFO_HEAVY];
+        const uint32_t direct_max = std::max(MERGE_DIRECT_MAX, 2 * ((total_slots + B - 1) / B));
+        while (level_max > direct_max) {
+            const bool by_wave = level_heavy / MERGE_WAVE <= 8u * 1024u;
+            const uint32_t fold = by_wave ? MERGE_WAVE : MERGE_LANE;
             hipLaunchKernelGGL(heavy_scan_kernel, dim3(1), dim3(1024), 0, st, (const uint32_t*)cur_off, (const uint32_t*)cur_cnt, B,
-                               out_base, ws.hoff, nxt_off, nxt_cnt);
-            // a heavy bucket has more than 32 items and yields at most cnt / 64 + 1 <= cnt / 32 outputs
-            const uint32_t bound = level_total / MERGE_DIRECT_MAX + 1;
-            hipLaunchKernelGGL(merge_wave_kernel, dim3((bound + 3) / 4), dim3(256), 0, st, items, (const uint32_t*)cur_off,
-                               (const uint32_t*)cur_cnt, (const uint32_t*)ws.hoff, B, out_base);
+                               fold, direct_max, out_base, ws.hoff, nxt_off, nxt_cnt);
+            // a heavy bucket yields at most cnt / fold + 1 outputs, and there are at most min(B, heavy / 33) of them; all
+            // levels together stay below the T1 / 8 + 2 B + 64 items reserved behind the slot sums
+            const uint32_t bound = level_heavy / fold + std::min(B, level_heavy / (MERGE_DIRECT_MAX + 1)) + 1;
+            if (by_wave)
+                hipLaunchKernelGGL(merge_wave_kernel, dim3((bound + 3) / 4), dim3(256), 0, st, items, (const uint32_t*)cur_off,
+                                   (const uint32_t*)cur_cnt, (const uint32_t*)ws.hoff, B, out_base);
+            else
+                hipLaunchKernelGGL(merge_lane_kernel, dim3((bound + 255) / 256), dim3(256), 0, st, items, (const uint32_t*)cur_off,
+                                   (const uint32_t*)cur_cnt, (const uint32_t*)ws.hoff, B, out_base);
             ZK_HIP(ctx, hipGetLastError());
             std::swap(cur_off, nxt_off);
             std::swap(cur_cnt, nxt_cnt);
             out_base += bound;
-            level_max = (level_max + MERGE_WAVE - 1) / MERGE_WAVE;
-            level_total = bound;
+            level_max = (level_max + fold - 1) / fold;
+            level_heavy = bound;
         }
         hipLaunchKernelGGL(merge_final_kernel, dim3((B * MERGE_P + 255) / 256), dim3(256), 0, st, (const g1_xyzz*)items,
                            (const uint32_t*)cur_off, (const uint32_t*)cur_cnt, B, ws.sums);
