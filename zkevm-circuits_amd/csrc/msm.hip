@@ -146,7 +146,8 @@ constexpr int FINE_PER_LANE = FINE_SLICE / FINE_THREADS;
 // deterministic and no global atomics are needed.
 template <uint32_t C>
 __global__ void __launch_bounds__(COARSE_THREADS) scatter_coarse_kernel(const fe* scalars, size_t n, size_t chunk, uint32_t T,
-                                                                        const uint32_t* bincount, uint2* tmp) {
+                                                                        const uint32_t* bincount, const uint32_t* start,
+                                                                        uint2* tmp) {
     extern __shared__ __align__(16) unsigned char smem_sc[];
     uint32_t* hist = reinterpret_cast<uint32_t*>(smem_sc);        // [256] records of this round per bin
     uint32_t* roff = hist + 256;                                  // [256] exclusive scan of hist
@@ -157,42 +158,20 @@ __global__ void __launch_bounds__(COARSE_THREADS) scatter_coarse_kernel(const fe
     __shared__ uint32_t total_s;
     constexpr uint32_t W = windows_for(C), NB = (1u << (C - 1)) >> BIN_LOG;
     const uint32_t tid = threadIdx.x, g = blockIdx.x;
-    // cursor[q] = first record of bin q (the bins before it, over all workgroups) + the records of bin q that the
-    // workgroups before this one hold.  Both follow from the per-workgroup bin counts alone.  (Running the column sums and
-    // the plan beside this kernel on a second stream was measured: no gain, the sort phase stayed at 150 us.)
+    // cursor[q] = first record of bin q (= start of its first bucket) + the records of bin q that the workgroups before
+    // this one hold.  (Deriving the bin starts from the bin counts instead, so that the bucket scan could run beside this
+    // kernel on a second stream, was measured: no gain, the sort phase stayed at 150 us.)
     if (tid < 256) {
-        cursor[tid] = 0;
-        hist[tid] = 0;
+        cursor[tid] = tid < NB ? start[tid << BIN_LOG] : 0;
         fill[tid] = 0;
     }
     __syncthreads();
     {
-        const uint32_t q = tid & 255, part = tid >> 8;            // four lanes share the rows of one bin
-        uint32_t before = 0, all = 0;
-        for (uint32_t r = part; r < gridDim.x; r += COARSE_THREADS / 256) {
-            const uint32_t v = bincount[(size_t)r * 256 + q];
-            all += v;
-            if (r < g) before += v;
-        }
-        if (before) atomicAdd(&cursor[q], before);
-        if (all) atomicAdd(&hist[q], all);                         // hist doubles as the bin totals until the scan below
+        const uint32_t q = tid & 255, part = tid >> 8;            // four lanes share the rows before g of one bin
+        uint32_t sum = 0;
+        for (uint32_t r = part; r < g; r += COARSE_THREADS / 256) sum += bincount[(size_t)r * 256 + q];
+        if (sum) atomicAdd(&cursor[q], sum);
     }
-    __syncthreads();
-    if (tid < 64) {   // exclusive scan of the 256 bin totals, four per lane
-        const uint32_t h0 = hist[4 * tid], h1 = hist[4 * tid + 1], h2 = hist[4 * tid + 2], h3 = hist[4 * tid + 3];
-        const uint32_t sum = h0 + h1 + h2 + h3;
-        uint32_t inc = sum;
-        for (int o = 1; o < 64; o <<= 1) {
-            const uint32_t t = __shfl_up(inc, o, 64);
-            if ((int)tid >= o) inc += t;
-        }
-        const uint32_t e = inc - sum;
-        cursor[4 * tid] += e;
-        cursor[4 * tid + 1] += e + h0;
-        cursor[4 * tid + 2] += e + h0 + h1;
-        cursor[4 * tid + 3] += e + h0 + h1 + h2;
-    }
-    __syncthreads();
     const size_t lo = (size_t)g * chunk, hi = lo + chunk < n ? lo + chunk : n;
     for (size_t r0 = lo; r0 < hi; r0 += T) {
         if (tid < 256) hist[tid] = 0;
@@ -921,7 +900,7 @@ static int msm_phase1(zkhip_ctx* ctx, MsmWorkspace& ws, const MsmTables& tb, siz
         const uint32_t parts = (uint32_t)std::max<size_t>(1, (n * W / NB * 5 / 4 + FINE_SLICE - 1) / FINE_SLICE);
 #define ZK_LAUNCH_COARSE(C)                                                                                              \
     hipLaunchKernelGGL(scatter_coarse_kernel<C>, dim3(G), dim3(COARSE_THREADS), lds_coarse, st, d_scalars, n, chunk, T, \
-                       ws.bincount, ws.tmp)
+                       ws.bincount, ws.start, ws.tmp)
         ZK_FOR_WINDOW_WIDTH(ZK_LAUNCH_COARSE)
 #undef ZK_LAUNCH_COARSE
 #undef ZK_FOR_WINDOW_WIDTH
