@@ -1,0 +1,127 @@
+"""GPU suite, multi-rank: two processes share cuda:0 (gloo carries the few exchanges) and run the sharded pipeline on the
+HIP path; rank 0 compares every result with the unsharded computation.  The partition logic is the one `bench.py --gpus N`
+uses over RCCL with one GPU per rank."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for p in (root, os.path.join(root, "oracle"), os.path.join(root, "tests")):
+        sys.path.insert(0, p)
+    import torch
+    import zkhip_pkg
+    zk = zkhip_pkg.load()
+    from zkevm_circuits_amd import evalh_host, ffi, sharding, synthetic
+    from util import rand_fr
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        ctx = zk.Context(0)
+        k, ncols = 10, 5
+        n = 1 << k
+        rng = np.random.default_rng(4242)                     # the same inputs on every rank
+        bases = ctx.g1_multiples(n)
+        bid = ctx.register_bases(bases)
+        cols = [rand_fr(rng, n) for _ in range(ncols)]
+        d_cols = [ctx.upload(c) for c in cols]
+
+        # (1) column-sharded commitments, gathered in column order
+        mine = {c: ctx.msm_range_dev(bid, 0, d_cols[c], n) for c in sharding.columns_for_rank(ncols, rank, world)}
+        allc = sharding.gather_commitments(mine, ncols, dist)
+        # (2) one MSM split by base range
+        split = sharding.msm_base_split(n, lambda first, cnt: ctx.msm_range_dev(bid, first, d_cols[0] + 32 * first, cnt),
+                                        ctx.g1_sum_jacobian, dist)
+        # (3) evaluate_h split by coset, every rank starting from the coefficient form of the columns
+        cs = synthetic.synthetic_cs(num_advice=6, num_fixed=3, num_gate_polys=30, num_lookups=2, num_perm_cols=4,
+                                    rotations=(-2, -1, 0, 1))
+        dom = zk.Domain(ctx, cs.degree(), k)
+        e, en = dom.extended_k - k, dom.extended_len
+        call = evalh_host.EvalhCall(cs)
+        ext_cols = {name: [rand_fr(rng, en) for _ in range(cnt)] for name, cnt in
+                    (("fixed", cs.num_fixed_columns), ("sigma", len(cs.permutation_columns)),
+                     ("perm_z", cs.num_permutation_sets()), ("l", 3))}
+        coeff = {"advice": [rand_fr(rng, n) for _ in range(cs.num_advice_columns)],
+                 "instance": [rand_fr(rng, n) for _ in range(cs.num_instance_columns)],
+                 "lookups": [tuple(rand_fr(rng, n) for _ in range(3)) for _ in cs.lookups]}
+        call.challenges = rand_fr(rng, cs.num_challenges)
+        call.y, call.beta, call.gamma, call.theta = (rand_fr(rng, 1)[0] for _ in range(4))
+        call.advice, call.instance, call.lookups = coeff["advice"], coeff["instance"], coeff["lookups"]
+
+        def compact(a, cosets):
+            out = np.empty((n * len(cosets), 4), dtype=np.uint64)
+            for s, j in enumerate(cosets):
+                out[s::len(cosets)] = a[j::1 << e]
+            return out
+
+        def evaluate(cosets):
+            if not cosets:
+                return torch.empty((0, 4), dtype=torch.int64)
+            call.cosets = cosets
+            call.fixed = [compact(a, cosets) for a in ext_cols["fixed"]]
+            call.perm_sigma = [compact(a, cosets) for a in ext_cols["sigma"]]
+            call.perm_z = [compact(a, cosets) for a in ext_cols["perm_z"]]
+            call.l0, call.l_last, call.l_active = (compact(a, cosets) for a in ext_cols["l"])
+            part = dom.evaluate_h(call.build(ffi.MEM_HOST, ffi.FORM_COEFF))
+            return torch.from_numpy(part.view(np.int64).copy())
+        pieces = sharding.evaluate_h_by_cosets(dom.extended_k, k, evaluate, dist)
+        h = np.zeros((en, 4), dtype=np.uint64)
+        for cosets, rows in pieces:
+            arr = rows.numpy().view(np.uint64)
+            for s, j in enumerate(cosets):
+                h[j::1 << e] = arr[s::len(cosets)]
+
+        if rank == 0:   # the unsharded computation, on this rank alone
+            ref_c = np.stack([ctx.g1_to_affine(ctx.msm_range_dev(bid, 0, d_cols[c], n)) for c in range(ncols)])
+            got_c = np.stack([ctx.g1_to_affine(j) for j in allc])
+            ok_cols = bool(np.array_equal(ref_c, got_c))
+            ok_split = bool(np.array_equal(ctx.g1_to_affine(split), ref_c[0]))
+            call.cosets = None
+            call.fixed, call.perm_sigma, call.perm_z = ext_cols["fixed"], ext_cols["sigma"], ext_cols["perm_z"]
+            call.l0, call.l_last, call.l_active = ext_cols["l"]
+            whole = dom.evaluate_h(call.build(ffi.MEM_HOST, ffi.FORM_COEFF))
+            ok_h = bool(np.array_equal(whole, h))
+            q.put((ok_cols, ok_split, ok_h, len(pieces)))
+        dist.barrier()
+        dom.close()
+        ctx.close()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_match_the_unsharded_pipeline():
+    world = 2
+    mpctx = mp.get_context("spawn")
+    q = mpctx.Queue()
+    port = _free_port()
+    procs = [mpctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    try:
+        ok_cols, ok_split, ok_h, owners = q.get(timeout=240)
+    finally:
+        for p in procs:
+            p.join(timeout=120)
+    assert all(p.exitcode == 0 for p in procs)
+    assert ok_cols, "column-sharded commitments differ from the unsharded ones"
+    assert ok_split, "base-range split MSM differs from the whole MSM"
+    assert ok_h, "coset-split evaluate_h differs from the whole-domain evaluate_h"
+    assert owners == 2
