@@ -1,11 +1,11 @@
 #!/usr/bin/env python3
 """Benchmark of the halo2 create_proof hot path on MI355X.
 
-A step is one pass of BASELINE.json's configs[1] ("Synthetic BN254 kernels"): one 2^19-point G1 MSM plus one
-2^19 -> 2^21 coset-extension NTT, inputs resident in HBM.  With N > 1 every rank runs the same step on its own
+A step is one pass of the synthetic BN254 kernel configuration the benchmark is quoted on: one 2^19-point G1 MSM plus
+one 2^19 -> 2^21 coset-extension NTT, inputs resident in HBM.  With N > 1 every rank runs the same step on its own
 columns (columns are the independent unit of the prover: no data-path collective), so scaling is weak and `value`
-is the sum over ranks.  After the timed steps the run also measures evaluate_h on the synthetic constraint system of
-BASELINE.md (k = 19, e = 2, A = 64, F = 16, 256 gate polynomials, 16 lookups, 8 permutation columns), an iNTT, and
+is the sum over ranks.  After the timed steps the run also measures evaluate_h on a synthetic constraint system
+(k = 19, e = 2, A = 64, F = 16, 256 gate polynomials, 16 lookups, 8 permutation columns), an iNTT, and
 (rank 0, N = 1) the restated CPU baseline on the host cores.
 
 Prints ONE JSON line on rank 0.

@@ -6,7 +6,7 @@
  * and reaches through `create_proof` (/root/reference/zkevm-circuits/benches/benchmark_list/main.rs:265,315;
  * /root/reference/prover/src/chunk/prover.rs:85; /root/reference/prover/src/batch/prover.rs:149-150) and
  * `keygen_vk/keygen_pk` (/root/reference/zkevm-circuits/benches/benchmark_list/main.rs:121,132,189,194).
- * The comments name the replaced symbol; a Rust binding for each is sketched in INTEGRATION.md.
+ * The comments name the replaced symbol of that crate.
  *
  * Conventions
  *  - Field elements (`halo2curves::bn256::{Fr,Fq}`) are 4 x uint64_t little-endian limbs in Montgomery form
