@@ -19,8 +19,8 @@
 //                           scalars first pass through serial pre-levels of 16 sums per lane)
 //   6. reduce             : sum (b + 1) S_b without scalar multiplications: per wave of 64 buckets six rounds of
 //                           shuffles and additions give the total and the six "bit sums" (sum of the buckets whose
-//                           index has bit j set); a second level folds those over the waves in nine more rounds and
-//                           the host joins the 16 leftover points by Horner in powers of two
+//                           index has bit j set); a second level folds those over the waves in eight more rounds and
+//                           the host joins the 30 leftover points by Horner in powers of two
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
@@ -671,7 +671,7 @@ __device__ __forceinline__ g1_xyzz_w lanes_bit_sums(g1_xyzz_w p, uint32_t lane) 
     return p;
 }
 constexpr uint32_t RED_STREAMS = 7;    // the total and six bit sums of every wave of level 1
-constexpr size_t REDUCE_OUT = 16;      // [0] total, [1 + i] D_i (i < 9), [10 + j] sum over the waves of B_j (j < 6)
+constexpr size_t REDUCE_OUT = 30;      // two halves of 15 points each, see reduce_level2_kernel
 
 // level 1: sums[b] for b < B (B a multiple of 64) -> l1[0][h] = A_h, l1[1 + j][h] = B_{h,j} for wave h = b / 64
 // (J = number of waves = row stride of l1)
@@ -684,27 +684,31 @@ __global__ void __launch_bounds__(256) reduce_level1_kernel(const g1_xyzz* sums,
         xyzz_w_store(l1 + (size_t)stream * J + (b >> 6), p);
     }
 }
-// level 2: workgroup `stream` (eight waves) folds l1[stream][0 .. J), J <= 512.  Wave w takes the waves h = 64 w + lane
-// of level 1; then one wave folds the eight results.  Stream 0 (the totals A_h) keeps its bit sums: over the lane bits
-// they are D_0..D_5, over the wave index D_6..D_8, with D_i = sum of the A_h with bit i of h set.
-__global__ void __launch_bounds__(512) reduce_level2_kernel(const g1_xyzz* l1, uint32_t J, g1_xyzz* out) {
-    __shared__ g1_xyzz_w ex[8][RED_STREAMS];
-    const uint32_t stream = blockIdx.x, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const uint32_t h = w * 64 + lane;
+// level 2: workgroup (stream, half) folds l1[stream][256 half .. 256 half + 256), J <= 512, with four waves -- one per SIMD
+// of its CU: two waves on one SIMD would halve each other's issue rate, and this phase is nothing but one dependency
+// chain.  Wave w takes the waves h = 256 half + 64 w + lane of level 1; then one wave folds the four results.  Stream 0
+// (the totals A_h) keeps its bit sums: over the lane bits they are D_0..D_5, over the wave index D_6, D_7, with
+// D_i = sum of the A_h with bit i of h set; D_8 is the total of the upper half, which the host reads off.
+// out[15 half + ..]: [0] total, [1 + i] D_i (i < 8, this half's part), [9 + j] this half's sum of B_j (j < 6)
+__global__ void __launch_bounds__(256) reduce_level2_kernel(const g1_xyzz* l1, uint32_t J, g1_xyzz* out) {
+    __shared__ g1_xyzz_w ex[4][RED_STREAMS];
+    const uint32_t stream = blockIdx.x >> 1, half = blockIdx.x & 1, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const uint32_t h = half * 256 + w * 64 + lane;
     g1_xyzz_w p = h < J ? xyzz_w_load(l1 + (size_t)stream * J + h) : xyzz_w_identity();
     p = lanes_bit_sums<6>(p, lane);
     if ((lane & (lane - 1)) == 0) ex[w][lane ? 1 + __builtin_ctz(lane) : 0] = p;
     __syncthreads();
     if (w != 0) return;
-    // lane 8 g + u: element u (the wave index of above) of group g; group 0 = totals, group 1 + j = bit sums j
-    const uint32_t g = lane >> 3, u = lane & 7;
+    // lane 4 g + u: element u (the wave index of above) of group g; group 0 = totals, group 1 + j = bit sums j
+    const uint32_t g = lane >> 2, u = lane & 3;
     g1_xyzz_w q = g < RED_STREAMS ? ex[u][g] : xyzz_w_identity();
-    q = lanes_bit_sums<3>(q, lane);
+    q = lanes_bit_sums<2>(q, lane);
+    g1_xyzz* o = out + 15 * half;
     if (stream == 0) {
-        if (g == 0 && (u & (u - 1)) == 0) xyzz_w_store(out + (u ? 7 + __builtin_ctz(u) : 0), q);   // total, D_6..D_8
-        else if (g >= 1 && g < RED_STREAMS && u == 0) xyzz_w_store(out + g, q);                     // D_0..D_5
+        if (g == 0 && u != 3) xyzz_w_store(o + (u ? 6 + u : 0), q);              // total, D_6 (u = 1), D_7 (u = 2)
+        else if (g >= 1 && g < RED_STREAMS && u == 0) xyzz_w_store(o + g, q);     // D_0..D_5
     } else if (lane == 0) {
-        xyzz_w_store(out + 9 + stream, q);                                                          // sum of B_{.,stream-1}
+        xyzz_w_store(o + 8 + stream, q);                                         // sum of B_{., stream - 1}
     }
 }
 
@@ -976,7 +980,7 @@ static int msm_phase2(zkhip_ctx* ctx, MsmWorkspace& ws, const MsmTables& tb, boo
         TimedRegion tr(ctx, timed ? "msm_reduce" : nullptr, st);
         const uint32_t blocks1 = (B + 255) / 256, J = B / 64;   // B is a multiple of 128
         hipLaunchKernelGGL(reduce_level1_kernel, dim3(blocks1), dim3(256), 0, st, ws.sums, B, J, ws.l1);
-        hipLaunchKernelGGL(reduce_level2_kernel, dim3(RED_STREAMS), dim3(512), 0, st, ws.l1, J, ws.out2);
+        hipLaunchKernelGGL(reduce_level2_kernel, dim3(2 * RED_STREAMS), dim3(256), 0, st, ws.l1, J, ws.out2);
         ZK_HIP(ctx, hipGetLastError());
     }
     ZK_HIP(ctx, hipMemcpyAsync(ws.h_sums, ws.out2, REDUCE_OUT * sizeof(g1_xyzz), hipMemcpyDeviceToHost, st));
@@ -985,19 +989,28 @@ static int msm_phase2(zkhip_ctx* ctx, MsmWorkspace& ws, const MsmTables& tb, boo
 
 // phase 3: waits for the leftover sums of the reduce and joins them on the host:
 //   result = total + sum_{t < 15} 2^t X_t,  X_t = sum over the waves of B_t for t < 6, D_(t - 6) for t >= 6
-// (bucket b = 64 h + l weighs b + 1 = 64 h + l + 1), by Horner: 14 doublings and 15 additions.
+// (bucket b = 64 h + l weighs b + 1 = 64 h + l + 1), by Horner: 14 doublings and 15 additions, after the two halves of
+// level 2 have been added up (D_8 = total of the upper half).
 static int msm_phase3(zkhip_ctx* ctx, MsmWorkspace& ws, uint64_t out_jacobian[12]) {
     ZK_HIP(ctx, hipStreamSynchronize(ws.stream));
     memset(out_jacobian, 0, 96);
     if (!ws.nonzero) return ZKHIP_OK;
+    uint64_t pt[2][15][12];
+    for (int hf = 0; hf < 2; hf++)
+        for (int i = 0; i < 15; i++) xyzz_to_jacobian_host(pt[hf][i], ws.h_sums + 16 * (15 * hf + i));
     uint64_t acc[12], t[12];
     memset(acc, 0, sizeof acc);
     for (int k = 14; k >= 0; k--) {
         h_g1_double(acc, acc);
-        xyzz_to_jacobian_host(t, ws.h_sums + 16 * (k < 6 ? 10 + k : 1 + (k - 6)));
+        if (k == 14) {
+            memcpy(t, pt[1][0], sizeof t);                       // D_8
+        } else {
+            const int idx = k < 6 ? 9 + k : 1 + (k - 6);        // B_k or D_(k - 6)
+            h_g1_add(t, pt[0][idx], pt[1][idx]);
+        }
         h_g1_add(acc, acc, t);
     }
-    xyzz_to_jacobian_host(t, ws.h_sums);
+    h_g1_add(t, pt[0][0], pt[1][0]);
     h_g1_add(acc, acc, t);
     memcpy(out_jacobian, acc, 96);
     return ZKHIP_OK;
