@@ -141,6 +141,18 @@ def test_msm_full_size_known_answer(ctx, co):
     ctx.release_bases(bid)
 
 
+@pytest.mark.parametrize("n", [140001, 200000, 1 << 20])
+def test_msm_other_window_widths_known_answer(ctx, co, n):
+    """window widths 15 (2^17 < n <= 2^18) and 16 with more than 2^19 points, against the closed form for bases (i+1)G"""
+    rng = np.random.default_rng(n)
+    bid = ctx.register_bases(ctx.g1_multiples(n))
+    sc = rand_fr(rng, n)
+    vals = fr_ints(sc)
+    k = sum(v * (i + 1) for i, v in enumerate(vals)) % P
+    assert affine_pt(ctx.g1_to_affine(ctx.msm(bid, sc))) == bn.g1_mul(bn.G1_GENERATOR, k)
+    ctx.release_bases(bid)
+
+
 # ------------------------------------------------------------------------------------------------ NTT / domain
 def test_ntt_golden(ctx):
     for case in golden("ntt.json")["cases"]:
