@@ -227,6 +227,11 @@ int zkhip_lookup_product_dev(zkhip_domain* dom, const uint64_t* d_compressed_inp
                              const uint64_t* d_permuted_input, const uint64_t* d_permuted_table, const uint64_t beta[4],
                              const uint64_t gamma[4], uint64_t* d_z);
 int zkhip_eval_polynomial_dev(zkhip_ctx* ctx, const uint64_t* d_coeff, size_t n, const uint64_t x[4], uint64_t out[4]);
+/* `count` calls of `arithmetic::eval_polynomial` in one launch and one synchronisation: out[i] = d_coeffs[i](points[i]),
+ * every polynomial with n coefficients (the evaluations `create_proof` writes to the transcript before the multi-open:
+ * one per (polynomial, rotation) query).  d_coeffs: HOST array of device pointers; points, out: HOST, count x 4 limbs. */
+int zkhip_eval_polynomials_dev(zkhip_ctx* ctx, const uint64_t* const* d_coeffs, const uint64_t* points, uint32_t count, size_t n,
+                               uint64_t* out);
 /* `plonk::lookup::prover::permute_expression_pair`: rows [0, usable_rows) of the permuted input A' (the compressed input
  * sorted by canonical value) and of the permuted table S' (S'[i] = A'[i] where A'[i] first occurs; the table values left
  * over, ascending, fill the repeated rows from the last one backwards).  usable_rows = n - (blinding_factors + 1); the

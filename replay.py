@@ -262,9 +262,10 @@ def main():
     queries = []
 
     def openings():
-        for key, (ptr, rots) in enumerate(shapes):
-            for r in rots:
-                queries.append(shplonk.Query(key, points[r], to_int(ctx.eval_polynomial_dev(ptr, n, point_limbs[r]))))
+        flat = [(key, ptr, r) for key, (ptr, rots) in enumerate(shapes) for r in rots]
+        vals = ctx.eval_polynomials_dev([f[1] for f in flat], np.stack([point_limbs[f[2]] for f in flat]), n)
+        for (key, _, r), v in zip(flat, vals):
+            queries.append(shplonk.Query(key, points[r], to_int(v)))
     ph.run("eval_polynomial", openings)
 
     class Transcript:   # the Blake2b transcript stays on the host in the reference; challenges are stand-ins

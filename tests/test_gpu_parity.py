@@ -490,6 +490,20 @@ def test_eval_polynomial(ctx, n):
     ctx.free(d)
 
 
+def test_eval_polynomials_batch(ctx):
+    """many (polynomial, point) pairs in one call equal the single calls"""
+    rng = np.random.default_rng(8)
+    n = 5000
+    polys = [ctx.upload(rand_fr(rng, n)) for _ in range(5)]
+    queries = [(polys[i % 5], rand_fr(rng, 1)[0]) for i in range(23)]
+    got = ctx.eval_polynomials_dev([q[0] for q in queries], np.stack([q[1] for q in queries]), n)
+    for (ptr, x), g_ in zip(queries, got):
+        assert np.array_equal(g_, ctx.eval_polynomial_dev(ptr, n, x))
+    assert ctx.eval_polynomials_dev([], np.zeros((0, 4), np.uint64), n).shape == (0, 4)
+    for p_ in polys:
+        ctx.free(p_)
+
+
 def test_grand_products_golden(ctx):
     g = golden("products.json")
     for c in g["permutation"]:

@@ -379,6 +379,36 @@ __global__ void __launch_bounds__(PO_THREADS) perm_sigma_kernel(const uint32_t* 
     store_fe(out + i, Fr::mul(om, load_fe(dpow + col[i])));
 }
 
+// many (polynomial, point) pairs in one launch: blockIdx.y = query, the same lane work as eval_poly_kernel
+struct EvalQuery {
+    const fe* coeff;
+    fe x, x_per;
+};
+__global__ void __launch_bounds__(PO_THREADS) eval_poly_batch_kernel(const EvalQuery* queries, size_t n, fe* partial) {
+    __shared__ fe sh[PO_THREADS];
+    const EvalQuery q = queries[blockIdx.y];
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t base = t * EP_PER;
+    fe acc = Fr::zero();
+    if (base < n) {
+        const size_t hi = base + EP_PER < n ? base + EP_PER : n;
+        for (size_t i = hi; i-- > base;) acc = Fr::add(Fr::mul(acc, q.x), load_fe(q.coeff + i));
+        fe p = Fr::one(), b = q.x_per;
+        for (size_t e = t; e; e >>= 1) {
+            if (e & 1) p = Fr::mul(p, b);
+            b = Fr::sqr(b);
+        }
+        acc = Fr::mul(acc, p);
+    }
+    sh[threadIdx.x] = acc;
+    __syncthreads();
+    for (uint32_t half = PO_THREADS / 2; half >= 1; half >>= 1) {
+        if (threadIdx.x < half) sh[threadIdx.x] = Fr::add(sh[threadIdx.x], sh[threadIdx.x + half]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) store_fe(partial + (size_t)blockIdx.y * gridDim.x + blockIdx.x, sh[0]);
+}
+
 // ---- launch helpers ----------------------------------------------------------------------------------
 static fe fe_from(const uint64_t v[4]) {
     fe o;
@@ -543,6 +573,52 @@ int zkhip_eval_polynomial_dev(zkhip_ctx* ctx, const uint64_t* d_coeff, size_t n,
     uint64_t acc[4] = {0, 0, 0, 0};
     for (size_t b = 0; b < nblocks; b++) h_add(HFR, acc, acc, &part[4 * b]);
     memcpy(out, acc, 32);
+    return ZKHIP_OK;
+}
+
+int zkhip_eval_polynomials_dev(zkhip_ctx* ctx, const uint64_t* const* d_coeffs, const uint64_t* points, uint32_t count, size_t n,
+                               uint64_t* out) {
+    if (!ctx) return ZKHIP_ERR_INVALID;
+    ZK_CHECK(ctx, (d_coeffs && points && out) || count == 0, "eval_polynomials: null pointer");
+    if (count == 0) return ZKHIP_OK;
+    memset(out, 0, (size_t)count * 32);
+    if (n == 0) return ZKHIP_OK;
+    for (uint32_t i = 0; i < count; i++) ZK_CHECK(ctx, d_coeffs[i], "eval_polynomials: null polynomial %u", i);
+    ZK_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t lanes = (n + EP_PER - 1) / EP_PER;
+    const size_t nblocks = (lanes + PO_THREADS - 1) / PO_THREADS;
+    const uint32_t chunk_max = 16384;   // queries per launch (gridDim.y limit is 65535)
+    std::vector<EvalQuery> q(std::min(count, chunk_max));
+    std::vector<uint64_t> part;
+    for (uint32_t first = 0; first < count; first += chunk_max) {
+        const uint32_t c = std::min(chunk_max, count - first);
+        const size_t qbytes = (c * sizeof(EvalQuery) + 255) & ~(size_t)255;
+        int rc = ensure_scratch(ctx, qbytes + (size_t)c * nblocks * 32);
+        if (rc) return rc;
+        for (uint32_t i = 0; i < c; i++) {
+            q[i].coeff = (const fe*)d_coeffs[first + i];
+            memcpy(q[i].x.l, points + 4 * (size_t)(first + i), 32);
+            uint64_t x_per[4];
+            h_pow(HFR, x_per, points + 4 * (size_t)(first + i), EP_PER);
+            memcpy(q[i].x_per.l, x_per, 32);
+        }
+        fe* d_part = (fe*)((unsigned char*)ctx->scratch + qbytes);
+        ZK_HIP(ctx, hipMemcpyAsync(ctx->scratch, q.data(), c * sizeof(EvalQuery), hipMemcpyHostToDevice, ctx->stream));
+        {
+            TimedRegion tr(ctx, "eval_polynomial");
+            hipLaunchKernelGGL(eval_poly_batch_kernel, dim3((unsigned)nblocks, c), dim3(PO_THREADS), 0, ctx->stream,
+                               (const EvalQuery*)ctx->scratch, n, d_part);
+            ZK_HIP(ctx, hipGetLastError());
+        }
+        part.resize((size_t)c * nblocks * 4);
+        ZK_HIP(ctx, hipMemcpyAsync(part.data(), d_part, (size_t)c * nblocks * 32, hipMemcpyDeviceToHost, ctx->stream));
+        ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        for (uint32_t i = 0; i < c; i++) {
+            uint64_t acc[4] = {0, 0, 0, 0};
+            for (size_t b = 0; b < nblocks; b++) h_add(HFR, acc, acc, &part[4 * ((size_t)i * nblocks + b)]);
+            memcpy(out + 4 * (size_t)(first + i), acc, 32);
+        }
+    }
     return ZKHIP_OK;
 }
 

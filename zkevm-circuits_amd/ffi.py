@@ -30,7 +30,7 @@ EXPORTS = [
     "zkhip_evaluate_h", "zkhip_evaluate_h_last_stats",
     "zkhip_coeff_to_cosets_dev", "zkhip_extended_to_cosets_dev", "zkhip_cosets_to_extended_dev",
     "zkhip_batch_invert_dev", "zkhip_prefix_product_dev", "zkhip_permutation_product_dev", "zkhip_lookup_product_dev",
-    "zkhip_eval_polynomial_dev", "zkhip_poly_lincomb_dev", "zkhip_kate_division_dev", "zkhip_lookup_permute_dev", "zkhip_permutation_sigma_dev",
+    "zkhip_eval_polynomial_dev", "zkhip_eval_polynomials_dev", "zkhip_poly_lincomb_dev", "zkhip_kate_division_dev", "zkhip_lookup_permute_dev", "zkhip_permutation_sigma_dev",
     "zkhip_timing_enable", "zkhip_timing_reset", "zkhip_timing_get",
 ]
 
@@ -296,6 +296,15 @@ class Context:
         out = np.zeros(4, dtype=np.uint64)
         self._ck(self._l.zkhip_eval_polynomial_dev(self.h, C.c_void_p(d_coeff), C.c_size_t(n), _p(x), _p(out)))
         return out
+
+    def eval_polynomials_dev(self, d_coeffs, points, n: int):
+        """out[i] = polynomial d_coeffs[i] (n coefficients, device) at points[i] ((count, 4) Montgomery limbs)"""
+        count = len(d_coeffs)
+        ptrs = (C.c_void_p * max(count, 1))(*[C.c_void_p(int(p)) for p in d_coeffs])
+        pts = np.ascontiguousarray(np.asarray(points, dtype=np.uint64).reshape(count, 4)) if count else np.zeros((1, 4), np.uint64)
+        out = np.zeros((max(count, 1), 4), dtype=np.uint64)
+        self._ck(self._l.zkhip_eval_polynomials_dev(self.h, ptrs, _p(pts), C.c_uint32(count), C.c_size_t(n), _p(out)))
+        return out[:count]
 
     def poly_lincomb_dev(self, d_polys, lens, coeffs, n: int, d_out: int):
         """d_out[i] = sum_k coeffs[k] * d_polys[k][i]; d_polys: device pointers, lens: their lengths (<= n),
