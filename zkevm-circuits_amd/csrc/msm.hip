@@ -303,9 +303,34 @@ constexpr uint32_t PLAN_STRIDE = 128;   // words per block in the plan statistic
 enum { INFO_SLOTS = 0, INFO_MAXCNT = 1, INFO_L = 2, INFO_ENTRIES = 3, INFO_HEAVY = 4 };   // HEAVY: slots in buckets of > 32
 constexpr uint32_t MERGE_DIRECT_MAX = 32;   // the final merge level takes buckets of up to this many partial sums
 ZK_DEV uint32_t next_slot_len(uint32_t L) { return L + (L < 40 ? 1 : L / 40); }
+// the candidates, built once on the host: L[i] for ladder step i (plan word 2 + i), 0 beyond L_MAX
+struct SlotLadder {
+    uint32_t L[PLAN_STRIDE];
+};
+static SlotLadder make_ladder(uint32_t l_min) {
+    SlotLadder lad;
+    uint32_t L = l_min;
+    for (uint32_t i = 0; i < PLAN_STRIDE; i++) {
+        lad.L[i] = (i + 2 < PLAN_STRIDE && L <= L_MAX) ? L : 0;
+        if (L <= L_MAX) L = next_slot_len(L);
+    }
+    return lad;
+}
 
 __device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {
     for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+    return v;
+}
+// inclusive prefix sum over the 64 lanes with data-parallel-primitive moves (no LDS crossbar round trips): shifts by
+// 1, 2, 4, 8 inside each row of 16 lanes (lanes without a source read 0), then the last lane of row 0 / 2 is added to
+// row 1 / 3 and the last lane of row 1 to rows 2 and 3
+__device__ __forceinline__ uint32_t wave_inclusive_scan_u32(uint32_t v) {
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);   // row_shr:1
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);   // row_shr:2
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);   // row_shr:4
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);   // row_shr:8
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);   // row_bcast:15 into rows 1, 3
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);   // row_bcast:31 into rows 2, 3
     return v;
 }
 __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
@@ -321,7 +346,7 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
 // Each block also leaves its share of the plan statistics in plan[blockIdx.x][*].
 constexpr int COLSUM_THREADS = 1024;
 __global__ void __launch_bounds__(COLSUM_THREADS) column_sum_kernel(const uint32_t* counts /*[G][B]*/, uint32_t G, uint32_t B,
-                                                                    uint32_t* cnt, uint32_t l_min, uint32_t* plan) {
+                                                                    uint32_t* cnt, const SlotLadder ladder, uint32_t* plan) {
     __shared__ uint32_t sh[PLAN_STRIDE];
     __shared__ uint32_t part[COLSUM_THREADS / 64][256];
     for (uint32_t i = threadIdx.x; i < PLAN_STRIDE; i += COLSUM_THREADS) sh[i] = 0;
@@ -350,14 +375,13 @@ __global__ void __launch_bounds__(COLSUM_THREADS) column_sum_kernel(const uint32
     __syncthreads();
     // statistics: lane i < 2 folds max / sum, lane 2 + i the slots of ladder step i, over the block's 256 bucket sizes
     if (threadIdx.x < PLAN_STRIDE) {
-        uint32_t L = l_min;
-        for (uint32_t i = 2; i < threadIdx.x && L <= L_MAX; i++) L = next_slot_len(L);
+        const uint32_t L = threadIdx.x >= 2 ? ladder.L[threadIdx.x - 2] : 0;
         uint32_t acc = 0;
         if (threadIdx.x == 0) {
             for (int k = 0; k < 256; k++) acc = cv[k] > acc ? cv[k] : acc;
         } else if (threadIdx.x == 1) {
             for (int k = 0; k < 256; k++) acc += cv[k];
-        } else if (L <= L_MAX) {
+        } else if (L) {
             // ceil(c / L) = floor((c + L - 1) * ceil(2^32 / L) / 2^32), exact while (c + L) * L < 2^32
             const uint32_t magic = (uint32_t)((0x100000000ull + L - 1) / L);
             for (int k = 0; k < 256; k++) acc += __umulhi(cv[k] + L - 1, magic);
@@ -377,7 +401,7 @@ __global__ void __launch_bounds__(COLSUM_THREADS) column_sum_kernel(const uint32
 __global__ void __launch_bounds__(1024) bucket_scan_kernel(const uint32_t* cnt, uint32_t B, uint32_t D, uint32_t* f_out,
                                                            uint32_t* off_out, uint32_t* start_out, uint32_t* cur_out,
                                                            const uint32_t* plan,
-                                                           uint32_t plan_blocks, uint32_t l_min, uint32_t round_lanes,
+                                                           uint32_t plan_blocks, const SlotLadder ladder, uint32_t round_lanes,
                                                            uint32_t force_L, uint32_t* info) {
     __shared__ uint32_t wsum[3][16];
     __shared__ uint32_t best;
@@ -406,9 +430,8 @@ __global__ void __launch_bounds__(1024) bucket_scan_kernel(const uint32_t* cnt, 
             if (tid == 1) info[INFO_ENTRIES] = v;
             if (tid >= 2) {
                 // candidate index tid - 2: recompute its L
-                uint32_t L = l_min;
-                for (uint32_t i = 2; i < tid && L <= L_MAX; i++) L = next_slot_len(L);
-                if (L <= L_MAX) {
+                const uint32_t L = ladder.L[tid - 2];
+                if (L) {
                     const uint32_t rounds = v == 0 ? 1 : (v + round_lanes - 1) / round_lanes;
                     // in 1/16 of a mixed addition per SIMD: the accumulate rounds, the partly filled last round
                     // (about 0.7 L, measured) and the merge of v / B partial sums per bucket; ties go to the longer slot
@@ -436,14 +459,7 @@ __global__ void __launch_bounds__(1024) bucket_scan_kernel(const uint32_t* cnt, 
             const uint32_t f = (c + D - 1) / D;
             if (idx < B) f_out[idx] = f;
             heavy += f > MERGE_DIRECT_MAX ? f : 0;
-            uint32_t inf = f, inc = c;
-            for (int d = 1; d < 64; d <<= 1) {
-                const uint32_t tf = __shfl_up(inf, d, 64), tc = __shfl_up(inc, d, 64);
-                if ((int)lane >= d) {
-                    inf += tf;
-                    inc += tc;
-                }
-            }
+            const uint32_t inf = wave_inclusive_scan_u32(f), inc = wave_inclusive_scan_u32(c);
             offf[r] = carry_f + inf - f;
             offc[r] = carry_c + inc - c;
             carry_f += __shfl(inf, 63, 64);
@@ -564,11 +580,7 @@ __global__ void __launch_bounds__(1024) heavy_scan_kernel(const uint32_t* off_in
         const bool in = (uint32_t)(i * 64) < S && b < B;
         const uint32_t c = in ? cnt_in[b] : 0;
         const uint32_t f = c > direct_max ? (c + fold - 1) / fold : 0;
-        uint32_t inc = f;
-        for (int d = 1; d < 64; d <<= 1) {
-            const uint32_t t = __shfl_up(inc, d, 64);
-            if ((int)lane >= d) inc += t;
-        }
+        const uint32_t inc = wave_inclusive_scan_u32(f);
         cs[i] = c;
         ex[i] = run + inc - f;
         run += __shfl(inc, 63, 64);
@@ -792,6 +804,7 @@ struct MsmWorkspace {
     size_t n = 0, first = 0;
     const fe* d_scalars = nullptr;
     uint32_t G = 0, l_min = 0, plan_blocks = 0, acc_blocks = 0;
+    SlotLadder ladder;
     bool nonzero = false;
     uint32_t *counts, *entries, *start, *cnt, *offA, *cntA, *offB, *cntB, *info, *plan, *cur, *bincount, *hoff;
     uint2* tmp;
@@ -807,6 +820,7 @@ static int ws_prepare(zkhip_ctx* ctx, MsmWorkspace& ws, const MsmTables& tb, siz
     // shortest slot the plan may pick: keeps the partial-sum buffers within E_max / l_min + B items
     ws.l_min = (uint32_t)std::min<size_t>(64, std::max<size_t>(8, E_max / (8 * round_lanes)));
     if (FORCE_L) ws.l_min = std::min(ws.l_min, FORCE_L);
+    ws.ladder = make_ladder(ws.l_min);
     ws.plan_blocks = (B + 255) / 256;
     const size_t T1_max = E_max / ws.l_min + B + 1;
     const size_t J = (B + 63) / 64;
@@ -890,9 +904,9 @@ static int msm_phase1(zkhip_ctx* ctx, MsmWorkspace& ws, const MsmTables& tb, siz
     hipLaunchKernelGGL(digits_hist_kernel<C>, dim3(G), dim3(HIST_THREADS), lds_hist, st, d_scalars, n, chunk, ws.counts, ws.bincount)
     ZK_FOR_WINDOW_WIDTH(ZK_LAUNCH_HIST)
 #undef ZK_LAUNCH_HIST
-    hipLaunchKernelGGL(column_sum_kernel, dim3(ws.plan_blocks), dim3(COLSUM_THREADS), 0, st, ws.counts, G, B, ws.cnt, ws.l_min, ws.plan);
+    hipLaunchKernelGGL(column_sum_kernel, dim3(ws.plan_blocks), dim3(COLSUM_THREADS), 0, st, ws.counts, G, B, ws.cnt, ws.ladder, ws.plan);
     hipLaunchKernelGGL(bucket_scan_kernel, dim3(1), dim3(1024), 0, st, ws.cnt, B, 0u, ws.cntA, ws.offA, ws.start, ws.cur, ws.plan,
-                       ws.plan_blocks, ws.l_min, (uint32_t)ctx->num_cus * 256u, FORCE_L, ws.info);
+                       ws.plan_blocks, ws.ladder, (uint32_t)ctx->num_cus * 256u, FORCE_L, ws.info);
     // the plan travels to the host while scatter and accumulate run
     ZK_HIP(ctx, hipMemcpyAsync(ws.h_info, ws.info, 32, hipMemcpyDeviceToHost, st));
     ZK_HIP(ctx, hipEventRecord(ws.ev_info, st));
