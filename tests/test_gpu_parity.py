@@ -141,6 +141,30 @@ def test_msm_full_size_known_answer(ctx, co):
     ctx.release_bases(bid)
 
 
+def test_msm_batch_with_skewed_columns_matches_single_calls(ctx):
+    """the pipelined batch over columns of different scalar distributions (uniform, witness-like, 16-bit, all ones:
+    heavy-bucket pre-levels of either kind in neighbouring workspaces) equals the single calls"""
+    n = 1 << 17
+    rng = np.random.default_rng(17)
+    bid = ctx.register_bases(ctx.g1_multiples(n))
+    to_mont = lambda c: ctx.field_binop(0, 2, c, np.repeat(fr_arr([(1 << 256) % P]), len(c), axis=0))
+    small = np.zeros((n, 4), dtype=np.uint64)
+    small[:, 0] = rng.integers(0, 1 << 16, size=n, dtype=np.uint64)
+    ones = np.zeros((n, 4), dtype=np.uint64)
+    ones[:, 0] = 1
+    cols = [rand_fr(rng, n), witness_like(rng, n, to_mont), to_mont(small), to_mont(ones),
+            rand_fr(rng, n), np.zeros((n, 4), dtype=np.uint64)]
+    d_cols = [ctx.upload(c) for c in cols]
+    batch = ctx.msm_batch_dev(bid, d_cols, n)
+    for i, d in enumerate(d_cols):
+        assert np.array_equal(ctx.g1_to_affine(batch[i]), ctx.g1_to_affine(ctx.msm_range_dev(bid, 0, d, n))), i
+    # all ones: sum of the bases = (n (n + 1) / 2) G
+    assert affine_pt(ctx.g1_to_affine(batch[3])) == bn.g1_mul(bn.G1_GENERATOR, n * (n + 1) // 2)
+    for d in d_cols:
+        ctx.free(d)
+    ctx.release_bases(bid)
+
+
 @pytest.mark.parametrize("n", [140001, 200000, 1 << 20])
 def test_msm_other_window_widths_known_answer(ctx, co, n):
     """window widths 15 (2^17 < n <= 2^18) and 16 with more than 2^19 points, against the closed form for bases (i+1)G"""
