@@ -26,16 +26,21 @@ namespace zkhip {
 
 constexpr int PO_THREADS = 256;
 
+// x^(p - 2) in the lazy digit form (2^261 Montgomery domain inside, 2^256 domain in and out): 254 squarings and about
+// 127 products of ~245 instructions each instead of ~345 in the packed form -- this chain is the latency of every
+// batch inversion
 template <class F, class FP>
 ZK_DEV fe field_invert(const fe& x) {
-    fe acc = F::one();
+    using W = Wide<FP>;
+    const fw xw = W::from_fe_shl5(x);      // x 2^256 -> x 2^261
+    fw acc = W::one();
     for (int bit = 255; bit >= 0; bit--) {
-        acc = F::sqr(acc);
+        acc = W::sqr(acc);
         uint32_t word = FP::P[bit >> 5];
         if ((bit >> 5) == 0) word -= 2;   // exponent p - 2; the low word of p is > 2
-        if ((word >> (bit & 31)) & 1) acc = F::mul(acc, x);
+        if ((word >> (bit & 31)) & 1) acc = W::mul(acc, xw);
     }
-    return acc;
+    return W::to_fe(W::mul(acc, W::r256()));
 }
 
 // ---- batch inversion ---------------------------------------------------------------------------------
