@@ -409,7 +409,7 @@ def finish(args, ctx, dist, world, rank, local_rank, bid, scalars, n, en, elapse
             "msm_phases_us": {"sort": sort_us, "accumulate": acc_us, "merge": merge_us, "reduce": reduce_us},
             "coset_ntt_ms": ntt_ms, "coset_ntt_GBps": world * ntt_bytes / (ntt_ms * 1e-3) / 1e9,
             "coset_ntt_frac_of_hbm_peak": ntt_bytes / (ntt_ms * 1e-3) / 1e9 / HBM_PEAK,
-            "roofline": {"bound": "valu-int (32x32+64 multiply-add issue; no MFMA or HBM bound applies to this kernel)", "kernel": "accumulate_kernel", "achieved": achieved / 1e12,
+            "roofline": {"bound": "valu", "bound_note": "32x32+64 integer multiply-add issue rate of the vector ALUs: the kernel is no dense contraction (no MFMA) and moves 0.75 GB per launch (not HBM-bound)", "kernel": "accumulate_kernel", "achieved": achieved / 1e12,
                          "peak": VALU_MAD_PEAK / 1e12, "unit": "Tmad/s", "frac": achieved / VALU_MAD_PEAK,
                          "avg_launch_us": acc_us, "launches": acc_launches,
                          # HBM bytes per launch from separate rocprofv3 --pmc passes over this same command
