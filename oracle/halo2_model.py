@@ -272,16 +272,17 @@ def graph_evaluate(prog, inp: EvalInputs, previous_value: int, idx: int, rot_sca
 #   perm: None | {columns: [(kind, index)], sigma: [coset], z: [coset], chunk_len, blinding_factors}
 #   l0, l_last, l_active: extended cosets
 # ---------------------------------------------------------------------------------------------
-def evaluate_h(dom: EvaluationDomain, inp: EvalInputs, desc) -> list:
+def evaluate_h_row(dom: EvaluationDomain, inp: EvalInputs, desc, idx: int) -> int:
+    """One row of evaluate_h.  Upstream sweeps the gates over all rows, then the permutation argument, then each lookup;
+    the value of a row depends on that row's running value only, so the sweeps commute with the row loop.  Columns are
+    only ever indexed, so they may be any object with __getitem__ (e.g. a lazy view of device memory)."""
     size = dom.extended_len()
     rot_scale = 1 << (dom.extended_k - dom.k)
     y, beta, gamma = inp.y, inp.beta, inp.gamma
     l0, l_last, l_active = desc["l0"], desc["l_last"], desc["l_active"]
-    values = [0] * size
-
+    v = 0
     if desc.get("gates") is not None:
-        for idx in range(size):
-            values[idx] = graph_evaluate(desc["gates"], inp, values[idx], idx, rot_scale, size)
+        v = graph_evaluate(desc["gates"], inp, v, idx, rot_scale, size)
 
     perm = desc.get("perm")
     if perm and perm["z"]:
@@ -291,45 +292,43 @@ def evaluate_h(dom: EvaluationDomain, inp: EvalInputs, desc) -> list:
         cols = perm["columns"]
         delta_start = beta * FR_ZETA % P
         src = {VS_ADVICE: inp.advice, VS_FIXED: inp.fixed, VS_INSTANCE: inp.instance}
-        for idx in range(size):
-            v = values[idx]
-            r_next = rotation_idx(idx, 1, rot_scale, size)
-            r_last = rotation_idx(idx, last_rot, rot_scale, size)
-            v = (v * y + (1 - z[0][idx]) * l0[idx]) % P
-            zl = z[-1][idx]
-            v = (v * y + (zl * zl - zl) * l_last[idx]) % P
-            for s in range(1, len(z)):
-                v = (v * y + (z[s][idx] - z[s - 1][r_last]) * l0[idx]) % P
-            current_delta = delta_start * pow(dom.extended_omega, idx, P) % P
-            for s in range(len(z)):
-                chunk = cols[s * chunk_len:(s + 1) * chunk_len]
-                sig = perm["sigma"][s * chunk_len:(s + 1) * chunk_len]
-                left = z[s][r_next]
-                for (kind, ci), sg in zip(chunk, sig):
-                    left = left * (src[kind][ci][idx] + beta * sg[idx] + gamma) % P
-                right = z[s][idx]
-                for (kind, ci) in chunk:
-                    right = right * (src[kind][ci][idx] + current_delta + gamma) % P
-                    current_delta = current_delta * FR_DELTA % P
-                v = (v * y + (left - right) * l_active[idx]) % P
-            values[idx] = v
+        r_next = rotation_idx(idx, 1, rot_scale, size)
+        r_last = rotation_idx(idx, last_rot, rot_scale, size)
+        v = (v * y + (1 - z[0][idx]) * l0[idx]) % P
+        zl = z[-1][idx]
+        v = (v * y + (zl * zl - zl) * l_last[idx]) % P
+        for s in range(1, len(z)):
+            v = (v * y + (z[s][idx] - z[s - 1][r_last]) * l0[idx]) % P
+        current_delta = delta_start * pow(dom.extended_omega, idx, P) % P
+        for s in range(len(z)):
+            chunk = cols[s * chunk_len:(s + 1) * chunk_len]
+            sig = perm["sigma"][s * chunk_len:(s + 1) * chunk_len]
+            left = z[s][r_next]
+            for (kind, ci), sg in zip(chunk, sig):
+                left = left * (src[kind][ci][idx] + beta * sg[idx] + gamma) % P
+            right = z[s][idx]
+            for (kind, ci) in chunk:
+                right = right * (src[kind][ci][idx] + current_delta + gamma) % P
+                current_delta = current_delta * FR_DELTA % P
+            v = (v * y + (left - right) * l_active[idx]) % P
 
     for lk in desc.get("lookups", []):
         zc, ac, sc = lk["product"], lk["permuted_input"], lk["permuted_table"]
-        for idx in range(size):
-            v = values[idx]
-            table_value = graph_evaluate(lk["program"], inp, 0, idx, rot_scale, size)
-            r_next = rotation_idx(idx, 1, rot_scale, size)
-            r_prev = rotation_idx(idx, -1, rot_scale, size)
-            a_minus_s = (ac[idx] - sc[idx]) % P
-            v = (v * y + (1 - zc[idx]) * l0[idx]) % P
-            v = (v * y + (zc[idx] * zc[idx] - zc[idx]) * l_last[idx]) % P
-            v = (v * y + (zc[r_next] * (ac[idx] + beta) * (sc[idx] + gamma) - zc[idx] * table_value)
-                 * l_active[idx]) % P
-            v = (v * y + a_minus_s * l0[idx]) % P
-            v = (v * y + a_minus_s * (ac[idx] - ac[r_prev]) * l_active[idx]) % P
-            values[idx] = v
-    return values
+        table_value = graph_evaluate(lk["program"], inp, 0, idx, rot_scale, size)
+        r_next = rotation_idx(idx, 1, rot_scale, size)
+        r_prev = rotation_idx(idx, -1, rot_scale, size)
+        a_minus_s = (ac[idx] - sc[idx]) % P
+        v = (v * y + (1 - zc[idx]) * l0[idx]) % P
+        v = (v * y + (zc[idx] * zc[idx] - zc[idx]) * l_last[idx]) % P
+        v = (v * y + (zc[r_next] * (ac[idx] + beta) * (sc[idx] + gamma) - zc[idx] * table_value)
+             * l_active[idx]) % P
+        v = (v * y + a_minus_s * l0[idx]) % P
+        v = (v * y + a_minus_s * (ac[idx] - ac[r_prev]) * l_active[idx]) % P
+    return v
+
+
+def evaluate_h(dom: EvaluationDomain, inp: EvalInputs, desc) -> list:
+    return [evaluate_h_row(dom, inp, desc, idx) for idx in range(dom.extended_len())]
 
 
 # ---------------------------------------------------------------------------------------------

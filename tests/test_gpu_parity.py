@@ -1114,3 +1114,74 @@ def test_g_to_lagrange_commits_like_the_monomial_basis(ctx, co, k):
     ctx.release_bases(b_g)
     ctx.release_bases(b_l)
     d.close()
+
+
+# ------------------------------------------------------------------------------------------------ evaluate_h at full size
+class _DeviceColumn:
+    """Lazy view of a device-resident column for the big-int model: rows are fetched one by one on first use."""
+    R_INV = pow(1 << 256, P - 2, P)
+
+    def __init__(self, tensor):
+        self.t, self.cache = tensor, {}
+
+    def __getitem__(self, i):
+        v = self.cache.get(i)
+        if v is None:
+            limbs = self.t[i].cpu().numpy().view(np.uint64)
+            v = sum(int(w) << (64 * j) for j, w in enumerate(limbs)) * self.R_INV % P
+            self.cache[i] = v
+        return v
+
+
+def test_evaluate_h_full_size_sampled_rows(ctx):
+    """k = 19, extended domain 2^21, the benchmark's constraint system (64 advice, 16 fixed, 256 gate polynomials,
+    16 lookups, 8 permutation columns), all 143 columns resident on the device: rows sampled over the whole domain
+    (first, last, wrap-around neighbours of the rotations) against the big-int model evaluated on those rows only"""
+    import torch
+    import halo2_model as hm
+    k = 19
+    cs = synthetic.synthetic_cs(num_advice=64, num_fixed=16, num_instance=1, num_gate_polys=256, max_degree=5,
+                                rotations=(-2, -1, 0, 1), num_lookups=16, lookup_width=3, num_perm_cols=8)
+    d = zk.Domain(ctx, cs.degree(), k)
+    en = d.extended_len
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(19)
+
+    def col():
+        t = torch.randint(-(1 << 63), (1 << 63) - 1, (en, 4), dtype=torch.int64, device="cuda", generator=gen)
+        t[:, 3] &= 0x0FFFFFFFFFFFFFFF
+        return t
+    T = {"fixed": [col() for _ in range(cs.num_fixed_columns)], "advice": [col() for _ in range(cs.num_advice_columns)],
+         "instance": [col() for _ in range(cs.num_instance_columns)], "l": [col() for _ in range(3)],
+         "lookups": [tuple(col() for _ in range(3)) for _ in cs.lookups],
+         "sigma": [col() for _ in cs.permutation_columns], "perm_z": [col() for _ in range(cs.num_permutation_sets())]}
+    torch.cuda.synchronize()
+    rng = np.random.default_rng(19)
+    call = evalh_host.EvalhCall(cs)
+    ptr = lambda t: t.data_ptr()
+    call.fixed, call.advice, call.instance = [ptr(t) for t in T["fixed"]], [ptr(t) for t in T["advice"]], [ptr(t) for t in T["instance"]]
+    call.challenges = rand_fr(rng, cs.num_challenges)
+    call.y, call.beta, call.gamma, call.theta = (rand_fr(rng, 1)[0] for _ in range(4))
+    call.l0, call.l_last, call.l_active = (ptr(t) for t in T["l"])
+    call.lookups = [tuple(ptr(t) for t in tri) for tri in T["lookups"]]
+    call.perm_sigma, call.perm_z = [ptr(t) for t in T["sigma"]], [ptr(t) for t in T["perm_z"]]
+    out = torch.empty((en, 4), dtype=torch.int64, device="cuda")
+    d.evaluate_h(call.build(ffi.MEM_DEVICE, ffi.FORM_EXTENDED), out.data_ptr())
+    torch.cuda.synchronize()
+
+    D = _DeviceColumn
+    one = lambda limbs: fr_ints(np.asarray(limbs)[None])[0]
+    inp = hm.EvalInputs([D(t) for t in T["fixed"]], [D(t) for t in T["advice"]], [D(t) for t in T["instance"]],
+                        fr_ints(call.challenges), one(call.beta), one(call.gamma), one(call.theta), one(call.y))
+    ev = call.ev
+    desc = {"gates": ev.custom_gates.to_model(), "l0": D(T["l"][0]), "l_last": D(T["l"][1]), "l_active": D(T["l"][2]),
+            "lookups": [{"program": g.to_model(), "product": D(z), "permuted_input": D(a), "permuted_table": D(s)}
+                        for g, (z, a, s) in zip(ev.lookups, T["lookups"])],
+            "perm": {"columns": cs.permutation_columns, "sigma": [D(t) for t in T["sigma"]], "z": [D(t) for t in T["perm_z"]],
+                     "chunk_len": cs.permutation_chunk_len(), "blinding_factors": cs.blinding_factors()}}
+    md = hm.EvaluationDomain(cs.degree(), k)
+    rows = [0, 1, 3, 4, 7, en - 1, en - 2, en - 5, en - 8, en // 2, en // 2 + 1] + [int(r) for r in rng.integers(0, en, size=9)]
+    got = _DeviceColumn(out)
+    for r in rows:
+        assert got[r] == hm.evaluate_h_row(md, inp, desc, r), r
+    d.close()
