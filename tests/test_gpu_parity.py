@@ -1133,15 +1133,20 @@ class _DeviceColumn:
         return v
 
 
-def test_evaluate_h_full_size_sampled_rows(ctx):
-    """k = 19, extended domain 2^21, the benchmark's constraint system (64 advice, 16 fixed, 256 gate polynomials,
-    16 lookups, 8 permutation columns), all 143 columns resident on the device: rows sampled over the whole domain
-    (first, last, wrap-around neighbours of the rotations) against the big-int model evaluated on those rows only"""
+@pytest.mark.parametrize("kw", [
+    dict(num_advice=64, num_fixed=16, num_instance=1, num_gate_polys=256, max_degree=5, rotations=(-2, -1, 0, 1),
+         num_lookups=16, lookup_width=3, num_perm_cols=8),
+    dict(num_advice=40, num_fixed=8, num_instance=1, num_gate_polys=300, max_degree=9, rotations=(-5, -1, 0, 1, 3),
+         num_lookups=4, lookup_width=4, num_perm_cols=11),
+], ids=["bench-config-2^21", "degree-9-2^22"])
+def test_evaluate_h_full_size_sampled_rows(ctx, kw):
+    """k = 19 with all columns resident on the device -- the benchmark's constraint system (extended domain 2^21, 143
+    columns) and a degree-9 one (extended domain 2^22, as the SuperCircuit): rows sampled over the whole domain (first,
+    last, wrap-around neighbours of the rotations, random) against the big-int model evaluated on those rows only"""
     import torch
     import halo2_model as hm
     k = 19
-    cs = synthetic.synthetic_cs(num_advice=64, num_fixed=16, num_instance=1, num_gate_polys=256, max_degree=5,
-                                rotations=(-2, -1, 0, 1), num_lookups=16, lookup_width=3, num_perm_cols=8)
+    cs = synthetic.synthetic_cs(**kw)
     d = zk.Domain(ctx, cs.degree(), k)
     en = d.extended_len
     gen = torch.Generator(device="cuda")
@@ -1180,7 +1185,8 @@ def test_evaluate_h_full_size_sampled_rows(ctx):
             "perm": {"columns": cs.permutation_columns, "sigma": [D(t) for t in T["sigma"]], "z": [D(t) for t in T["perm_z"]],
                      "chunk_len": cs.permutation_chunk_len(), "blinding_factors": cs.blinding_factors()}}
     md = hm.EvaluationDomain(cs.degree(), k)
-    rows = [0, 1, 3, 4, 7, en - 1, en - 2, en - 5, en - 8, en // 2, en // 2 + 1] + [int(r) for r in rng.integers(0, en, size=9)]
+    rows = [0, 1, 3, 4, 7, 8, 39, en - 1, en - 2, en - 5, en - 8, en - 24, en // 2, en // 2 + 1]
+    rows += [int(r) for r in rng.integers(0, en, size=8)]
     got = _DeviceColumn(out)
     for r in rows:
         assert got[r] == hm.evaluate_h_row(md, inp, desc, r), r
