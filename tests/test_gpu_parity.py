@@ -1191,3 +1191,43 @@ def test_evaluate_h_full_size_sampled_rows(ctx, kw):
     for r in rows:
         assert got[r] == hm.evaluate_h_row(md, inp, desc, r), r
     d.close()
+
+
+def test_shplonk_full_size_identity(ctx, co):
+    """k = 19: after create_proof, h(X) and the final quotient q(X) satisfy, at a random r,
+         q(r) (r - u) z_0 = sum_i v^i z_i sum_j y^j (P_ij(r) - R_ij(u)) - Z_T(u) h(r)
+    with every polynomial evaluated on the device and the few low-degree pieces recomputed here; h itself is pinned by
+    the prover's own check that the right-hand side vanishes at u"""
+    from zkevm_circuits_amd import shplonk
+    k = 19
+    n = 1 << k
+    rng = np.random.default_rng(1919)
+    md_omega = pow(bn.FR_ROOT_OF_UNITY, 1 << (bn.FR_S - k), P)
+    x = int(rng.integers(2, 2 ** 62))
+    shape = [(0,), (0, 1), (0, 1), (0, -1), (0, 1, -1)]
+    d_polys = {key: ctx.upload(rand_fr(rng, n)) for key in range(len(shape))}
+    pts = {r: x * pow(md_omega, r % n, P) % P for r in (-1, 0, 1)}
+    flat = [(key, r) for r_i in range(3) for key, rots in enumerate(shape) if r_i < len(rots) for r in [rots[r_i]]]
+    vals = ctx.eval_polynomials_dev([d_polys[key] for key, _ in flat], fr_arr([pts[r] for _, r in flat]), n)
+    queries = [shplonk.Query(key, pts[r], v) for (key, r), v in zip(flat, fr_ints(vals))]
+    y, v, u, r = (int(c) for c in rng.integers(2, 2 ** 62, size=4))
+    bid = ctx.register_bases(ctx.g1_multiples(n))
+    tr = _ReplayTranscript([y, v, u])
+    d_h, d_q = shplonk.ProverSHPLONK(ctx, bid, n).create_proof(d_polys, queries, tr)
+    at = lambda d_p: fr_ints(ctx.eval_polynomial_dev(d_p, n, fr_arr([r])[0])[None])[0]
+    sets, sup = shplonk.construct_intermediate_sets(queries)
+    rhs, z0 = 0, None
+    for i, (points, cs_) in enumerate(sets):
+        z_i = shplonk.evaluate_vanishing_polynomial([p_ for p_ in sup if p_ not in points], u)
+        z0 = z_i if z0 is None else z0
+        inner = 0
+        for j, (key, evals) in enumerate(cs_):
+            low = shplonk.lagrange_interpolate(points, evals)
+            inner = (inner + pow(y, j, P) * (at(d_polys[key]) - shplonk.eval_small(low, u))) % P
+        rhs = (rhs + pow(v, i, P) * z_i % P * inner) % P
+    rhs = (rhs - shplonk.evaluate_vanishing_polynomial(sup, u) * at(d_h)) % P
+    assert at(d_q) * (r - u) % P * z0 % P == rhs
+    assert len(tr.points) == 2 and len(sets) == 4
+    for p_ in list(d_polys.values()) + [d_h, d_q]:
+        ctx.free(p_)
+    ctx.release_bases(bid)
