@@ -1,0 +1,106 @@
+"""CPU suite: the on-disk formats around the proving path (parameter file, polynomial records, proof JSON).
+
+The proof JSON and instance encoding are checked against literal bytes derived from the reference's own description of
+them (prover/src/proof.rs); the parameter / polynomial layouts are round-trip and byte-layout checks only (unpinned: the
+halo2 fork that defines them is not part of the reference tree)."""
+import base64
+import io
+import json
+import random
+import struct
+
+import numpy as np
+import pytest
+
+import bn254 as bn
+from zkevm_circuits_amd import formats
+
+P = bn.FR_MODULUS
+
+
+def _mont_rows(vals):
+    return np.array([[((v << 256) % P >> (64 * i)) & (2**64 - 1) for i in range(4)] for v in vals], dtype="<u8")
+
+
+def test_instances_big_endian_canonical():
+    rng = random.Random(5)
+    vals = [0, 1, P - 1, 0x0102030405060708090A0B0C0D0E0F10] + [rng.randrange(P) for _ in range(6)]
+    data = formats.serialize_instances([_mont_rows(vals)])
+    assert len(data) == 32 * len(vals)
+    # value 1 -> 31 zero bytes then 0x01; the fourth value ends ... 0f 10
+    assert data[32:64] == b"\x00" * 31 + b"\x01"
+    assert data[96:128][-2:] == b"\x0f\x10"
+    for i, v in enumerate(vals):
+        assert int.from_bytes(data[32 * i:32 * i + 32], "big") == v
+    back = formats.deserialize_instances(data)
+    assert len(back) == 1 and np.array_equal(back[0], _mont_rows(vals))
+    with pytest.raises(formats.FormatError):
+        formats.deserialize_instances(P.to_bytes(32, "big"))
+    with pytest.raises(formats.FormatError):
+        formats.deserialize_instances(b"\x00" * 33)
+    with pytest.raises(formats.FormatError):
+        formats.serialize_instances([_mont_rows([1]), _mont_rows([2])])
+
+
+def test_proof_json_fields(tmp_path):
+    inst = [_mont_rows([7, P - 2])]
+    proof = bytes(range(200))
+    path = formats.dump_proof_json(str(tmp_path), "super", proof, inst, vk=b"\x01\x02")
+    assert path.endswith("/full_proof_super.json")
+    doc = json.load(open(path))
+    assert sorted(doc) == ["instances", "proof", "vk"]
+    assert base64.b64decode(doc["proof"]) == proof
+    assert base64.b64decode(doc["instances"]) == (7).to_bytes(32, "big") + (P - 2).to_bytes(32, "big")
+    p2, i2, vk2 = formats.load_proof_json(str(tmp_path), "super")
+    assert p2 == proof and vk2 == b"\x01\x02" and np.array_equal(i2[0], inst[0])
+    with pytest.raises(formats.FormatError):
+        formats.load_proof_json(str(tmp_path), "absent")
+
+
+def test_params_raw_layout_and_round_trip(tmp_path):
+    k = 5
+    rng = np.random.default_rng(3)
+    g = rng.integers(0, 2**63, size=(1 << k, 8), dtype=np.uint64)
+    gl = rng.integers(0, 2**63, size=(1 << k, 8), dtype=np.uint64)
+    g2, s_g2 = bytes(range(128)), bytes(reversed(range(128)))
+    path = str(tmp_path / "k5.params")
+    formats.write_params_raw(path, formats.ParamsRaw(k, g, gl, g2, s_g2))
+    raw = open(path, "rb").read()
+    assert len(raw) == 4 + 2 * 32 * 64 + 256
+    assert raw[:4] == struct.pack("<I", k)
+    assert raw[4:12] == int(g[0, 0]).to_bytes(8, "little")                 # x limb 0 of g[0]
+    assert raw[4 + 32 * 64:][:8] == int(gl[0, 0]).to_bytes(8, "little")    # g_lagrange follows g
+    assert raw[-256:-128] == g2 and raw[-128:] == s_g2
+    p = formats.read_params_raw(path)
+    assert p.k == k and p.n == 32 and p.nbytes() == len(raw)
+    assert np.array_equal(p.g, g) and np.array_equal(p.g_lagrange, gl) and p.g2 == g2 and p.s_g2 == s_g2
+    open(path, "ab").write(b"\x00")
+    with pytest.raises(formats.FormatError):
+        formats.read_params_raw(path)
+    with pytest.raises(formats.FormatError):
+        formats.ParamsRaw(k, g[:3], gl, g2, s_g2)
+
+
+def test_polynomial_raw_records():
+    rng = random.Random(9)
+    a = _mont_rows([rng.randrange(P) for _ in range(17)])
+    b = _mont_rows([])
+    f = io.BytesIO()
+    formats.write_polynomial_raw(f, a)
+    formats.write_polynomial_raw(f, b)
+    raw = f.getvalue()
+    assert raw[:4] == struct.pack(">I", 17) and len(raw) == 4 + 17 * 32 + 4
+    assert raw[4:36] == a[0].tobytes()
+    f.seek(0)
+    assert np.array_equal(formats.read_polynomial_raw(f), a)
+    assert formats.read_polynomial_raw(f).shape == (0, 4)
+    with pytest.raises(formats.FormatError):
+        formats.read_polynomial_raw(f)                         # end of file
+    with pytest.raises(formats.FormatError):
+        formats.read_polynomial_raw(io.BytesIO(struct.pack(">I", 2) + b"\x00" * 32))
+    bad = np.array([[(P >> (64 * i)) & (2**64 - 1) for i in range(4)]], dtype="<u8")   # the modulus itself
+    g = io.BytesIO()
+    formats.write_polynomial_raw(g, bad)
+    g.seek(0)
+    with pytest.raises(formats.FormatError):
+        formats.read_polynomial_raw(g)

@@ -1116,6 +1116,30 @@ def test_g_to_lagrange_commits_like_the_monomial_basis(ctx, co, k):
     d.close()
 
 
+def test_params_file_tables_commit_unchanged(ctx, co, tmp_path):
+    """g and g_lagrange written as a raw-bytes parameter file and read back memory-mapped are the bases as they were:
+    commitments from the file's tables equal those from the arrays in memory (no conversion pass between file and device)"""
+    from zkevm_circuits_amd import formats, keygen
+    k = 10
+    n = 1 << k
+    d = zk.Domain(ctx, 3, k)
+    g = co.g1_bases(n)
+    g_lagrange = keygen.g_to_lagrange(ctx, d, g)
+    path = str(tmp_path / "k10.params")
+    formats.write_params_raw(path, formats.ParamsRaw(k, g, g_lagrange, bytes(128), bytes(128)))
+    p = formats.read_params_raw(path)
+    assert p.k == k and np.array_equal(p.g, g) and np.array_equal(p.g_lagrange, g_lagrange)
+    rng = np.random.default_rng(4)
+    values = rand_fr(rng, n)
+    b_file, b_mem = ctx.register_bases(p.g_lagrange), ctx.register_bases(g_lagrange)
+    got = ctx.g1_to_affine(ctx.msm(b_file, values))
+    assert np.array_equal(got, ctx.g1_to_affine(ctx.msm(b_mem, values)))
+    assert np.array_equal(got, co.g1_to_affine(co.best_multiexp(values, g_lagrange, threads=8)))
+    ctx.release_bases(b_file)
+    ctx.release_bases(b_mem)
+    d.close()
+
+
 # ------------------------------------------------------------------------------------------------ evaluate_h at full size
 class _DeviceColumn:
     """Lazy view of a device-resident column for the big-int model: rows are fetched one by one on first use."""

@@ -808,6 +808,34 @@ extern "C" int zkhip_evaluate_h(zkhip_domain* dom, const zkhip_evalh_desc* desc,
     const char* env_slots = getenv("ZKHIP_EVALH_LDS_SLOTS");
     const uint32_t lds_budget = env_slots && *env_slots ? (uint32_t)atoi(env_slots) : 5;
     uint32_t result = W_ACC, lds_slots = 1, n_slots = 1;
+    if (getenv("ZKHIP_DEBUG")) {
+        // how many instructions add or subtract a value that a plain multiplication produced for them alone: each such
+        // pair is a sum of two products and could share one Montgomery reduction
+        const size_t ni = b.words.size() / 4;
+        std::vector<uint32_t> reads(b.n_virtual, 0), writes(b.n_virtual, 0), pure_mul(b.n_virtual, 0);
+        for (size_t pc = 0; pc < ni; pc++) {
+            for (int q = 1; q <= 3; q++)
+                if ((b.words[4 * pc + q] >> 28) == K_SLOT) reads[b.words[4 * pc + q] & 0x0fffffffu]++;
+            const uint32_t dst = b.words[4 * pc] >> 8;
+            if (dst != DST_ACC) {
+                writes[dst]++;
+                pure_mul[dst] = (b.words[4 * pc] & 0x3f) == F_MUL;
+            }
+        }
+        size_t with_mul = 0, without_mul = 0;
+        for (size_t pc = 0; pc < ni; pc++) {
+            const uint32_t w0 = b.words[4 * pc];
+            if (!(w0 & (F_ADD | F_SUB))) continue;
+            auto lone_product = [&](uint32_t w) {
+                const uint32_t v = w & 0x0fffffffu;
+                return (w >> 28) == K_SLOT && reads[v] == 1 && writes[v] == 1 && pure_mul[v];
+            };
+            if (w0 & F_MUL) with_mul += lone_product(b.words[4 * pc + 3]);
+            else without_mul += lone_product(b.words[4 * pc + 3]) || lone_product(b.words[4 * pc + 1]);
+        }
+        fprintf(stderr, "[zkhip] evaluate_h program: %zu of %zu instructions are a*b +- (c*d) with c*d used once, %zu more are "
+                        "x +- (c*d)\n", with_mul, ni, without_mul);
+    }
     assign_slots(b.words, result, b.n_virtual, lds_budget, lds_slots, n_slots);
     {
         size_t nmul = 0, ncol = 0;
