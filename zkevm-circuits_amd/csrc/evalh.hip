@@ -15,11 +15,13 @@
 //   * arithmetic runs in the lazy signed-digit form of wide.cuh (nine 29-bit digits, Montgomery radix 2^261): a
 //     multiply-add is one Montgomery product, nine digit additions and a carry pass, with no comparison against p;
 //     the host bounds every value's magnitude while it builds the program and the kernel canonicalises the result.
-// Every instruction is r = (a * b | a) (+ c | - c | nothing): the interpreter holds one multiplier instance.  The
-// program is wave-uniform: its words arrive by scalar loads with column pointers and row offsets already resolved,
-// every branch is a scalar branch, and the column / constant reads of instruction pc + 1 are issued before
-// instruction pc computes.  Column reads are (row + rotation * 2^(ext_k - k)) mod 2^ext_k, i.e. 32 contiguous bytes
-// per lane.
+// Every instruction is r = (a * b | a) (+ c | - c | nothing), r = c - a * b, or r = a * b +- c * d where both products
+// share one Montgomery reduction; a peephole pass over the finished program moves a product that feeds a single
+// addition or subtraction into its consumer.  The program is wave-uniform: its words arrive by scalar loads with
+// column pointers and row offsets already resolved, every branch is a scalar branch, and the column / constant reads
+// of instruction pc + 1 are issued as soon as instruction pc has computed; the four waves per SIMD hide their latency
+// (holding a second set of staged operands across the products costs a wave per SIMD and more than it gains).
+// Column reads are (row + rotation * 2^(ext_k - k)) mod 2^ext_k, i.e. 32 contiguous bytes per lane.
 // Results equal upstream's bit for bit: field arithmetic is exact, only the order of independent operations differs.
 #include <algorithm>
 #include <cstdlib>
@@ -34,25 +36,31 @@ namespace zkhip {
 constexpr int EV_THREADS = 256;
 
 // instruction word 0: bit 0 = multiply a * b, bit 1 = add c, bit 2 = subtract c, bit 3 = carry-normalise the result,
-// bits 4 / 5 = carry-normalise operand a / b after fetching it, bits 8.. = destination
-constexpr uint32_t F_MUL = 1, F_ADD = 2, F_SUB = 4, F_NORM = 8, F_NORM_A = 16, F_NORM_B = 32;
+// bits 4 / 5 = carry-normalise operand a / b after fetching it, bit 6 = reverse subtraction (c - a * b),
+// bit 7 = second product: a * b +- c * d under one Montgomery reduction, bits 8 / 9 = carry-normalise operand c / d
+// of a second product, bits 12.. = destination
+constexpr uint32_t F_MUL = 1, F_ADD = 2, F_SUB = 4, F_NORM = 8, F_NORM_A = 16, F_NORM_B = 32, F_RSUB = 64, F_MUL2 = 128,
+                   F_NORM_C = 256, F_NORM_D = 512;
+constexpr uint32_t F_OPS = F_MUL | F_ADD | F_SUB | F_RSUB | F_MUL2;
+constexpr uint32_t F_NORMS = F_NORM | F_NORM_A | F_NORM_B | F_NORM_C | F_NORM_D;
+constexpr uint32_t DST_SHIFT = 12;
 enum DevKind : uint32_t { K_CONST = 0, K_SLOT, K_COL, K_SCALAR, K_ACC, K_ZERO };
-constexpr uint32_t DST_ACC = 0xffffffu;
+constexpr uint32_t DST_ACC = 0xfffffu;         // in a linked instruction
+constexpr uint32_t DST_ACC_V = 0xffffffffu;    // in the program under construction (virtual destinations)
 constexpr uint32_t W_ZERO = K_ZERO << 28, W_ACC = K_ACC << 28;
 
 // scalar table layout
 constexpr uint32_t SC_BETA = 0, SC_GAMMA = 1, SC_THETA = 2, SC_Y = 3, SC_ONE = 4, SC_CHALLENGE0 = 5;
 
-// Linked program: 12 words per instruction,
-//   [0] flags | dst << 8, then for each operand a, b, c: header = kind << 28 | payload, pointer low, pointer high.
+// Linked program: 16 words per instruction (13 used),
+//   [0] flags | dst << 12, then for each operand a, b, c, d: header = kind << 28 | payload, pointer low, pointer high.
 //   L_ROW : pointer = column base, payload = signed row offset of the rotation (28 bits)
 //   L_UNI : pointer = one field element read by every lane (constant / scalar)
 //   L_SLOT: payload = value slot;  L_ACC: the running value;  L_ZERO
 // The words are read through the constant address space, i.e. by scalar loads: decode never touches the vector
 // memory path and needs no table lookups.
 enum LinkKind : uint32_t { L_ZERO = 0, L_ROW, L_UNI, L_SLOT, L_ACC };
-constexpr uint32_t INS_WORDS = 12;
-constexpr int EV_DEPTH = 2;
+constexpr uint32_t INS_WORDS = 16;
 typedef const uint32_t __attribute__((address_space(4))) * prog_ptr;
 
 struct Opnd {
@@ -74,15 +82,20 @@ __device__ __forceinline__ Opnd ev_operand(prog_ptr w) {
     o.ptr = reinterpret_cast<const fe*>(((uint64_t)w[2] << 32) | w[1]);
     return o;
 }
-// issues the memory read of a column / constant operand (other kinds read nothing)
+// Issues the memory read of a column / constant operand, through the global address space (a pointer rebuilt from
+// program words would otherwise be read with flat loads, which also count against the LDS / scalar-load waits).
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef const u32x4 __attribute__((address_space(1))) * global_u4;
 __device__ __forceinline__ fe ev_raw(const Opnd& o, uint32_t idx, uint32_t mask) {
     const uint32_t kind = o.hdr >> 28;
-    if (kind == L_ROW) {
-        const int32_t delta = (int32_t)(o.hdr << 4) >> 4;
-        return load_fe(o.ptr + ((uint32_t)((int32_t)idx + delta) & mask));
-    }
-    if (kind == L_UNI) return load_fe(o.ptr);
-    return Fr::zero();
+    const int32_t delta = (int32_t)(o.hdr << 4) >> 4;
+    const uint32_t row = kind == L_ROW ? ((uint32_t)((int32_t)idx + delta) & mask) : 0u;
+    const global_u4 q = (global_u4)(uintptr_t)(o.ptr + row);
+    const u32x4 a = q[0], b = q[1];
+    fe v;
+    v.l[0] = a.x; v.l[1] = a.y; v.l[2] = a.z; v.l[3] = a.w;
+    v.l[4] = b.x; v.l[5] = b.y; v.l[6] = b.z; v.l[7] = b.w;
+    return v;
 }
 // Values are held in the lazy signed-digit form of wide.cuh, 2^261 Montgomery domain, always normalised.  Columns
 // enter through from_fe_shl5 (value up to 32 p); the host tracks magnitudes and keeps every stored value below EV_LIMIT p.
@@ -111,35 +124,63 @@ __device__ __forceinline__ fw ev_value(const InterpArgs& a, const Opnd& o, const
     }
 }
 
-// decoded instruction plus the raw memory operands whose loads are already in flight
+// decoded instruction plus its raw memory operands, loads in flight
+// An instruction reads at most three operands from memory: with a second product (F_MUL2) operand a is a value slot or
+// the running value, and the staging register `rad` holds d's memory operand instead of a's.
 struct Staged {
     uint32_t w0;
-    Opnd a, b, c;
-    fe ra, rb, rc;
+    Opnd a, b, c, d;
+    fe rad, rb, rc;
 };
 __device__ __forceinline__ void ev_stage(Staged& s, prog_ptr w, uint32_t idx, uint32_t mask) {
     s.w0 = w[0];
     s.a = ev_operand(w + 1);
     s.b = ev_operand(w + 4);
     s.c = ev_operand(w + 7);
-    const uint32_t ka = s.a.hdr >> 28, kb = s.b.hdr >> 28, kc = s.c.hdr >> 28;
-    if (ka == L_ROW || ka == L_UNI) s.ra = ev_raw(s.a, idx, mask);
+    s.d = ev_operand(w + 10);
+    const Opnd& ad = (s.w0 & F_MUL2) ? s.d : s.a;
+    const uint32_t kad = ad.hdr >> 28, kb = s.b.hdr >> 28, kc = s.c.hdr >> 28;
+    if (kad == L_ROW || kad == L_UNI) s.rad = ev_raw(ad, idx, mask);
     if (kb == L_ROW || kb == L_UNI) s.rb = ev_raw(s.b, idx, mask);
     if (kc == L_ROW || kc == L_UNI) s.rc = ev_raw(s.c, idx, mask);
 }
 __device__ __forceinline__ void ev_execute(const InterpArgs& a, const Staged& s, int32_t* lds, fw& acc, fw& reg0, uint32_t idx) {
-    const uint32_t w0 = s.w0, dst = w0 >> 8;
-    fw t = ev_value(a, s.a, s.ra, lds, acc, reg0, idx);
-    if (w0 & F_NORM_A) t = FrW::norm(t);
-    if (w0 & F_MUL) {
+    const uint32_t w0 = s.w0, dst = w0 >> DST_SHIFT;
+    fw t;
+    if (w0 & F_MUL2) {
+        // a b +- c d: both products land in the same 64-bit columns and one reduction retires them.  c d goes first: it
+        // consumes two of the staged memory operands before a (a slot or the running value, never memory) and b are touched
+        int64_t col[18];
+#pragma unroll
+        for (int k = 0; k < 18; k++) col[k] = 0;
+        {
+            fw c = ev_value(a, s.c, s.rc, lds, acc, reg0, idx);
+            if (w0 & F_NORM_C) c = FrW::norm(c);
+            fw d = ev_value(a, s.d, s.rad, lds, acc, reg0, idx);
+            if (w0 & F_NORM_D) d = FrW::norm(d);
+            FrW::mac(col, FrW::cneg(c, (w0 & F_SUB) != 0), d);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        t = ev_value(a, s.a, Fr::zero(), lds, acc, reg0, idx);
+        if (w0 & F_NORM_A) t = FrW::norm(t);
         fw u = ev_value(a, s.b, s.rb, lds, acc, reg0, idx);
         if (w0 & F_NORM_B) u = FrW::norm(u);
-        t = FrW::mul(t, u);
-    }
-    if (w0 & (F_ADD | F_SUB)) {
-        const fw c = ev_value(a, s.c, s.rc, lds, acc, reg0, idx);
-        t = (w0 & F_ADD) ? FrW::add(t, c) : FrW::sub(t, c);
-        if (w0 & F_NORM) t = FrW::norm(t);
+        FrW::mac(col, t, u);
+        t = FrW::reduce(col);
+    } else {
+        t = ev_value(a, s.a, s.rad, lds, acc, reg0, idx);
+        if (w0 & F_NORM_A) t = FrW::norm(t);
+        if (w0 & F_MUL) {
+            fw u = ev_value(a, s.b, s.rb, lds, acc, reg0, idx);
+            if (w0 & F_NORM_B) u = FrW::norm(u);
+            t = FrW::mul(t, u);
+        }
+        if (w0 & (F_ADD | F_SUB | F_RSUB)) {
+            const fw c = ev_value(a, s.c, s.rc, lds, acc, reg0, idx);
+            t = (w0 & F_ADD) ? FrW::add(t, c) : FrW::sub(t, c);
+            if (w0 & F_RSUB) t = FrW::neg(t);
+            if (w0 & F_NORM) t = FrW::norm(t);
+        }
     }
     if (dst == DST_ACC) {
         acc = t;
@@ -163,19 +204,12 @@ __global__ void __launch_bounds__(EV_THREADS) evalh_interp_kernel(const uint32_t
     const uint32_t mask = (1u << a.log_size) - 1;
     if (idx > mask) return;   // domains smaller than one workgroup
     fw acc = FrW::zero(), reg0 = FrW::zero();
-    // software pipeline over EV_DEPTH staging sets: while instruction pc computes, instructions pc + 1 .. pc + EV_DEPTH - 1
-    // are already decoded and their column / constant loads are in flight
-    Staged st[EV_DEPTH];
-#pragma unroll
-    for (int j = 0; j < EV_DEPTH - 1; j++)
-        if ((uint32_t)j < a.n_instr) ev_stage(st[j], prog + (size_t)j * INS_WORDS, idx, mask);
-    for (uint32_t pc = 0; pc < a.n_instr; pc += EV_DEPTH) {
-#pragma unroll
-        for (int j = 0; j < EV_DEPTH; j++) {
-            const uint32_t cur = pc + j, ahead = cur + EV_DEPTH - 1;
-            if (ahead < a.n_instr) ev_stage(st[(j + EV_DEPTH - 1) % EV_DEPTH], prog + (size_t)ahead * INS_WORDS, idx, mask);
-            if (cur < a.n_instr) ev_execute(a, st[j], lds, acc, reg0, idx);
-        }
+    // instruction pc + 1 is decoded and its column / constant loads are issued right after instruction pc has computed
+    Staged st;
+    if (a.n_instr) ev_stage(st, prog, idx, mask);
+    for (uint32_t pc = 0; pc < a.n_instr; pc++) {
+        ev_execute(a, st, lds, acc, reg0, idx);
+        if (pc + 1 < a.n_instr) ev_stage(st, prog + (size_t)(pc + 1) * INS_WORDS, idx, mask);
     }
     // back to the 2^256 domain, canonical
     Opnd ro;
@@ -251,8 +285,9 @@ static bool parse_graph(const zkhip_graph* g, std::vector<Calc>& out, std::strin
     return true;
 }
 
-// The fused program under construction: instruction words with virtual destination ids, the merged constant and
-// rotation tables.
+// The fused program under construction: six words per instruction (flags, virtual destination, operands a b c d), the
+// merged constant and rotation tables.
+constexpr size_t IW = 6;
 struct Builder {
     std::vector<uint32_t> words;
     std::vector<uint64_t> consts;      // 4 limbs each
@@ -306,41 +341,168 @@ struct Builder {
             default: return {0.0, 0.0};
         }
     }
-    void emit(uint32_t flags, uint32_t dst, uint32_t a, uint32_t b = W_ZERO, uint32_t c = W_ZERO) {
+    // Magnitude bookkeeping of one instruction: sets the carry-normalisation flags it needs, records the bounds of its
+    // result and returns the flags; `v_out` is the value bound of the result.
+    uint32_t track(uint32_t flags, uint32_t dst, uint32_t a, uint32_t b, uint32_t c, uint32_t d, double& v_out) {
+        flags &= ~F_NORMS;
         double v = bound(a);
         Digits t = digits(a);
-        if (flags & F_MUL) {
-            v = v * bound(b) / EV_CONTRACT + 1.0;
-            Digits u = digits(b);
-            if (t.mag() * u.mag() > 2.0 && t.mag() > 1.0) {
-                flags |= F_NORM_A;
-                t = {0.0, 1.0};
+        if (flags & F_MUL2) {
+            // both products share the columns: |a_i| |b_j| + |c_i| |d_j| <= 2 * 2^58; widest operand first
+            double m[4] = {t.mag(), digits(b).mag(), digits(c).mag(), digits(d).mag()};
+            const uint32_t nf[4] = {F_NORM_A, F_NORM_B, F_NORM_C, F_NORM_D};
+            while (m[0] * m[1] + m[2] * m[3] > 2.0) {
+                int w = 0;
+                for (int q = 1; q < 4; q++)
+                    if (m[q] > m[w]) w = q;
+                if (m[w] <= 1.0) break;   // all normalised: 1 + 1
+                flags |= nf[w];
+                m[w] = 1.0;
             }
-            if (t.mag() * u.mag() > 2.0) flags |= F_NORM_B;
+            v = (v * bound(b) + bound(c) * bound(d)) / EV_CONTRACT + 1.0;
             t = {0.0, 1.0};
-        }
-        if (flags & (F_ADD | F_SUB)) {
-            v += bound(c);
-            const Digits w = digits(c);
-            if (!(flags & F_MUL) && t.mag() + w.mag() > 3.5) {   // int32 headroom of the digit sums
-                flags |= F_NORM_A;
+        } else {
+            if (flags & F_MUL) {
+                v = v * bound(b) / EV_CONTRACT + 1.0;
+                Digits u = digits(b);
+                if (t.mag() * u.mag() > 2.0 && t.mag() > 1.0) {
+                    flags |= F_NORM_A;
+                    t = {0.0, 1.0};
+                }
+                if (t.mag() * u.mag() > 2.0) flags |= F_NORM_B;
                 t = {0.0, 1.0};
             }
-            if (flags & F_ADD) t = {t.lo + w.lo, t.hi + w.hi};
-            else t = {t.lo - w.hi, t.hi - w.lo};
-            if (t.mag() > 2.0) {
-                flags |= F_NORM;
-                t = {0.0, 1.0};
+            if (flags & (F_ADD | F_SUB | F_RSUB)) {
+                v += bound(c);
+                const Digits w = digits(c);
+                if (!(flags & F_MUL) && t.mag() + w.mag() > 3.5) {   // int32 headroom of the digit sums
+                    flags |= F_NORM_A;
+                    t = {0.0, 1.0};
+                }
+                if (flags & F_ADD) t = {t.lo + w.lo, t.hi + w.hi};
+                else if (flags & F_SUB) t = {t.lo - w.hi, t.hi - w.lo};
+                else t = {w.lo - t.hi, w.hi - t.lo};
+                if (t.mag() > 2.0) {
+                    flags |= F_NORM;
+                    t = {0.0, 1.0};
+                }
             }
         }
-        words.push_back(flags | (dst << 8));
-        words.push_back(a);
-        words.push_back(b);
-        words.push_back(c);
-        (dst == DST_ACC ? acc_bound : vbound[dst]) = v;
-        (dst == DST_ACC ? acc_dig : vdig[dst]) = t;
+        (dst == DST_ACC_V ? acc_bound : vbound[dst]) = v;
+        (dst == DST_ACC_V ? acc_dig : vdig[dst]) = t;
+        v_out = v;
+        return flags;
+    }
+    void emit(uint32_t flags, uint32_t dst, uint32_t a, uint32_t b = W_ZERO, uint32_t c = W_ZERO) {
+        double v;
+        flags = track(flags, dst, a, b, c, W_ZERO, v);
+        const uint32_t ins[IW] = {flags, dst, a, b, c, W_ZERO};
+        words.insert(words.end(), ins, ins + IW);
         // renormalise the value through a multiplication by one
-        if (v > EV_LIMIT) emit(F_MUL, dst, dst == DST_ACC ? W_ACC : slot(dst), scalar(SC_ONE));
+        if (v > EV_LIMIT) emit(F_MUL, dst, dst == DST_ACC_V ? W_ACC : slot(dst), scalar(SC_ONE));
+    }
+
+    // Peephole pass over the finished program.  A value that one plain multiplication p * q produces for a single
+    // consumer, itself an addition or subtraction, moves into the consumer:
+    //     x + p q, p q +- x  ->  one multiply-add;      x - p q  ->  reverse multiply-subtract;
+    //     a b +- p q         ->  a second product in the same instruction, retired by the one Montgomery reduction.
+    // The operands of the moved product must not change in between (values written once; never the running value).
+    // Bounds are then recomputed from scratch: a fused result is never larger than what it replaces.
+    struct FuseStats { size_t two_products = 0, multiply_adds = 0; };
+    bool fuse_products(uint32_t result, FuseStats& fs) {
+        const size_t ni = words.size() / IW;
+        std::vector<uint32_t> reads(n_virtual, 0), writes(n_virtual, 0), def(n_virtual, 0);
+        for (size_t pc = 0; pc < ni; pc++) {
+            const uint32_t* w = &words[pc * IW];
+            for (int q = 2; q < 6; q++)
+                if ((w[q] >> 28) == K_SLOT) reads[w[q] & 0x0fffffffu]++;
+            if (w[1] != DST_ACC_V) {
+                writes[w[1]]++;
+                def[w[1]] = (uint32_t)pc;
+            }
+        }
+        if ((result >> 28) == K_SLOT) reads[result & 0x0fffffffu]++;
+        std::vector<uint8_t> dead(ni, 0);
+        auto lone_product = [&](uint32_t opnd, size_t pc, size_t& src) {
+            if ((opnd >> 28) != K_SLOT) return false;
+            const uint32_t v = opnd & 0x0fffffffu;
+            if (reads[v] != 1 || writes[v] != 1) return false;
+            src = def[v];
+            if (src >= pc || dead[src]) return false;
+            const uint32_t* p = &words[src * IW];
+            if ((p[0] & F_OPS) != F_MUL) return false;
+            for (int q = 2; q < 4; q++) {
+                const uint32_t kind = p[q] >> 28;
+                if (kind == K_ACC) return false;
+                if (kind == K_SLOT && writes[p[q] & 0x0fffffffu] != 1) return false;
+            }
+            return true;
+        };
+        for (size_t pc = 0; pc < ni; pc++) {
+            uint32_t* w = &words[pc * IW];
+            size_t src;
+            if (!(w[0] & (F_ADD | F_SUB)) || (w[0] & (F_RSUB | F_MUL2))) continue;
+            if (!(w[0] & F_MUL)) {
+                if (lone_product(w[2], pc, src)) {             // p q +- c
+                    w[0] = (w[0] & (F_ADD | F_SUB)) | F_MUL;
+                    w[2] = words[src * IW + 2];
+                    w[3] = words[src * IW + 3];
+                } else if (lone_product(w[4], pc, src)) {      // x +- p q
+                    const uint32_t x = w[2];
+                    w[0] = F_MUL | ((w[0] & F_ADD) ? F_ADD : F_RSUB);
+                    w[2] = words[src * IW + 2];
+                    w[3] = words[src * IW + 3];
+                    w[4] = x;
+                } else {
+                    continue;
+                }
+                dead[src] = 1;
+                fs.multiply_adds++;
+                if (w[0] & F_RSUB) continue;
+            }
+            if (lone_product(w[4], pc, src)) {                 // a b +- p q
+                // the interpreter stages three memory operands: a must be a value slot or the running value
+                auto in_memory = [](uint32_t o) { const uint32_t k = o >> 28; return k == K_COL || k == K_CONST || k == K_SCALAR; };
+                uint32_t p = words[src * IW + 2], q = words[src * IW + 3];
+                if (in_memory(w[2]) && !in_memory(w[3])) std::swap(w[2], w[3]);
+                if (in_memory(w[2]) && (w[0] & F_ADD) && !(in_memory(p) && in_memory(q))) {   // p q + a b
+                    if (in_memory(p)) std::swap(p, q);
+                    std::swap(w[2], p);
+                    std::swap(w[3], q);
+                }
+                if (in_memory(w[2])) continue;
+                w[0] |= F_MUL2;
+                w[4] = p;
+                w[5] = q;
+                dead[src] = 1;
+                fs.two_products++;
+            }
+        }
+        // drop the moved multiplications, then redo the magnitude bookkeeping over what is left
+        size_t keep = 0;
+        for (size_t pc = 0; pc < ni; pc++) {
+            if (dead[pc]) continue;
+            if (keep != pc) std::copy(&words[pc * IW], &words[pc * IW] + IW, &words[keep * IW]);
+            keep++;
+        }
+        words.resize(keep * IW);
+        std::fill(vbound.begin(), vbound.end(), 0.0);
+        std::fill(vdig.begin(), vdig.end(), Digits());
+        acc_bound = 0.0;
+        acc_dig = Digits();
+        for (size_t pc = 0; pc < keep; pc++) {
+            uint32_t* w = &words[pc * IW];
+            double v;
+            w[0] = track(w[0], w[1], w[2], w[3], w[4], w[5], v);
+            if (v > EV_LIMIT) {
+                // allowed only where the emitter already put its multiplication by one right behind
+                const uint32_t* nx = w + IW;
+                const uint32_t self = w[1] == DST_ACC_V ? W_ACC : slot(w[1]);
+                if (pc + 1 >= keep || (nx[0] & F_OPS) != F_MUL || nx[1] != w[1] || nx[2] != self || nx[3] != scalar(SC_ONE))
+                    return false;
+            }
+        }
+        return true;
     }
     // value-returning helpers (destination = fresh virtual value)
     uint32_t mul(uint32_t a, uint32_t b) { const uint32_t d = fresh(); emit(F_MUL, d, a, b); return slot(d); }
@@ -349,7 +511,7 @@ struct Builder {
     uint32_t mul_add(uint32_t a, uint32_t b, uint32_t c) { const uint32_t d = fresh(); emit(F_MUL | F_ADD, d, a, b, c); return slot(d); }
     uint32_t mul_sub(uint32_t a, uint32_t b, uint32_t c) { const uint32_t d = fresh(); emit(F_MUL | F_SUB, d, a, b, c); return slot(d); }
     // values[idx] = values[idx] * y + term
-    void fold(uint32_t term) { emit(F_MUL | F_ADD, DST_ACC, W_ACC, scalar(SC_Y), term); }
+    void fold(uint32_t term) { emit(F_MUL | F_ADD, DST_ACC_V, W_ACC, scalar(SC_Y), term); }
 };
 
 // Lowers one GraphEvaluator into the builder.  `is_gates`: the root Horner accumulates into the running value.
@@ -443,11 +605,11 @@ struct Lowering {
                     if (dep(c.start) || dep(c.factor)) { if (!err.empty()) return false; continue; }
                     uint32_t s;
                     if (!operand(c.start, s)) return false;
-                    c.acc_dst = to_acc ? DST_ACC : b.fresh();
+                    c.acc_dst = to_acc ? DST_ACC_V : b.fresh();
                     if (!(to_acc && s == W_ACC)) b.emit(0, c.acc_dst, s);   // the running value already holds previous_value
                     st.back().stage = 1;
                 }
-                const uint32_t accw = (c.acc_dst == DST_ACC) ? W_ACC : Builder::slot(c.acc_dst);
+                const uint32_t accw = (c.acc_dst == DST_ACC_V) ? W_ACC : Builder::slot(c.acc_dst);
                 bool pushed = false;
                 while (st.back().stage - 1 < c.parts.size()) {
                     const VS& p = c.parts[st.back().stage - 1];
@@ -485,7 +647,7 @@ struct Lowering {
 // Liveness-based slot assignment.  lds_budget: LDS slots one lane may use; the program gets min(peak, budget).
 static void assign_slots(std::vector<uint32_t>& words, uint32_t& result, uint32_t n_virtual, uint32_t lds_budget,
                          uint32_t& lds_slots_out, uint32_t& n_slots_out) {
-    const size_t ni = words.size() / 4;
+    const size_t ni = words.size() / IW;
     std::vector<uint32_t> first(n_virtual, UINT32_MAX), last(n_virtual, 0), uses(n_virtual, 0);
     auto touch = [&](uint32_t v, uint32_t pc) {
         if (first[v] == UINT32_MAX) first[v] = pc;
@@ -493,10 +655,10 @@ static void assign_slots(std::vector<uint32_t>& words, uint32_t& result, uint32_
         uses[v]++;
     };
     for (size_t pc = 0; pc < ni; pc++) {
-        const uint32_t dst = words[4 * pc] >> 8;
-        for (int k = 1; k <= 3; k++)
-            if ((words[4 * pc + k] >> 28) == K_SLOT) touch(words[4 * pc + k] & 0x0fffffffu, (uint32_t)pc);
-        if (dst != DST_ACC) touch(dst, (uint32_t)pc);
+        const uint32_t dst = words[IW * pc + 1];
+        for (size_t k = 2; k < IW; k++)
+            if ((words[IW * pc + k] >> 28) == K_SLOT) touch(words[IW * pc + k] & 0x0fffffffu, (uint32_t)pc);
+        if (dst != DST_ACC_V) touch(dst, (uint32_t)pc);
     }
     if ((result >> 28) == K_SLOT) touch(result & 0x0fffffffu, (uint32_t)ni);
     std::vector<uint32_t> order(n_virtual);
@@ -553,9 +715,9 @@ static void assign_slots(std::vector<uint32_t>& words, uint32_t& result, uint32_
         if ((w >> 28) == K_SLOT) w = (K_SLOT << 28) | phys[w & 0x0fffffffu];
     };
     for (size_t pc = 0; pc < ni; pc++) {
-        const uint32_t dst = words[4 * pc] >> 8;
-        if (dst != DST_ACC) words[4 * pc] = (words[4 * pc] & 0xff) | (phys[dst] << 8);
-        for (int k = 1; k <= 3; k++) remap(words[4 * pc + k]);
+        const uint32_t dst = words[IW * pc + 1];
+        if (dst != DST_ACC_V) words[IW * pc + 1] = phys[dst];
+        for (size_t k = 2; k < IW; k++) remap(words[IW * pc + k]);
     }
     remap(result);
     n_slots_out = lds_slots + next_sp;
@@ -701,7 +863,7 @@ extern "C" int zkhip_evaluate_h(zkhip_domain* dom, const zkhip_evalh_desc* desc,
         Lowering lw(b, g, desc, true);
         uint32_t res;
         if (!lw.run(res)) return set_error(ctx, ZKHIP_ERR_INVALID, "evaluate_h: %s", lw.err.c_str());
-        if (res != W_ACC) b.emit(0, DST_ACC, res);   // a gates graph whose value is not the running Horner
+        if (res != W_ACC) b.emit(0, DST_ACC_V, res);   // a gates graph whose value is not the running Horner
     }
 
     // ---- 2. permutation argument ---------------------------------------------------------------------
@@ -801,69 +963,43 @@ extern "C" int zkhip_evaluate_h(zkhip_domain* dom, const zkhip_evalh_desc* desc,
         b.fold(b.mul(b.mul(a_minus_s, b.sub(A, b.col(c_a, -1))), b.col(c_active, 0)));
     }
     ZK_CHECK(ctx, cols.size() < (1u << 16) && b.rots.size() < (1u << 12), "evaluate_h: too many columns or rotations");
-    ZK_CHECK(ctx, b.n_virtual < DST_ACC, "evaluate_h: program too large");
+    ZK_CHECK(ctx, b.n_virtual < (1u << 28), "evaluate_h: program too large");
 
     // ---- slots, tables, launch -----------------------------------------------------------------------
     // on-chip budget per lane: one register slot + four LDS slots of 36 B (nine digits): four 256-lane workgroups per CU
     const char* env_slots = getenv("ZKHIP_EVALH_LDS_SLOTS");
     const uint32_t lds_budget = env_slots && *env_slots ? (uint32_t)atoi(env_slots) : 5;
     uint32_t result = W_ACC, lds_slots = 1, n_slots = 1;
-    if (getenv("ZKHIP_DEBUG")) {
-        // how many instructions add or subtract a value that a plain multiplication produced for them alone: each such
-        // pair is a sum of two products and could share one Montgomery reduction
-        const size_t ni = b.words.size() / 4;
-        std::vector<uint32_t> reads(b.n_virtual, 0), writes(b.n_virtual, 0), pure_mul(b.n_virtual, 0);
-        for (size_t pc = 0; pc < ni; pc++) {
-            for (int q = 1; q <= 3; q++)
-                if ((b.words[4 * pc + q] >> 28) == K_SLOT) reads[b.words[4 * pc + q] & 0x0fffffffu]++;
-            const uint32_t dst = b.words[4 * pc] >> 8;
-            if (dst != DST_ACC) {
-                writes[dst]++;
-                pure_mul[dst] = (b.words[4 * pc] & 0x3f) == F_MUL;
-            }
-        }
-        size_t with_mul = 0, without_mul = 0;
-        for (size_t pc = 0; pc < ni; pc++) {
-            const uint32_t w0 = b.words[4 * pc];
-            if (!(w0 & (F_ADD | F_SUB))) continue;
-            auto lone_product = [&](uint32_t w) {
-                const uint32_t v = w & 0x0fffffffu;
-                return (w >> 28) == K_SLOT && reads[v] == 1 && writes[v] == 1 && pure_mul[v];
-            };
-            if (w0 & F_MUL) with_mul += lone_product(b.words[4 * pc + 3]);
-            else without_mul += lone_product(b.words[4 * pc + 3]) || lone_product(b.words[4 * pc + 1]);
-        }
-        fprintf(stderr, "[zkhip] evaluate_h program: %zu of %zu instructions are a*b +- (c*d) with c*d used once, %zu more are "
-                        "x +- (c*d)\n", with_mul, ni, without_mul);
+    Builder::FuseStats fuse;
+    {
+        const char* env_fuse = getenv("ZKHIP_EVALH_FUSE");   // "0" keeps every product an instruction of its own
+        if (!(env_fuse && *env_fuse == '0'))
+            ZK_CHECK(ctx, b.fuse_products(result, fuse), "evaluate_h: internal error, a fused value left its bound");
     }
     assign_slots(b.words, result, b.n_virtual, lds_budget, lds_slots, n_slots);
     {
-        size_t nmul = 0, ncol = 0;
-        for (size_t pc = 0; pc < b.words.size() / 4; pc++) {
-            if (b.words[4 * pc] & F_MUL) nmul++;
-            for (int q = 1; q <= 3; q++)
-                if ((b.words[4 * pc + q] >> 28) == K_COL) ncol++;
+        // one multiplication = one product of two operands (an instruction with a second product counts two)
+        size_t nmul = 0, ncol = 0, nspill = 0;
+        const size_t ni = b.words.size() / IW;
+        for (size_t pc = 0; pc < ni; pc++) {
+            const uint32_t* w = &b.words[pc * IW];
+            nmul += ((w[0] & F_MUL) != 0) + ((w[0] & F_MUL2) != 0);
+            for (size_t q = 2; q < IW; q++) {
+                if ((w[q] >> 28) == K_COL) ncol++;
+                if ((w[q] >> 28) == K_SLOT && (w[q] & 0x0fffffffu) >= lds_slots) nspill++;
+            }
+            if (w[1] != DST_ACC_V && w[1] >= lds_slots) nspill++;
         }
-        ctx->evalh_stats[0] = b.words.size() / 4;
+        ctx->evalh_stats[0] = ni;
         ctx->evalh_stats[1] = nmul;
         ctx->evalh_stats[2] = ncol;
         ctx->evalh_stats[3] = n_slots;
-    }
-    if (getenv("ZKHIP_DEBUG")) {
-        size_t nmul = 0, ncol = 0, nspill = 0;
-        for (size_t pc = 0; pc < b.words.size() / 4; pc++) {
-            if (b.words[4 * pc] & F_MUL) nmul++;
-            for (int q = 1; q <= 3; q++) {
-                const uint32_t w = b.words[4 * pc + q];
-                if ((w >> 28) == K_COL) ncol++;
-                if ((w >> 28) == K_SLOT && (w & 0x0fffffffu) >= lds_slots) nspill++;
-            }
-            const uint32_t dst = b.words[4 * pc] >> 8;
-            if (dst != DST_ACC && dst >= lds_slots) nspill++;
-        }
-        fprintf(stderr, "[zkhip] evaluate_h program: %zu instructions (%zu multiplications, %zu column reads, %zu spill accesses), "
-                        "%zu columns, %zu rotations, %u values -> %u slots (%u in LDS)\n",
-                b.words.size() / 4, nmul, ncol, nspill, cols.size(), b.rots.size(), b.n_virtual, n_slots, lds_slots);
+        if (getenv("ZKHIP_DEBUG"))
+            fprintf(stderr, "[zkhip] evaluate_h program: %zu instructions (%zu products, %zu of them second products sharing a "
+                            "reduction, %zu multiply-adds formed; %zu column reads, %zu spill accesses), %zu columns, "
+                            "%zu rotations, %u values -> %u slots (%u in LDS)\n",
+                    ni, nmul, fuse.two_products, fuse.multiply_adds, ncol, nspill, cols.size(), b.rots.size(), b.n_virtual,
+                    n_slots, lds_slots);
     }
 
     std::vector<uint64_t> scal((size_t)(SC_CHALLENGE0 + desc->num_challenges) * 4);
@@ -912,14 +1048,17 @@ extern "C" int zkhip_evaluate_h(zkhip_domain* dom, const zkhip_evalh_desc* desc,
     };
     for (int32_t r : b.rots)
         ZK_CHECK(ctx, std::abs((int64_t)r) * rot_scale < (1 << 26), "evaluate_h: rotation %d out of range", r);
-    const size_t n_instr = b.words.size() / 4;
+    const size_t n_instr = b.words.size() / IW;
     std::vector<uint32_t> linked(n_instr * INS_WORDS, 0);
     for (size_t pc = 0; pc < n_instr; pc++) {
         uint32_t* o = &linked[pc * INS_WORDS];
-        o[0] = b.words[4 * pc];
-        link(b.words[4 * pc + 1], o + 1);
-        link(b.words[4 * pc + 2], o + 4);
-        link(b.words[4 * pc + 3], o + 7);
+        const uint32_t* w = &b.words[pc * IW];
+        ZK_CHECK(ctx, w[1] == DST_ACC_V || w[1] < DST_ACC, "evaluate_h: too many value slots");
+        o[0] = w[0] | ((w[1] == DST_ACC_V ? DST_ACC : w[1]) << DST_SHIFT);
+        link(w[2], o + 1);
+        link(w[3], o + 4);
+        link(w[4], o + 7);
+        link(w[5], o + 10);
     }
     uint32_t res_link[3];
     link(result, res_link);

@@ -137,6 +137,13 @@ struct Wide {
         o.d[8] = (int32_t)col[17];
         return o;
     }
+    // col += a b, the 81 digit products in their 17 columns (col[17] only takes carries in reduce)
+    ZK_DEV static void mac(int64_t col[18], const fw& a, const fw& b) {
+#pragma unroll
+        for (int i = 0; i < 9; i++)
+#pragma unroll
+            for (int j = 0; j < 9; j++) col[i + j] += (int64_t)a.d[i] * b.d[j];
+    }
     ZK_DEV static fw mul(const fw& a, const fw& b) {
         int64_t col[18];
 #pragma unroll
