@@ -104,3 +104,35 @@ def test_polynomial_raw_records():
     g.seek(0)
     with pytest.raises(formats.FormatError):
         formats.read_polynomial_raw(g)
+
+
+def _scrape(lines, tag):
+    """What scripts/report_system_data/report_bench.py:57-75 does with an End line: collapse runs of equal characters,
+    keep what follows the first dot."""
+    import itertools
+    line = [i for i in lines if "End" in i and tag in i][0]
+    return "".join(g[0] for g in itertools.groupby(line)).split(".", 1)[-1].strip()
+
+
+def test_reference_log_lines_are_scrapable():
+    lines = formats.reference_log_lines("replay_k19", 280000, 19, {"create_proof": 2.7203, "verify_proof": 0.0125,
+                                                                     "generate_witness": 1.5})
+    # the summary line as report_bench.py:29-34 splits it
+    fields = [i for i in lines if formats.CIRCUIT_SUMMARY in i][0].split(",")
+    got = {}
+    for spl in fields:
+        for key in ("max_num_row", "degree"):
+            if key in spl:
+                got[key] = spl.strip().removeprefix(key + ":")
+    assert got == {"max_num_row": "280000", "degree": "19"}
+    assert [i for i in lines if "running" in i and "test" in i][0].split()[1] == "1"
+    assert [i.split(":")[1].split(".")[0].replace(" ", "") for i in lines if "test result" in i][0] == "ok"
+    # 2.7203 s prints as 2.720s; the scraper's run-collapsing leaves 2.720s intact, and 12.500ms becomes 12.50ms
+    assert _scrape(lines, "[Create_proof]") == "2.720s"
+    assert _scrape(lines, "[Verify proof]") == "12.50ms"
+    assert [i for i in lines if "End" in i and "[Generate witness]" in i][0].split(" ")[-1].endswith("1.500s")
+    order = [i.split("]")[0] for i in lines if i.startswith("Start:")]
+    assert [o.split("[")[1] for o in order] == ["Generate witness", "Create_proof", "Verify proof"]
+    assert formats._ark_time(3.2e-6) == "3.200µs" and formats._ark_time(5e-9) == "5ns"
+    with pytest.raises(formats.FormatError):
+        formats.reference_log_lines("x", 1, 1, {"setup": 1.0})

@@ -198,3 +198,52 @@ def load_proof_json(directory: str, name: str):
     except (KeyError, ValueError) as e:
         raise FormatError(f"proof JSON: {e}") from None
     return proof, deserialize_instances(inst), vk
+
+
+# ---- benchmark log lines ----------------------------------------------------------------------------------------------
+# The reference's benchmark prints a summary line and brackets every phase with ark_std's start_timer! / end_timer!
+# (zkevm-circuits/benches/benchmark_list/main.rs:44-52 for the tags, :68-71 for the summary, :210-245 for the messages);
+# scripts/report_system_data/report_bench.py:10-110 scrapes those lines into its report.  Unpinned: the lines are checked
+# against a restatement of that script's parsing steps, not against the script itself, and ark_std's timer format is
+# restated from its published source.
+CIRCUIT_SUMMARY = "[Circuit summary]"
+PHASE_TAGS = {
+    "generate_witness": ("[Generate witness]", "Generate witness of one transaction's trace."),
+    "create_circuit": ("[Create circuit]", "Create a new SubCircuit from witness."),
+    "create_proof": ("[Create_proof]", "Create proof/Round 1/1"),
+    "verify_proof": ("[Verify proof]", "Verify proof/Round 1/1"),
+}
+
+
+def _ark_time(seconds: float) -> str:
+    """Elapsed time as ark_std's end_timer! prints it: 12.345s, 45.678ms, 9.012µs or 7ns."""
+    ns = int(round(seconds * 1e9))
+    secs, millis, micros, nanos = ns // 10**9, ns // 10**6 % 1000, ns // 1000 % 1000, ns % 1000
+    if secs:
+        return f"{secs}.{millis:03d}s"
+    if millis:
+        return f"{millis}.{micros:03d}ms"
+    if micros:
+        return f"{micros}.{nanos:03d}µs"
+    return f"{nanos}ns"
+
+
+def reference_log_lines(test_id: str, max_num_row: int, degree: int, phases: dict, passed: bool = True):
+    """The lines a run of the reference's benchmark would leave for `report_bench.py`: the circuit summary, cargo's
+    `running 1 test`, a Start / End pair per phase in `phases` (name -> seconds, names as in PHASE_TAGS) and the test
+    result.  End lines pad the message with dots to a fixed width, as ark_std does."""
+    unknown = set(phases) - set(PHASE_TAGS)
+    if unknown:
+        raise FormatError(f"log: unknown phases {sorted(unknown)}")
+    lines = [f"{CIRCUIT_SUMMARY}/id:{test_id}, max_num_row:{max_num_row}, degree:{degree}, round:1, use params file:false",
+             "running 1 test"]
+    for name in PHASE_TAGS:                      # the order the benchmark runs them in
+        if name not in phases:
+            continue
+        tag, text = PHASE_TAGS[name]
+        msg = f"{tag}/{test_id}/{text}"
+        lines.append(f"{'Start:':8} {msg}")
+        lines.append(f"{'End:':8} {msg} {'.' * max(3, 75 - len(msg))}{_ark_time(phases[name])}")
+    lines.append("test result: ok. 1 passed; 0 failed; 0 ignored; 0 measured; 0 filtered out" if passed
+                 else "test result: FAILED. 0 passed; 1 failed; 0 ignored; 0 measured; 0 filtered out")
+    return lines
