@@ -69,6 +69,10 @@ def main():
     ap.add_argument("--perm-cols", type=int, default=12)
     ap.add_argument("--degree", type=int, default=9)
     ap.add_argument("--gate-polys", type=int, default=3000)
+    ap.add_argument("--reference-log", metavar="PATH",
+                    help="also write the summary / Start / End lines the reference's benchmark prints "
+                         "(zkevm-circuits/benches/benchmark_list/main.rs:44-52,68-71,236-245), with the replay's total as "
+                         "the [Create_proof] phase")
     args = ap.parse_args()
 
     torch.cuda.set_device(0)
@@ -304,6 +308,11 @@ def main():
         "device_memory_GB": torch.cuda.max_memory_allocated() / 1e9,
     }
     print(json.dumps(line))
+    if args.reference_log:
+        from zkevm_circuits_amd import formats
+        with open(args.reference_log, "w") as f:
+            f.write("\n".join(formats.reference_log_lines(f"replay_k{args.k}", (1 << args.k), args.k,
+                                                           {"create_proof": total})) + "\n")
     ctx.release_bases(bid)
 
 

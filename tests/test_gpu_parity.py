@@ -621,18 +621,23 @@ def test_grand_products_golden(ctx):
         ctx.free(d_c)
 
 
-def test_replay_script_small_shape(ctx, capsys, monkeypatch):
+def test_replay_script_small_shape(ctx, capsys, monkeypatch, tmp_path):
     """replay.py (the create_proof operator multiset) runs end to end on a small shape and reports every phase"""
     import json
     import runpy
     import sys
+    log = tmp_path / "replay.log"
     monkeypatch.setattr(sys, "argv", ["replay.py", "--k", "10", "--advice", "9", "--fixed", "4", "--lookups", "3",
-                                      "--gate-polys", "20", "--degree", "5", "--perm-cols", "5"])
+                                      "--gate-polys", "20", "--degree", "5", "--perm-cols", "5",
+                                      "--reference-log", str(log)])
     runpy.run_path(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "replay.py"), run_name="__main__")
     line = json.loads(capsys.readouterr().out.strip().splitlines()[-1])
     assert line["msm_count"] == 9 + 3 * 3 + line["shape"]["permutation_sets"] + 1 + 4
     assert {"evaluate_h", "coeff_to_extended", "advice_commit_msm", "eval_polynomial", "shplonk_multiopen"} <= set(line["phases_s"])
     assert line["shplonk"]["queries"] == line["eval_polynomial_count"] and line["shplonk"]["kate_division_calls"] >= 4
+    text = log.read_text().splitlines()
+    assert text[0].startswith("[Circuit summary]/id:replay_k10, max_num_row:1024, degree:10,")
+    assert any(l.startswith("End:") and "[Create_proof]/replay_k10/" in l for l in text)
 
 
 # ------------------------------------------------------------------------------------------------ SHPLONK opening
