@@ -55,6 +55,14 @@ def test_proof_json_fields(tmp_path):
     assert p2 == proof and vk2 == b"\x01\x02" and np.array_equal(i2[0], inst[0])
     with pytest.raises(formats.FormatError):
         formats.load_proof_json(str(tmp_path), "absent")
+    # chunk proof: the protocol bytes lead, the proof fields sit flattened beside them
+    formats.dump_proof_json(str(tmp_path), "chunk", proof, inst, vk=b"", protocol=b'{"domain":{}}')
+    raw = open(formats.proof_path(str(tmp_path), "chunk")).read()
+    assert raw.startswith('{"protocol":"') and list(json.loads(raw)) == ["protocol", "proof", "instances", "vk"]
+    pr, p3, i3, vk3 = formats.load_proof_json(str(tmp_path), "chunk", with_protocol=True)
+    assert pr == b'{"domain":{}}' and p3 == proof and vk3 == b"" and np.array_equal(i3[0], inst[0])
+    with pytest.raises(formats.FormatError):
+        formats.load_proof_json(str(tmp_path), "super", with_protocol=True)     # a plain proof has no protocol
 
 
 def test_params_raw_layout_and_round_trip(tmp_path):

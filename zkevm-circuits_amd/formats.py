@@ -172,20 +172,24 @@ def proof_path(directory: str, name: str) -> str:
     return f"{directory}/full_proof_{name}.json"       # prover/src/proof.rs:94-96
 
 
-def dump_proof_json(directory: str, name: str, proof: bytes, instances, vk: bytes = b"") -> str:
-    """{"proof", "instances", "vk"}, each standard base64 (prover/src/proof.rs:24-48, 78-84); returns the path."""
-    doc = {
-        "proof": base64.b64encode(bytes(proof)).decode("ascii"),
-        "instances": base64.b64encode(serialize_instances(instances)).decode("ascii"),
-        "vk": base64.b64encode(bytes(vk)).decode("ascii"),
-    }
+def dump_proof_json(directory: str, name: str, proof: bytes, instances, vk: bytes = b"", protocol: bytes | None = None) -> str:
+    """{"proof", "instances", "vk"}, each standard base64 (prover/src/proof.rs:24-48, 78-84); with `protocol` (the
+    serialised PlonkProtocol of a chunk proof) that field comes first and the others are flattened beside it
+    (prover/src/proof/chunk.rs:22-28).  Returns the path."""
+    doc = {}
+    if protocol is not None:
+        doc["protocol"] = base64.b64encode(bytes(protocol)).decode("ascii")
+    doc["proof"] = base64.b64encode(bytes(proof)).decode("ascii")
+    doc["instances"] = base64.b64encode(serialize_instances(instances)).decode("ascii")
+    doc["vk"] = base64.b64encode(bytes(vk)).decode("ascii")
     path = proof_path(directory, name)
     with open(path, "w") as f:
         json.dump(doc, f, separators=(",", ":"))
     return path
 
 
-def load_proof_json(directory: str, name: str):
+def load_proof_json(directory: str, name: str, with_protocol: bool = False):
+    """(proof, instances, vk), or (protocol, proof, instances, vk) for a chunk proof."""
     path = proof_path(directory, name)
     if not os.path.exists(path):
         raise FormatError(f"File {path} doesn't exist")
@@ -195,8 +199,11 @@ def load_proof_json(directory: str, name: str):
         proof = base64.b64decode(doc["proof"], validate=True)
         inst = base64.b64decode(doc["instances"], validate=True)
         vk = base64.b64decode(doc["vk"], validate=True)
+        protocol = base64.b64decode(doc["protocol"], validate=True) if with_protocol else None
     except (KeyError, ValueError) as e:
         raise FormatError(f"proof JSON: {e}") from None
+    if with_protocol:
+        return protocol, proof, deserialize_instances(inst), vk
     return proof, deserialize_instances(inst), vk
 
 
