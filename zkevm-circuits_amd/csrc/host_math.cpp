@@ -65,35 +65,33 @@ void h_sub(const HostField& F, uint64_t o[4], const uint64_t a[4], const uint64_
     memcpy(o, t, 32);
 }
 void h_mul(const HostField& F, uint64_t o[4], const uint64_t a[4], const uint64_t b[4]) {
-    // product scanning into 8 words, then word-wise Montgomery reduction
-    uint64_t t[9] = {0};
+    // Coarsely integrated operand scanning, unrolled.  Both BN254 moduli leave the two top bits of the high limb clear,
+    // so the running value fits four limbs plus one carry limb and no second carry chain is needed.
+    const uint64_t p0 = F.p[0], p1 = F.p[1], p2 = F.p[2], p3 = F.p[3];
+    uint64_t t0 = 0, t1 = 0, t2 = 0, t3 = 0;
     for (int i = 0; i < 4; i++) {
-        u128 c = 0;
-        for (int j = 0; j < 4; j++) {
-            c += (u128)a[i] * b[j] + t[i + j];
-            t[i + j] = (uint64_t)c;
-            c >>= 64;
-        }
-        t[i + 4] = (uint64_t)c;
+        const uint64_t bi = b[i];
+        u128 c = (u128)a[0] * bi + t0;
+        t0 = (uint64_t)c;
+        c = (u128)a[1] * bi + t1 + (uint64_t)(c >> 64);
+        t1 = (uint64_t)c;
+        c = (u128)a[2] * bi + t2 + (uint64_t)(c >> 64);
+        t2 = (uint64_t)c;
+        c = (u128)a[3] * bi + t3 + (uint64_t)(c >> 64);
+        t3 = (uint64_t)c;
+        const uint64_t t4 = (uint64_t)(c >> 64);
+        const uint64_t m = t0 * F.inv;
+        c = (u128)m * p0 + t0;
+        c = (u128)m * p1 + t1 + (uint64_t)(c >> 64);
+        t0 = (uint64_t)c;
+        c = (u128)m * p2 + t2 + (uint64_t)(c >> 64);
+        t1 = (uint64_t)c;
+        c = (u128)m * p3 + t3 + (uint64_t)(c >> 64);
+        t2 = (uint64_t)c;
+        t3 = t4 + (uint64_t)(c >> 64);
     }
-    uint64_t top = 0;
-    for (int i = 0; i < 4; i++) {
-        const uint64_t m = t[i] * F.inv;
-        u128 c = 0;
-        for (int j = 0; j < 4; j++) {
-            c += (u128)m * F.p[j] + t[i + j];
-            t[i + j] = (uint64_t)c;
-            c >>= 64;
-        }
-        for (int k = i + 4; k < 8 && c; k++) {
-            c += t[k];
-            t[k] = (uint64_t)c;
-            c >>= 64;
-        }
-        top += (uint64_t)c;
-    }
-    uint64_t r[4] = {t[4], t[5], t[6], t[7]};
-    if (top || geq(r, F.p)) sub_nb(r, F.p);
+    uint64_t r[4] = {t0, t1, t2, t3};
+    if (geq(r, F.p)) sub_nb(r, F.p);
     memcpy(o, r, 32);
 }
 void h_pow(const HostField& F, uint64_t o[4], const uint64_t a[4], uint64_t e) {
