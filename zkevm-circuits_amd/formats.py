@@ -78,7 +78,6 @@ def read_params_raw(path: str, max_k: int = 28) -> ParamsRaw:
     want = 4 + 2 * n * G1_RAW + 2 * G2_RAW
     if size != want:
         raise FormatError(f"params: k = {k} needs {want} bytes, file has {size}")
-    # the tables start at byte 4 of the file; _limb_view copies a table only if its mapping is not 8-byte aligned
     raw = np.memmap(path, dtype=np.uint8, mode="r", offset=4, shape=(2 * n * G1_RAW,))
     g = _limb_view(raw[: n * G1_RAW], 8)
     gl = _limb_view(raw[n * G1_RAW:], 8)
@@ -90,10 +89,10 @@ def read_params_raw(path: str, max_k: int = 28) -> ParamsRaw:
 
 
 def _limb_view(raw_u8: np.ndarray, limbs: int) -> np.ndarray:
-    """(rows, limbs) little-endian u64 view of a byte array; copies only when the bytes are not 8-byte aligned."""
-    if raw_u8.ctypes.data % 8 == 0:
-        return raw_u8.view("<u8").reshape(-1, limbs)
-    return np.frombuffer(raw_u8.tobytes(), dtype="<u8").reshape(-1, limbs)
+    """(rows, limbs) little-endian u64 view of a byte array, never a copy.  The tables of a parameter file start at byte 4,
+    so the view is not 8-byte aligned: numpy reads such arrays correctly, and the library only ever copies them to the
+    device."""
+    return raw_u8.view("<u8").reshape(-1, limbs)
 
 
 # ---- Polynomial<F, B>, SerdeFormat::RawBytes --------------------------------------------------------------------------
