@@ -1,5 +1,6 @@
 // EvaluationDomain state (internal to libzkhip).
 #pragma once
+#include <map>
 #include "common.h"
 #include "ntt.h"
 
@@ -11,6 +12,7 @@ struct zkhip_domain {
     std::vector<uint64_t> t_evaluations;   // 2^(extended_k - k) inverted values, Montgomery limbs
     void* d_t_evaluations = nullptr;
     void* d_xpoints = nullptr;             // zeta * extended_omega^idx per extended row (built on first use by evaluate_h)
+    std::map<uint32_t, void*> d_coset_powers;   // coset j -> (zeta * extended_omega^j)^i for i < 2^k (built on first use)
     zkhip::NttPlan *plan_fwd = nullptr, *plan_inv = nullptr, *plan_ext_fwd = nullptr, *plan_ext_inv = nullptr;
 };
 
@@ -23,8 +25,10 @@ struct CosetList {
     uint32_t j[16];
 };
 int coset_list_check(zkhip_domain* dom, const uint32_t* cosets, uint32_t num, CosetList* out);
-// coeff (2^k, device) -> its values on the listed cosets, compact layout (2^k * num); tmp: 4 * 2^k elements
-int domain_coeff_to_cosets(zkhip_domain* dom, const fe* d_coeff, const CosetList& cl, fe* d_out, fe* tmp);
+// `batch` coefficient vectors (2^k each, back to back, device) -> their values on the listed cosets, compact layout
+// (2^k * num per vector, back to back); tmp: domain_coeff_to_cosets_tmp(...) elements
+size_t domain_coeff_to_cosets_tmp(const zkhip_domain* dom, const CosetList& cl, size_t batch);
+int domain_coeff_to_cosets(zkhip_domain* dom, const fe* d_coeff, size_t batch, const CosetList& cl, fe* d_out, fe* tmp);
 // x[q * num + s] = zeta * extended_omega^(q * 2^e + j[s])
 int domain_coset_xpoints(zkhip_domain* dom, const CosetList& cl, fe* d_x);
 // coeff (2^k per member, stride 2^k) -> extended coset (2^extended_k per member); tmp0/tmp1: batch * 2^extended_k each

@@ -21,25 +21,40 @@ int domain_coeff_to_extended(zkhip_domain* dom, const fe* d_coeff, fe* d_out, si
 
 // ---- coset subsets (the unit of the multi-GPU split of evaluate_h) -------------------------------------------
 // t[i] = c[i] * zeta^(i mod 3) * extended_omega^(j i): the coefficients of p(zeta extended_omega^j X)
-__global__ void __launch_bounds__(256) coset_prescale_kernel(const fe* c, fe* t, uint32_t n, uint32_t j, fe zeta, fe zeta2,
-                                                             const fe* om_lo, const fe* om_hi, uint32_t h) {
+// t[i] = (zeta * extended_omega^j)^i: the factor that moves coefficient i to coset j
+__global__ void __launch_bounds__(256) coset_powers_kernel(fe* t, uint32_t n, uint32_t j, fe one, fe zeta, fe zeta2,
+                                                           const fe* om_lo, const fe* om_hi, uint32_t h) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    fe v = load_fe(c + i);
+    fe v = one;
     const uint32_t e = i * j;   // < 2^extended_k
     if (e) {
-        fe om = load_fe(om_lo + (e & ((1u << h) - 1)));
-        if (e >> h) om = Fr::mul(om, load_fe(om_hi + (e >> h)));
-        v = Fr::mul(v, om);
+        v = load_fe(om_lo + (e & ((1u << h) - 1)));
+        if (e >> h) v = Fr::mul(v, load_fe(om_hi + (e >> h)));
     }
     const uint32_t r = i % 3;
     if (r == 1) v = Fr::mul(v, zeta);
     else if (r == 2) v = Fr::mul(v, zeta2);
     store_fe(t + i, v);
 }
-__global__ void __launch_bounds__(256) coset_interleave_kernel(const fe* src, fe* dst, uint32_t n, uint32_t num, uint32_t s) {
-    const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
-    if (q < n) store_fe(dst + (size_t)q * num + s, load_fe(src + q));
+// A group of (coefficient vector, coset) pairs handled by one launch: blockIdx.y = member of the group.
+constexpr int COSET_GROUP = 32;
+struct CosetGroup {
+    const fe* src[COSET_GROUP];    // coefficient vector of the member
+    const fe* pow[COSET_GROUP];    // power table of its coset
+    fe* dst[COSET_GROUP];          // compact output of its vector
+    uint32_t slot[COSET_GROUP];    // position of its coset in the compact layout
+};
+// t[g][i] = src_g[i] * pow_g[i]
+__global__ void __launch_bounds__(256) coset_prescale_kernel(const CosetGroup grp, fe* t, uint32_t n) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x, g = blockIdx.y;
+    if (i >= n) return;
+    store_fe(t + (size_t)g * n + i, Fr::mul(load_fe(grp.src[g] + i), load_fe(grp.pow[g] + i)));
+}
+// dst_g[q * num + slot_g] = t[g][q]
+__global__ void __launch_bounds__(256) coset_interleave_kernel(const CosetGroup grp, const fe* t, uint32_t n, uint32_t num) {
+    const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x, g = blockIdx.y;
+    if (q < n) store_fe(grp.dst[g] + (size_t)q * num + grp.slot[g], load_fe(t + (size_t)g * n + q));
 }
 // to_compact: dst[q * num + s] = src[q * 2^e + j[s]]; otherwise the reverse (rows of other cosets are left alone)
 __global__ void __launch_bounds__(256) coset_gather_kernel(const fe* src, fe* dst, size_t rows, CosetList cl, uint32_t e, int to_compact) {
@@ -79,22 +94,69 @@ int coset_list_check(zkhip_domain* dom, const uint32_t* cosets, uint32_t num, Co
     return ZKHIP_OK;
 }
 
-int domain_coeff_to_cosets(zkhip_domain* dom, const fe* d_coeff, const CosetList& cl, fe* d_out, fe* tmp) {
+// members per launch: as many as fit a scratch budget of 1 GiB (four vectors of 2^k elements per member)
+static size_t coset_group_size(const zkhip_domain* dom, size_t members) {
+    const size_t n = (size_t)1 << dom->k;
+    const size_t fit = std::max<size_t>(1, ((size_t)1 << 30) / (4 * n * 32));
+    return std::min<size_t>(std::min<size_t>(members, (size_t)COSET_GROUP), fit);
+}
+size_t domain_coeff_to_cosets_tmp(const zkhip_domain* dom, const CosetList& cl, size_t batch) {
+    return 4 * coset_group_size(dom, batch * cl.num) * ((size_t)1 << dom->k);
+}
+static int coset_power_table(zkhip_domain* dom, uint32_t j, const fe** out) {
+    zkhip_ctx* ctx = dom->ctx;
+    auto it = dom->d_coset_powers.find(j);
+    if (it == dom->d_coset_powers.end()) {
+        const uint32_t n = 1u << dom->k;
+        void* d;
+        ZK_HIP(ctx, hipMalloc(&d, (size_t)n * 32));
+        fe one, zeta, zeta2;
+        to_fe(one, HFR.r);
+        to_fe(zeta, dom->g_coset);
+        to_fe(zeta2, dom->g_coset_inv);   // zeta^2 = zeta^-1
+        hipLaunchKernelGGL(coset_powers_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, (fe*)d, n, j, one, zeta, zeta2,
+                           (const fe*)dom->plan_ext_fwd->d_lo, (const fe*)dom->plan_ext_fwd->d_hi, dom->plan_ext_fwd->h);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) {
+            (void)hipFree(d);
+            return set_error(ctx, ZKHIP_ERR_HIP, "coset powers: %s", hipGetErrorString(e));
+        }
+        it = dom->d_coset_powers.emplace(j, d).first;
+    }
+    *out = (const fe*)it->second;
+    return ZKHIP_OK;
+}
+
+// Per (vector, coset) member: scale coefficient i by (zeta * extended_omega^j)^i, one size-2^k NTT, interleave into the
+// compact layout.  Members run in groups: one scaling launch, one batched NTT and one interleave launch per group.
+int domain_coeff_to_cosets(zkhip_domain* dom, const fe* d_coeff, size_t batch, const CosetList& cl, fe* d_out, fe* tmp) {
     zkhip_ctx* ctx = dom->ctx;
     const uint32_t n = 1u << dom->k;
-    fe zeta, zeta2;
-    to_fe(zeta, dom->g_coset);
-    to_fe(zeta2, dom->g_coset_inv);   // zeta^2 = zeta^-1
-    fe *t_in = tmp, *t_out = tmp + n, *t0 = tmp + 2 * (size_t)n, *t1 = tmp + 3 * (size_t)n;
-    const dim3 grid((n + 255) / 256);
-    NttFuse fuse;
+    const fe* pow[16];
     for (uint32_t s = 0; s < cl.num; s++) {
-        hipLaunchKernelGGL(coset_prescale_kernel, grid, dim3(256), 0, ctx->stream, d_coeff, t_in, n, cl.j[s], zeta, zeta2,
-                           (const fe*)dom->plan_ext_fwd->d_lo, (const fe*)dom->plan_ext_fwd->d_hi, dom->plan_ext_fwd->h);
-        ZK_HIP(ctx, hipGetLastError());
-        int rc = ntt_run(ctx, dom->plan_fwd, t_in, n, n, t_out, n, n, 1, fuse, t0, t1);
+        int rc = coset_power_table(dom, cl.j[s], &pow[s]);
         if (rc) return rc;
-        hipLaunchKernelGGL(coset_interleave_kernel, grid, dim3(256), 0, ctx->stream, (const fe*)t_out, d_out, n, cl.num, s);
+    }
+    const size_t members = batch * cl.num, gs = coset_group_size(dom, members);
+    fe *t_in = tmp, *t_out = tmp + gs * n, *t0 = tmp + 2 * gs * n, *t1 = tmp + 3 * gs * n;
+    NttFuse fuse;
+    for (size_t m0 = 0; m0 < members; m0 += gs) {
+        const size_t cnt = std::min(gs, members - m0);
+        CosetGroup grp;
+        memset(&grp, 0, sizeof grp);
+        for (size_t g = 0; g < cnt; g++) {
+            const size_t b = (m0 + g) / cl.num, s = (m0 + g) % cl.num;
+            grp.src[g] = d_coeff + b * n;
+            grp.pow[g] = pow[s];
+            grp.dst[g] = d_out + b * n * cl.num;
+            grp.slot[g] = (uint32_t)s;
+        }
+        const dim3 grid((n + 255) / 256, (unsigned)cnt);
+        hipLaunchKernelGGL(coset_prescale_kernel, grid, dim3(256), 0, ctx->stream, grp, t_in, n);
+        ZK_HIP(ctx, hipGetLastError());
+        int rc = ntt_run(ctx, dom->plan_fwd, t_in, n, n, t_out, n, n, cnt, fuse, t0, t1);
+        if (rc) return rc;
+        hipLaunchKernelGGL(coset_interleave_kernel, grid, dim3(256), 0, ctx->stream, grp, (const fe*)t_out, n, cl.num);
         ZK_HIP(ctx, hipGetLastError());
     }
     return ZKHIP_OK;
@@ -183,6 +245,7 @@ void zkhip_domain_destroy(zkhip_domain* dom) {
     if (!dom) return;
     if (dom->d_t_evaluations) (void)hipFree(dom->d_t_evaluations);
     if (dom->d_xpoints) (void)hipFree(dom->d_xpoints);
+    for (auto& kv : dom->d_coset_powers) (void)hipFree(kv.second);
     delete dom;   // NTT plans are owned by the context
 }
 
@@ -289,14 +352,9 @@ int zkhip_coeff_to_cosets_dev(zkhip_domain* dom, const uint64_t* d_coeff, const 
     int rc = coset_list_check(dom, cosets, num_cosets, &cl);
     if (rc) return rc;
     ZK_HIP(ctx, hipSetDevice(ctx->device));
-    const size_t n = (size_t)1 << dom->k;
-    rc = ensure_scratch(ctx, 4 * n * 32);
+    rc = ensure_scratch(ctx, domain_coeff_to_cosets_tmp(dom, cl, batch) * 32);
     if (rc) return rc;
-    for (size_t b = 0; b < batch; b++) {
-        rc = domain_coeff_to_cosets(dom, (const fe*)d_coeff + b * n, cl, (fe*)d_out + b * n * cl.num, (fe*)ctx->scratch);
-        if (rc) return rc;
-    }
-    return ZKHIP_OK;
+    return domain_coeff_to_cosets(dom, (const fe*)d_coeff, batch, cl, (fe*)d_out, (fe*)ctx->scratch);
 }
 
 static int coset_copy(zkhip_domain* dom, const uint64_t* d_src, const uint32_t* cosets, uint32_t num_cosets, uint64_t* d_dst,

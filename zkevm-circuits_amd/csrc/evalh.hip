@@ -802,7 +802,7 @@ extern "C" int zkhip_evaluate_h(zkhip_domain* dom, const zkhip_evalh_desc* desc,
     // Bring one polynomial to an extended coset on the device.  `ext_in`: already extended.
     fe *tmp0 = nullptr, *tmp1 = nullptr;
     if (coeff) {
-        rc = ensure_scratch(ctx, (compact ? 4 * n : 2 * size) * 32);
+        rc = ensure_scratch(ctx, (compact ? domain_coeff_to_cosets_tmp(dom, cl, 1) : 2 * size) * 32);
         if (rc) return rc;
         tmp0 = (fe*)ctx->scratch;
         tmp1 = tmp0 + size;
@@ -827,7 +827,7 @@ extern "C" int zkhip_evaluate_h(zkhip_domain* dom, const zkhip_evalh_desc* desc,
         void* d_ext;
         int r = ar.alloc(size * 32, &d_ext);
         if (r) return r;
-        r = compact ? domain_coeff_to_cosets(dom, d_coeff, cl, (fe*)d_ext, tmp0)
+        r = compact ? domain_coeff_to_cosets(dom, d_coeff, 1, cl, (fe*)d_ext, tmp0)
                     : domain_coeff_to_extended(dom, d_coeff, (fe*)d_ext, 1, tmp0, tmp1);
         if (r) return r;
         *outp = (const fe*)d_ext;
