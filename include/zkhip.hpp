@@ -11,6 +11,9 @@
 //                                                                extended_to_coeff, divide_by_vanishing_poly}
 //     halo2::poly::ParamsKZG::{commit, commit_lagrange}          poly::kzg::commitment::ParamsKZG (the two MSM call sites)
 //     halo2::plonk::Evaluator::evaluate_h                        plonk::evaluation::Evaluator::evaluate_h
+//     halo2::arithmetic::{eval_polynomial, kate_division}        arithmetic::{eval_polynomial, kate_division}
+//     halo2::arithmetic::batch_invert                            ff::BatchInvert::batch_invert
+//     halo2::plonk::lookup::permute_expression_pair              plonk::lookup::prover::permute_expression_pair
 //
 // Upstream's functions panic on misuse (length mismatch, wrong domain); here every failure of the C ABI throws
 // halo2::Panic carrying zkhip_last_error's text.  As in the reference (`env_info: &mut Option<JitProverEnv>`,
@@ -118,6 +121,63 @@ inline void best_fft(std::vector<Fr>& a, const Fr& omega, uint32_t log_n) {
     Accelerator& acc = Accelerator::get();
     std::lock_guard<std::mutex> g(acc.lock());
     acc.check(zkhip_ntt(acc.ctx(), reinterpret_cast<uint64_t*>(a.data()), log_n, omega.l), "best_fft");
+}
+
+// A device buffer of field elements for the duration of one call (the context's allocator; freed on scope exit)
+class DeviceVec {
+public:
+    DeviceVec(Accelerator& acc, size_t elements) : acc_(acc) {
+        acc.check(zkhip_dev_alloc(acc.ctx(), (elements ? elements : 1) * 32, &p_), "device allocation");
+    }
+    DeviceVec(Accelerator& acc, const std::vector<Fr>& host) : DeviceVec(acc, host.size()) {
+        if (!host.empty()) acc.check(zkhip_upload(acc.ctx(), p_, host.data(), host.size() * 32), "upload");
+    }
+    ~DeviceVec() { zkhip_dev_free(acc_.ctx(), p_); }
+    DeviceVec(const DeviceVec&) = delete;
+    DeviceVec& operator=(const DeviceVec&) = delete;
+    uint64_t* ptr() const { return static_cast<uint64_t*>(p_); }
+    std::vector<Fr> download(size_t elements) const {
+        std::vector<Fr> out(elements);
+        if (elements) acc_.check(zkhip_download(acc_.ctx(), out.data(), p_, elements * 32), "download");
+        return out;
+    }
+
+private:
+    Accelerator& acc_;
+    void* p_ = nullptr;
+};
+
+// sum_i poly[i] point^i
+inline Fr eval_polynomial(const std::vector<Fr>& poly, const Fr& point) {
+    Accelerator& acc = Accelerator::get();
+    std::lock_guard<std::mutex> g(acc.lock());
+    Fr out{{0, 0, 0, 0}};
+    if (poly.empty()) return out;
+    const DeviceVec d(acc, poly);
+    acc.check(zkhip_eval_polynomial_dev(acc.ctx(), d.ptr(), poly.size(), point.l, out.l), "eval_polynomial");
+    return out;
+}
+
+// quotient of a(X) by (X - b): a.len() - 1 coefficients, the remainder a(b) is dropped
+inline std::vector<Fr> kate_division(const std::vector<Fr>& a, const Fr& b) {
+    if (a.empty()) throw Panic("kate_division: empty polynomial");
+    Accelerator& acc = Accelerator::get();
+    std::lock_guard<std::mutex> g(acc.lock());
+    const DeviceVec d(acc, a), q(acc, a.size());
+    acc.check(zkhip_kate_division_dev(acc.ctx(), d.ptr(), a.size(), b.l, q.ptr()), "kate_division");
+    acc.check(zkhip_sync(acc.ctx()), "kate_division");
+    return q.download(a.size() - 1);
+}
+
+// every non-zero element replaced by its inverse, zeros kept
+inline void batch_invert(std::vector<Fr>& v) {
+    if (v.empty()) return;
+    Accelerator& acc = Accelerator::get();
+    std::lock_guard<std::mutex> g(acc.lock());
+    const DeviceVec d(acc, v);
+    acc.check(zkhip_batch_invert_dev(acc.ctx(), 0, d.ptr(), v.size()), "batch_invert");
+    acc.check(zkhip_sync(acc.ctx()), "batch_invert");
+    v = d.download(v.size());
 }
 
 inline G1Affine to_affine(const G1& p) {
@@ -396,6 +456,36 @@ inline poly::Polynomial Evaluator::evaluate_h(const ProvingKey& pk, const std::v
     acc.check(zkhip_evaluate_h(pk.domain->raw(), &call.desc, reinterpret_cast<uint64_t*>(out.values.data())), "evaluate_h");
     return out;
 }
+
+namespace lookup {
+
+// Rows [0, usable_rows) of the permuted input A' (the compressed input sorted) and of the permuted table S' (S'[i] =
+// A'[i] where A'[i] first occurs, leftover table values in the repeated rows); usable_rows = n - (blinding_factors + 1).
+// The blinding rows beyond are drawn from the prover's RNG by the caller and are returned as zero here.  An input value
+// missing from the table is upstream's Error::ConstraintSystemFailure: thrown as ConstraintSystemFailure.
+struct ConstraintSystemFailure : Panic {
+    using Panic::Panic;
+};
+inline std::pair<poly::Polynomial, poly::Polynomial> permute_expression_pair(const poly::EvaluationDomain& domain,
+                                                                             uint32_t blinding_factors,
+                                                                             const poly::Polynomial& input_expression,
+                                                                             const poly::Polynomial& table_expression) {
+    const size_t n = size_t(1) << domain.k();
+    if (input_expression.values.size() != n || table_expression.values.size() != n)
+        throw Panic("permute_expression_pair: expressions must have 2^k rows");
+    if (blinding_factors + 1 >= n) throw Panic("permute_expression_pair: no usable rows");
+    const uint32_t usable_rows = (uint32_t)(n - (blinding_factors + 1));
+    Accelerator& acc = Accelerator::get();
+    std::lock_guard<std::mutex> g(acc.lock());
+    const std::vector<Fr> zeros(n, Fr{{0, 0, 0, 0}});
+    const arithmetic::DeviceVec in(acc, input_expression.values), tab(acc, table_expression.values), pin(acc, zeros), ptab(acc, zeros);
+    const int rc = zkhip_lookup_permute_dev(domain.raw(), in.ptr(), tab.ptr(), usable_rows, pin.ptr(), ptab.ptr());
+    if (rc == ZKHIP_ERR_CONSTRAINT) throw ConstraintSystemFailure(zkhip_last_error(acc.ctx()));
+    acc.check(rc, "permute_expression_pair");
+    return {poly::Polynomial{pin.download(n)}, poly::Polynomial{ptab.download(n)}};
+}
+
+}  // namespace lookup
 
 }  // namespace plonk
 }  // namespace halo2

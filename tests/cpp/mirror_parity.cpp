@@ -1,6 +1,8 @@
 // Parity of the C++ mirror (include/zkhip.hpp) against the CPU oracle, on the GPU: reads like the reference's own
 // prover tests would if they compared results -- same calls, same argument order -- with the oracle as the checker.
 // Built by __graft_entry__.build(); run by tests/test_cpp_mirror.py on a machine with a gfx950 device.
+#include <algorithm>
+#include <array>
 #include <cstdio>
 #include <cstdlib>
 #include <random>
@@ -10,6 +12,7 @@
 extern "C" {
 typedef struct odomain odomain;
 void oracle_field_from_canonical(int field, const uint64_t* a, uint64_t* out, size_t n);
+void oracle_field_binop(int field, int op, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n);
 void oracle_g1_to_affine(const uint64_t* jac, uint64_t* out_xy);
 void oracle_g1_bases(uint64_t* out_xy, size_t n);
 void oracle_best_multiexp(const uint64_t* coeffs, const uint64_t* bases, size_t n, int threads, uint64_t* out_jac);
@@ -210,6 +213,70 @@ static void test_evaluate_h() {
     oracle_domain_free(od);
 }
 
+// field arithmetic of the checker: op 0 add, 1 sub, 2 mul
+static Fr fop(int op, const Fr& a, const Fr& b) {
+    Fr o;
+    oracle_field_binop(0, op, a.l, b.l, o.l, 1);
+    return o;
+}
+static Fr horner(const std::vector<Fr>& p, const Fr& x) {
+    Fr acc = mont(0);
+    for (size_t i = p.size(); i-- > 0;) acc = fop(0, fop(2, acc, x), p[i]);
+    return acc;
+}
+static std::vector<std::array<uint64_t, 4>> multiset(const std::vector<Fr>& v, size_t rows) {
+    std::vector<std::array<uint64_t, 4>> m(rows);
+    for (size_t i = 0; i < rows; i++) std::memcpy(m[i].data(), v[i].l, 32);
+    std::sort(m.begin(), m.end());
+    return m;
+}
+
+static void test_openings_and_lookup() {
+    const Polynomial a = rand_poly(1537);
+    const Fr x = rand_fr(), b = rand_fr();
+    CHECK(arithmetic::eval_polynomial(a.values, x) == horner(a.values, x), "eval_polynomial(poly, point) == Horner");
+    CHECK(arithmetic::eval_polynomial({}, x) == mont(0), "eval_polynomial of the empty polynomial is zero");
+    // a(X) - a(b) = q(X) (X - b), checked at a random point
+    const std::vector<Fr> q = arithmetic::kate_division(a.values, b);
+    CHECK(q.size() == a.values.size() - 1, "kate_division returns len - 1 coefficients");
+    CHECK(fop(1, horner(a.values, x), horner(a.values, b)) == fop(2, horner(q, x), fop(1, x, b)), "kate_division(a, b): a(x) - a(b) == q(x) (x - b)");
+    CHECK(panics([&] { arithmetic::kate_division({}, b); }), "kate_division panics on the empty polynomial");
+
+    std::vector<Fr> v = rand_poly(1000).values, orig;
+    v[3] = v[999] = mont(0);
+    orig = v;
+    arithmetic::batch_invert(v);
+    bool ok = v[3] == mont(0) && v[999] == mont(0);
+    for (size_t i = 0; i < v.size(); i++)
+        if (!(orig[i] == mont(0))) ok = ok && fop(2, v[i], orig[i]) == mont(1);
+    CHECK(ok, "batch_invert: x * x^-1 == 1, zeros stay zero");
+
+    // lookup: every input value occurs in the table
+    const uint32_t k = 9, blinding = 5;
+    const size_t n = size_t(1) << k, usable = n - (blinding + 1);
+    poly::EvaluationDomain domain(4, k);
+    Polynomial table = rand_poly(n), input;
+    for (size_t i = 0; i < n; i++)
+        if (i % 7 == 3) table.values[i] = table.values[i - 1];       // repeated table values
+    input.values.resize(n);
+    for (size_t i = 0; i < n; i++) input.values[i] = table.values[(i * i + 3 * i) % (usable / 4)];
+    const auto permuted = plonk::lookup::permute_expression_pair(domain, blinding, input, table);
+    const Polynomial &pa = permuted.first, &ps = permuted.second;
+    CHECK(multiset(pa.values, usable) == multiset(input.values, usable), "permuted input is a permutation of the input's usable rows");
+    CHECK(multiset(ps.values, usable) == multiset(table.values, usable), "permuted table is a permutation of the table's usable rows");
+    ok = pa.values[0] == ps.values[0];
+    for (size_t i = 1; i < usable; i++) ok = ok && (pa.values[i] == ps.values[i] || pa.values[i] == pa.values[i - 1]);
+    CHECK(ok, "A'[i] == S'[i] or A'[i] == A'[i-1] on every usable row");
+    ok = true;
+    for (size_t i = usable; i < n; i++) ok = ok && pa.values[i] == mont(0) && ps.values[i] == mont(0);
+    CHECK(ok, "blinding rows are left to the caller");
+    input.values[17] = rand_fr();
+    bool failure = false;
+    try { plonk::lookup::permute_expression_pair(domain, blinding, input, table); }
+    catch (const plonk::lookup::ConstraintSystemFailure&) { failure = true; }
+    CHECK(failure, "an input value missing from the table is a ConstraintSystemFailure");
+}
+
 int main(int argc, char** argv) {
     std::setvbuf(stdout, nullptr, _IOLBF, 0);
     if (argc > 1 && std::string(argv[1]) == "--list") {     // no device needed: proves the binary links and loads
@@ -220,6 +287,7 @@ int main(int argc, char** argv) {
         test_best_multiexp();
         test_best_fft_and_domain();
         test_evaluate_h();
+        test_openings_and_lookup();
     } catch (const std::exception& e) {
         std::printf("FAIL  uncaught: %s\n", e.what());
         return 2;

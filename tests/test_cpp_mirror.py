@@ -35,4 +35,4 @@ def test_cpp_mirror_parity_against_the_oracle(mirror_bin):
     assert out.returncode == 0, out.stdout + out.stderr
     lines = out.stdout.splitlines()
     assert lines[-1].startswith("all ok") and not any(l.startswith("FAIL") for l in lines)
-    assert sum(l.startswith("ok") for l in lines) >= 21
+    assert sum(l.startswith("ok") for l in lines) >= 32
