@@ -70,7 +70,8 @@ def scalars_by_distribution(ctx, n, which, seed):
 
 
 def cpu_baseline(steps_hint):
-    """Restated CPU prover (oracle/oracle.c, OpenMP) on the same workload: full 2^19 MSM and 2^19 -> 2^21 coset NTT."""
+    """Restated CPU prover (oracle/oracle.c, OpenMP) on the same workload: full 2^19 MSM, 2^19 -> 2^21 coset NTT, and
+    evaluate_h on a bounded sample of rows."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import coracle as co
     threads = min(os.cpu_count() or 1, 16)
@@ -86,14 +87,46 @@ def cpu_baseline(steps_hint):
     t0 = time.time()
     dom.coeff_to_extended(sc)
     t_ntt = time.time() - t0
+    # evaluate_h: the bench's constraint system on a domain of 2^15 rows (a sixteenth of the 2^21 extended rows of the
+    # GPU measurement; the cost per extended row does not depend on k)
+    ke = 15
+    cs = bench_cs()
+    od = co.Domain(cs.degree(), ke, threads=threads)
+    en_e = 1 << od.extended_k
+
+    def col():
+        a = rng.integers(0, 2 ** 64, size=(en_e, 4), dtype=np.uint64)
+        a[:, 3] &= np.uint64(0x0FFFFFFFFFFFFFFF)
+        return a
+    call = evalh_host.EvalhCall(cs)
+    call.fixed = [col() for _ in range(cs.num_fixed_columns)]
+    call.advice = [col() for _ in range(cs.num_advice_columns)]
+    call.instance = [col() for _ in range(cs.num_instance_columns)]
+    call.challenges = col()[:cs.num_challenges]
+    call.y, call.beta, call.gamma, call.theta = (r for r in col()[:4])
+    call.l0, call.l_last, call.l_active = col(), col(), col()
+    call.lookups = [(col(), col(), col()) for _ in cs.lookups]
+    call.perm_sigma = [col() for _ in cs.permutation_columns]
+    call.perm_z = [col() for _ in range(cs.num_permutation_sets())]
+    desc = call.build(ffi.MEM_HOST, ffi.FORM_EXTENDED)
+    t0 = time.time()
+    od.evaluate_h(desc)
+    t_evalh = time.time() - t0
     return {"value": n / t_msm / 1e6, "unit": "Mpts/s", "cores": threads, "kind": "port",
-            "sample": "one full 2^19 MSM (uniform scalars) and one 2^19->2^21 coset NTT, restated C/OpenMP prover",
-            "msm_s": t_msm, "coset_ntt_s": t_ntt, "coset_ntt_GBps": 32.0 * (n + (1 << LOG_EXT)) / t_ntt / 1e9}
+            "sample": "one full 2^19 MSM (uniform scalars), one 2^19->2^21 coset NTT and evaluate_h of the bench's constraint "
+                      "system over 2^17 extended rows (k = 15), restated C/OpenMP prover",
+            "msm_s": t_msm, "coset_ntt_s": t_ntt, "coset_ntt_GBps": 32.0 * (n + (1 << LOG_EXT)) / t_ntt / 1e9,
+            "evaluate_h_sample_s": t_evalh, "evaluate_h_extended_rows_per_s": en_e / t_evalh,
+            "evaluate_h_s_at_2p21_rows_extrapolated": t_evalh * (1 << LOG_EXT) / en_e}
+
+
+def bench_cs():
+    return synthetic.synthetic_cs(num_advice=64, num_fixed=16, num_instance=1, num_gate_polys=256, max_degree=5,
+                                  rotations=(-2, -1, 0, 1), num_lookups=16, lookup_width=3, num_perm_cols=8)
 
 
 def build_evalh(ctx, dom, gen, k, cosets=None):
-    cs = synthetic.synthetic_cs(num_advice=64, num_fixed=16, num_instance=1, num_gate_polys=256, max_degree=5,
-                                rotations=(-2, -1, 0, 1), num_lookups=16, lookup_width=3, num_perm_cols=8)
+    cs = bench_cs()
     assert cs.degree() == 5
     # all cosets: the whole extended domain; a subset: the compact layout of those cosets (2^k rows each)
     en = dom.extended_len if cosets is None else dom.n * len(cosets)
