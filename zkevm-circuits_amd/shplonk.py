@@ -16,6 +16,8 @@ coefficients.
 """
 from __future__ import annotations
 
+import functools
+
 import numpy as np
 
 from .evalh_host import fr_to_mont_limbs
@@ -35,12 +37,12 @@ def _inv(x: int) -> int:
     return pow(x, P - 2, P)
 
 
-def lagrange_interpolate(points, evals):
-    """`arithmetic::lagrange_interpolate`: coefficients, lowest first, of the polynomial of degree < len(points)."""
+@functools.lru_cache(maxsize=256)
+def _lagrange_basis(points):
+    """Coefficients of the Lagrange basis polynomials of a point tuple, each already divided by its denominator: every
+    polynomial opened at the same rotation set shares them."""
     n = len(points)
-    if n == 1:
-        return [evals[0] % P]
-    out = [0] * n
+    basis = []
     for j in range(n):
         num, den = [1], 1
         for k in range(n):
@@ -52,10 +54,18 @@ def lagrange_interpolate(points, evals):
                 nxt[i] = (nxt[i] - c * points[k]) % P
             num = nxt
             den = den * (points[j] - points[k]) % P
-        scale = evals[j] * _inv(den) % P
-        for i in range(n):
-            out[i] = (out[i] + num[i] * scale) % P
-    return out
+        inv = _inv(den)
+        basis.append([c * inv % P for c in num])
+    return basis
+
+
+def lagrange_interpolate(points, evals):
+    """`arithmetic::lagrange_interpolate`: coefficients, lowest first, of the polynomial of degree < len(points)."""
+    n = len(points)
+    if n == 1:
+        return [evals[0] % P]
+    basis = _lagrange_basis(tuple(points))
+    return [sum(evals[j] * basis[j][i] for j in range(n)) % P for i in range(n)]
 
 
 def evaluate_vanishing_polynomial(roots, z: int) -> int:
