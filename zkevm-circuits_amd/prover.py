@@ -1,0 +1,384 @@
+"""Host mirror of `halo2_proofs::plonk::{keygen::{keygen_vk, keygen_pk}, prover::create_proof}` over the C ABI.
+
+The reference proves with
+`create_proof::<KZGCommitmentScheme<Bn256>, ProverSHPLONK<Bn256>, Challenge255<_>, _, Blake2bWrite<_,_,_>, C>(&params,
+&pk, &[circuit], &[&[&instance]], rng, &mut transcript, ..)` (/root/reference/prover/src/test/proof_test.rs:297-306,
+/root/reference/zkevm-circuits/benches/benchmark_list/main.rs:265-281).  This module runs the same phases in the same
+order for one circuit whose witness is already assigned, with every operation over 2^k or 2^extended_k field elements
+on the device: commitments (`zkhip_msm_batch_dev`), lookup compression and the permuted columns, the grand products,
+`coeff_to_extended`, `evaluate_h`, the division by the vanishing polynomial, evaluations at x and the SHPLONK multi-open.
+What stays on the host is what upstream does on single field elements: the transcript, the RNG and the bookkeeping.
+
+Differences from upstream that a byte-for-byte comparison would have to remove (none of them touches the device work):
+the verifying key's `transcript_repr` is a stand-in digest of its commitments (upstream hashes a debug print of the
+key), the random polynomial of the vanishing argument is drawn coefficient by coefficient from the one RNG (upstream
+draws it chunk-parallel from per-thread streams), all advice columns belong to the first phase, and the order of the
+column queries follows first appearance in gates, lookups and permutation columns.  The compressed point encoding
+follows halo2curves 0.6.1 as published (little-endian x, sign of y in bit 6 and identity in bit 7 of the last byte).
+"""
+from __future__ import annotations
+
+import hashlib
+
+import numpy as np
+
+from . import evalh_host, ffi, keygen as kg, shplonk
+from .evalh_host import fr_to_mont_limbs
+from .plonk import ANY_ADVICE, ANY_FIXED, ANY_INSTANCE, FR_MODULUS, ConstraintSystem
+
+P = FR_MODULUS
+FQ_MODULUS = 0x30644E72E131A029B85045B68181585D97816A916871CA8D3C208C16D87CFD47
+FR_DELTA = pow(7, 1 << 28, P)
+_FR_RINV = pow(1 << 256, P - 2, P)
+_FQ_RINV = pow(1 << 256, FQ_MODULUS - 2, FQ_MODULUS)
+
+
+def fr_from_mont_limbs(limbs) -> int:
+    return sum(int(w) << (64 * j) for j, w in enumerate(limbs)) * _FR_RINV % P
+
+
+def fq_from_mont_limbs(limbs) -> int:
+    return sum(int(w) << (64 * j) for j, w in enumerate(limbs)) * _FQ_RINV % FQ_MODULUS
+
+
+def fr_limbs(vals) -> np.ndarray:
+    return np.array([fr_to_mont_limbs(v) for v in vals], dtype=np.uint64).reshape(len(vals), 4)
+
+
+def compress_point(xy) -> bytes:
+    """`G1Affine::to_bytes`: xy = (x, y) canonical integers, None for the identity."""
+    if xy is None:
+        b = bytearray(32)
+        b[31] |= 0x80
+        return bytes(b)
+    b = bytearray(xy[0].to_bytes(32, "little"))
+    b[31] |= (xy[1] & 1) << 6
+    return bytes(b)
+
+
+class Blake2bWrite:
+    """`transcript::Blake2bWrite<Vec<u8>, G1Affine, Challenge255<_>>`."""
+
+    PREFIX_CHALLENGE, PREFIX_POINT, PREFIX_SCALAR = b"\x00", b"\x01", b"\x02"
+
+    def __init__(self):
+        self.state = hashlib.blake2b(digest_size=64, person=b"Halo2-Transcript")
+        self.out = bytearray()
+
+    def squeeze_challenge(self) -> int:
+        self.state.update(self.PREFIX_CHALLENGE)
+        return int.from_bytes(self.state.copy().digest(), "little") % P     # Challenge255: from_uniform_bytes
+
+    def common_point(self, xy):
+        if xy is None:
+            raise ValueError("cannot write points at infinity to the transcript")
+        self.state.update(self.PREFIX_POINT)
+        self.state.update(xy[0].to_bytes(32, "little"))
+        self.state.update(xy[1].to_bytes(32, "little"))
+
+    def common_scalar(self, v: int):
+        self.state.update(self.PREFIX_SCALAR)
+        self.state.update((v % P).to_bytes(32, "little"))
+
+    def write_point(self, point):
+        """point: Jacobian (12) or affine (8) Montgomery limbs as the C ABI returns them."""
+        xy = affine_ints(point)
+        self.common_point(xy)
+        self.out += compress_point(xy)
+
+    def write_scalar(self, v: int):
+        self.common_scalar(v)
+        self.out += (v % P).to_bytes(32, "little")
+
+    def finalize(self) -> bytes:
+        return bytes(self.out)
+
+
+def affine_ints(point):
+    """Jacobian (12 limbs) or affine (8 limbs) point -> (x, y) canonical integers, None for the identity."""
+    point = np.asarray(point, dtype=np.uint64).reshape(-1)
+    if point.size == 12:
+        out = np.zeros(8, dtype=np.uint64)
+        rc = ffi.lib().zkhip_g1_to_affine(ffi._p(np.ascontiguousarray(point)), ffi._p(out))
+        if rc != 0:
+            raise ffi.ZkhipError(f"zkhip_g1_to_affine: status {rc}")
+        point = out
+    if not point.any():
+        return None
+    return fq_from_mont_limbs(point[:4]), fq_from_mont_limbs(point[4:])
+
+
+class FieldRng:
+    """`Fr::random(rng)` stand-in: 64 uniform bytes reduced mod r, drawn from a seeded numpy generator."""
+
+    def __init__(self, seed: int):
+        self.g = np.random.default_rng(seed)
+
+    def fr(self) -> int:
+        return int.from_bytes(self.g.bytes(64), "little") % P
+
+
+def collect_queries(cs: ConstraintSystem):
+    """(advice_queries, fixed_queries, instance_queries) as [(column, rotation)], each in order of first appearance."""
+    out = {"advice": [], "fixed": [], "instance": []}
+
+    def add(kind, q):
+        if q not in out[kind]:
+            out[kind].append(q)
+
+    def walk(e):
+        t = e[0]
+        if t in out:
+            add(t, (e[1], e[2]))
+        elif t in ("neg", "scaled"):
+            walk(e[1])
+        elif t in ("sum", "prod"):
+            walk(e[1])
+            walk(e[2])
+
+    for gate in cs.gates:
+        for poly in gate:
+            walk(poly)
+    for lk in cs.lookups:
+        for e in lk.input_expressions + lk.table_expressions:
+            walk(e)
+    names = {ANY_ADVICE: "advice", ANY_FIXED: "fixed", ANY_INSTANCE: "instance"}
+    for kind, idx in cs.permutation_columns:
+        add(names[kind], (idx, 0))
+    return out["advice"], out["fixed"], out["instance"]
+
+
+class ParamsKZG:
+    """`ParamsKZG<Bn256>` on one device: the monomial-basis SRS `g` and its Lagrange form, both registered for MSM."""
+
+    def __init__(self, ctx, dom, g_affine):
+        self.ctx, self.k, self.n = ctx, dom.k, dom.n
+        g_affine = np.ascontiguousarray(g_affine, dtype=np.uint64).reshape(self.n, 8)
+        self.g = ctx.register_bases(g_affine)
+        self.g_lagrange = ctx.register_bases(kg.g_to_lagrange(ctx, dom, g_affine))
+
+    def commit(self, d_polys):
+        return self.ctx.msm_batch_dev(self.g, list(d_polys), self.n)
+
+    def commit_lagrange(self, d_polys):
+        return self.ctx.msm_batch_dev(self.g_lagrange, list(d_polys), self.n)
+
+    def close(self):
+        self.ctx.release_bases(self.g)
+        self.ctx.release_bases(self.g_lagrange)
+
+
+class ProvingKey:
+    """`ProvingKey<G1Affine>`: the verifying key's commitments plus the device-resident key polynomials."""
+
+    def __init__(self):
+        self.cs = None
+        self.polys = None                     # keygen.ProvingKeyPolys
+        self.fixed_values = []                # device pointers, Lagrange basis
+        self.fixed_commitments, self.permutation_commitments = [], []      # (x, y) integers
+        self.transcript_repr = 0
+
+    def pointers(self):
+        return self.polys.pointers() + self.fixed_values
+
+
+def keygen(ctx, dom, params: ParamsKZG, cs: ConstraintSystem, fixed, assembly) -> ProvingKey:
+    """`keygen_vk` + `keygen_pk` for assigned fixed columns (lists of n canonical integers) and copy constraints."""
+    n = dom.n
+    if n < cs.minimum_rows():
+        raise ValueError("not enough rows available")
+    if len(fixed) != cs.num_fixed_columns or any(len(c) != n for c in fixed):
+        raise ValueError("fixed columns do not match the constraint system")
+    pk = ProvingKey()
+    pk.cs = cs
+    fixed_limbs = [fr_limbs(c) for c in fixed]
+    pk.polys = kg.keygen_polys(ctx, dom, fixed_limbs, assembly if cs.permutation_columns else None, cs.blinding_factors())
+    pk.fixed_values = [ctx.upload(a) for a in fixed_limbs]
+    if pk.fixed_values:
+        pk.fixed_commitments = [affine_ints(j) for j in params.commit_lagrange(pk.fixed_values)]
+    if pk.polys.permutations:
+        pk.permutation_commitments = [affine_ints(j) for j in params.commit_lagrange(pk.polys.permutations)]
+    h = hashlib.blake2b(digest_size=64, person=b"Halo2-Verify-Key")
+    h.update(dom.k.to_bytes(4, "little"))
+    for c in pk.fixed_commitments + pk.permutation_commitments:
+        h.update(compress_point(c))
+    pk.transcript_repr = int.from_bytes(h.digest(), "little") % P
+    return pk
+
+
+def create_proof(ctx, dom, params: ParamsKZG, pk: ProvingKey, advice, instance, rng: FieldRng, transcript: Blake2bWrite):
+    """One circuit.  advice: per column the values of the usable rows (canonical integers; the remaining rows are
+    blinding); instance: per column at most that many values.  Writes the proof into `transcript`."""
+    cs = pk.cs
+    n, en = dom.n, dom.extended_len
+    bf = cs.blinding_factors()
+    usable = n - (bf + 1)
+    if len(advice) != cs.num_advice_columns or len(instance) != cs.num_instance_columns:
+        raise ValueError("InvalidInstances / advice columns do not match the constraint system")
+    if any(len(c) != usable for c in advice) or any(len(c) > usable for c in instance):
+        raise ValueError("InstanceTooLarge / advice columns must hold the usable rows")
+    omega = fr_from_mont_limbs(dom.constant(0))
+    owned = []
+
+    def alloc(rows):
+        p = ctx.alloc(rows * 32)
+        owned.append(p)
+        return p
+
+    def upload_ints(vals):
+        p = ctx.upload(fr_limbs(vals))
+        owned.append(p)
+        return p
+
+    def limb(v):
+        return np.array(fr_to_mont_limbs(v), dtype=np.uint64)
+
+    def blind_rows(d_col, first_row):
+        ctx.upload(fr_limbs([rng.fr() for _ in range(n - first_row)]), d_col + first_row * 32)
+
+    try:
+        # ---- instances and advice ---------------------------------------------------------------------------
+        transcript.common_scalar(pk.transcript_repr)
+        inst = []
+        for col in instance:
+            for v in col:
+                transcript.common_scalar(v)
+            inst.append(upload_ints(list(col) + [0] * (n - len(col))))
+        adv = [upload_ints(list(col) + [rng.fr() for _ in range(n - usable)]) for col in advice]
+        for _ in adv:
+            rng.fr()                                            # one Blind per column: drawn, unused by KZG
+        if adv:
+            for jac in params.commit_lagrange(adv):
+                transcript.write_point(jac)
+        challenges = [transcript.squeeze_challenge() for _ in range(cs.num_challenges)]
+        ch_limbs = fr_limbs(challenges) if challenges else np.zeros((0, 4), dtype=np.uint64)
+        theta = transcript.squeeze_challenge()
+
+        # ---- lookups: compressed expressions, permuted columns ----------------------------------------------
+        lookups = []
+        for lk in cs.lookups:
+            d_in, d_tb, d_pa, d_ps = alloc(n), alloc(n), alloc(n), alloc(n)
+            for exprs, d_out in ((lk.input_expressions, d_in), (lk.table_expressions, d_tb)):
+                call = evalh_host.lookup_compress_call(cs, exprs, pk.fixed_values, adv, inst, ch_limbs, limb(theta))
+                dom.evaluate_h(call.build(ffi.MEM_DEVICE, ffi.FORM_EXTENDED), d_out)
+            dom.lookup_permute_dev(d_in, d_tb, usable, d_pa, d_ps)
+            blind_rows(d_pa, usable)
+            blind_rows(d_ps, usable)
+            rng.fr(), rng.fr()
+            for jac in params.commit_lagrange([d_pa, d_ps]):
+                transcript.write_point(jac)
+            lookups.append([d_in, d_tb, d_pa, d_ps, 0])
+        beta = transcript.squeeze_challenge()
+        gamma = transcript.squeeze_challenge()
+
+        # ---- permutation argument ---------------------------------------------------------------------------
+        chunk = cs.permutation_chunk_len()
+        pcols = cs.permutation_columns
+        sets = cs.num_permutation_sets()
+        lagrange_of = {ANY_ADVICE: adv, ANY_FIXED: pk.fixed_values, ANY_INSTANCE: inst}
+        perm_z, last_z = [], 1
+        for s in range(sets):
+            cols = pcols[s * chunk:(s + 1) * chunk]
+            d_z = alloc(n)
+            dom.permutation_product_dev([lagrange_of[kind][i] for kind, i in cols],
+                                        pk.polys.permutations[s * chunk:s * chunk + len(cols)], limb(beta), limb(gamma),
+                                        limb(pow(FR_DELTA, s * chunk, P)), limb(last_z), d_z)
+            blind_rows(d_z, usable + 1)
+            last_z = fr_from_mont_limbs(ctx.download(d_z + usable * 32, (1, 4))[0])
+            rng.fr()
+            perm_z.append(d_z)
+        if perm_z:
+            for jac in params.commit_lagrange(perm_z):
+                transcript.write_point(jac)
+
+        # ---- lookup grand products --------------------------------------------------------------------------
+        for lk in lookups:
+            d_z = alloc(n)
+            dom.lookup_product_dev(lk[0], lk[1], lk[2], lk[3], limb(beta), limb(gamma), d_z)
+            blind_rows(d_z, usable + 1)
+            rng.fr()
+            lk[4] = d_z
+            transcript.write_point(params.commit_lagrange([d_z])[0])
+
+        # ---- vanishing argument: random polynomial ----------------------------------------------------------
+        d_random = upload_ints([rng.fr() for _ in range(n)])
+        rng.fr()
+        transcript.write_point(params.commit([d_random])[0])
+        y = transcript.squeeze_challenge()
+
+        # ---- coefficient form and extended cosets -----------------------------------------------------------
+        per_lookup = [(lk[4], lk[2], lk[3]) for lk in lookups]
+        coeff_polys = adv + inst + [p for t in per_lookup for p in t] + perm_z
+        for p in coeff_polys:
+            dom.lagrange_to_coeff_dev(p)
+        ext = {}
+        for p in coeff_polys:
+            ext[p] = alloc(en)
+            dom.coeff_to_extended_dev(p, ext[p])
+
+        call = evalh_host.EvalhCall(cs)
+        call.fixed = pk.polys.fixed_cosets
+        call.advice = [ext[p] for p in adv]
+        call.instance = [ext[p] for p in inst]
+        call.challenges = ch_limbs
+        call.y, call.beta, call.gamma, call.theta = limb(y), limb(beta), limb(gamma), limb(theta)
+        call.l0, call.l_last, call.l_active = pk.polys.l0, pk.polys.l_last, pk.polys.l_active_row
+        call.lookups = [tuple(ext[p] for p in t) for t in per_lookup]
+        call.perm_sigma = pk.polys.permutation_cosets
+        call.perm_z = [ext[p] for p in perm_z]
+        d_h = alloc(en)
+        dom.evaluate_h(call.build(ffi.MEM_DEVICE, ffi.FORM_EXTENDED), d_h)
+        dom.divide_by_vanishing_poly_dev(d_h)
+        pieces = dom.quotient_poly_degree
+        d_hc = alloc(n * pieces)
+        dom.extended_to_coeff_dev(d_h, d_hc)
+        h_pieces = [d_hc + i * n * 32 for i in range(pieces)]
+        for _ in h_pieces:
+            rng.fr()
+        for jac in params.commit(h_pieces):
+            transcript.write_point(jac)
+        x = transcript.squeeze_challenge()
+
+        # ---- evaluations at x -------------------------------------------------------------------------------
+        adv_q, fix_q, _ = collect_queries(cs)
+        last_rot = -(bf + 1)
+        xn = pow(x, n, P)
+        d_hpoly = alloc(n)
+        ctx.poly_lincomb_dev(h_pieces, [n] * pieces, fr_limbs([pow(xn, i, P) for i in range(pieces)]), n, d_hpoly)
+
+        def point(rot):
+            return x * pow(omega, rot % n, P) % P
+
+        groups = {
+            "advice": [(adv[c], r) for c, r in adv_q],
+            "fixed": [(pk.polys.fixed_polys[c], r) for c, r in fix_q],
+            "random": [(d_random, 0)],
+            "sigma": [(p, 0) for p in pk.polys.permutation_polys],
+            "perm": [q for s, z in enumerate(perm_z)
+                     for q in [(z, 0), (z, 1)] + ([(z, last_rot)] if s + 1 < sets else [])],
+            "lookup": [q for z, pa, ps in per_lookup for q in [(z, 0), (z, 1), (pa, 0), (pa, -1), (ps, 0)]],
+            "h": [(d_hpoly, 0)],
+        }
+        flat = [q for name in ("advice", "fixed", "random", "sigma", "perm", "lookup", "h") for q in groups[name]]
+        vals = ctx.eval_polynomials_dev([p for p, _ in flat], fr_limbs([point(r) for _, r in flat]), n)
+        evals = {}
+        for (p, r), v in zip(flat, vals):
+            evals[(p, r)] = fr_from_mont_limbs(v)
+        for name in ("advice", "fixed", "random", "sigma", "perm", "lookup"):
+            for q in groups[name]:
+                transcript.write_scalar(evals[q])
+
+        # ---- multi-open: queries in upstream's order ---------------------------------------------------------
+        order = list(groups["advice"]) + list(groups["perm"])
+        for z, pa, ps in per_lookup:
+            order += [(z, 0), (pa, 0), (ps, 0), (pa, -1), (z, 1)]
+        order += groups["fixed"] + groups["sigma"] + groups["h"] + groups["random"]
+        queries = [shplonk.Query(p, point(r), evals[(p, r)]) for p, r in order]
+        polys = {p: p for p, _ in order}
+        outs = shplonk.ProverSHPLONK(ctx, params.g, n).create_proof(polys, queries, transcript)
+        owned.extend(outs)
+        ctx.sync()
+    finally:
+        for p in owned:
+            ctx.free(p)
+    return transcript.finalize()
