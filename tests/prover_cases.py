@@ -1,0 +1,63 @@
+"""The test circuit of the end-to-end prover tests: constraint system, a satisfying witness, a KZG test SRS with a
+known trapdoor.  Shared by the GPU suite (which proves), the CPU suite (which verifies the committed proof fixture) and
+tests/golden/gen_proof_golden.py."""
+import numpy as np
+
+import bn254 as bn
+from util import affine_arr, affine_pt, fr_arr
+
+from zkevm_circuits_amd import keygen, plonk
+
+P = bn.FR_MODULUS
+TAU = 0x1F3A9C0D5E6B7788990A1B2C3D4E5F60718293A4B5C6D7E8F9  # trapdoor of the test SRS
+
+
+def circuit():
+    from zkevm_circuits_amd.plonk import Advice, Challenge, Fixed, Product, Sub
+    a, b, c = Advice(0), Advice(1), Advice(2)
+    q, q_acc = Fixed(0), Fixed(1)
+    mul = Sub(Product(a, b), c)
+    cs = plonk.ConstraintSystem(num_fixed_columns=4, num_advice_columns=4, num_instance_columns=1, num_challenges=1)
+    cs.gates = [[Product(q, mul), Product(q, Product(Challenge(0), mul))],
+                [Product(q_acc, Sub(Sub(Advice(3, 1), Advice(3)), c))]]
+    cs.lookups = [plonk.Lookup([Product(q, a), Product(q, b)], [Fixed(2), Fixed(3)])]
+    cs.permutation_columns = [(plonk.ANY_ADVICE, 3), (plonk.ANY_INSTANCE, 0), (plonk.ANY_ADVICE, 0), (plonk.ANY_ADVICE, 2)]
+    return cs
+
+
+def witness(cs, n, seed):
+    """rows < m are active: b = a^2 (lookup into the table of squares), c = a b, s accumulates c; the copy constraints
+    tie s[0] and s[m] to the instance column and a few cells of a and c to each other."""
+    usable = n - (cs.blinding_factors() + 1)
+    m = min(usable - 2, 3000)
+    rng = np.random.default_rng(seed)
+    a = [int(v) for v in rng.integers(0, 11, size=m)] + [0] * (usable - m)
+    a[0], a[3] = 2, 8
+    a[4] = a[1]
+    b = [v * v for v in a]
+    c = [v * w for v, w in zip(a, b)]
+    s = [5]
+    for i in range(m):
+        s.append(s[-1] + c[i])
+    s += [0] * (usable - len(s))
+    fixed = [[1] * m + [0] * (n - m), [1] * m + [0] * (n - m),
+             [i if i < usable else 0 for i in range(n)], [i * i if i < usable else 0 for i in range(n)]]
+    asm = keygen.Assembly(n, len(cs.permutation_columns))       # argument columns: s, instance, a, c
+    asm.copy(0, 0, 1, 0)
+    asm.copy(0, m, 1, 1)
+    asm.copy(2, 1, 2, 4)
+    asm.copy(3, 0, 2, 3)
+    return [a, b, c, s], [[5, s[m]]], fixed, asm
+
+
+def srs(co, n):
+    """g[i] = tau^i G: the scalar multiplications by the C oracle (one-term multiexps), spot-checked against the
+    big-int model"""
+    gen = affine_arr([bn.G1_GENERATOR])
+    g = np.empty((n, 8), dtype=np.uint64)
+    power = 1
+    for i in range(n):
+        g[i] = co.g1_to_affine(co.best_multiexp(fr_arr([power]), gen))
+        power = power * TAU % P
+    assert affine_pt(g[3]) == bn.g1_mul(bn.G1_GENERATOR, pow(TAU, 3, P))
+    return g
