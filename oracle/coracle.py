@@ -74,6 +74,14 @@ def g1_bases(n):
     return out
 
 
+def g1_powers_of_tau(tau_limbs, n, threads=1):
+    """[tau^i] G for i < n (affine); tau_limbs: Montgomery Fr limbs"""
+    t = _u64(tau_limbs)
+    out = np.empty((n, 8), dtype=np.uint64)
+    lib().oracle_g1_powers_of_tau(_p(t), C.c_size_t(n), C.c_int(threads), _p(out))
+    return out
+
+
 def g1_to_affine(jac):
     jac = _u64(jac)
     out = np.empty(8, dtype=np.uint64)

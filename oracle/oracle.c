@@ -373,6 +373,54 @@ void oracle_g1_bases(uint64_t* out_xy, size_t n) {
     free(pre);
 }
 
+/* out[i] = [tau^i] G for i < n: the monomial-basis KZG test SRS of a known trapdoor (what upstream's
+ * ParamsKZG::unsafe_setup computes from a random s).  Fixed-base multiplication from a table of d * 256^w * G. */
+void oracle_g1_powers_of_tau(const uint64_t* tau_mont, size_t n, int threads, uint64_t* out_xy) {
+    enum { WIN = 32, DIG = 256 };
+    g1a* table = malloc((size_t)WIN * DIG * sizeof(g1a));
+    g1j base;
+    g1a g;
+    g.x = f_from_u64(Q, 1);
+    g.y = f_from_u64(Q, 2);
+    g1j_set_identity(&base);
+    g1j_add_mixed(&base, &base, &g);
+    for (int w = 0; w < WIN; w++) {
+        g1a b;
+        g1j_to_affine(&b, &base);
+        g1j acc;
+        g1j_set_identity(&acc);
+        memset(&table[w * DIG], 0, sizeof(g1a));
+        for (int d = 1; d < DIG; d++) {
+            g1j_add_mixed(&acc, &acc, &b);
+            g1j_to_affine(&table[w * DIG + d], &acc);
+        }
+        for (int j = 0; j < 8; j++) g1j_double(&base, &base);
+    }
+    fe tau;
+    memcpy(tau.l, tau_mont, 32);
+    if (threads < 1) threads = 1;
+    size_t chunk = (n + (size_t)threads - 1) / (size_t)threads;
+#pragma omp parallel for num_threads(threads) schedule(static, 1)
+    for (int t = 0; t < threads; t++) {
+        size_t lo = (size_t)t * chunk, hi = lo + chunk < n ? lo + chunk : n;
+        if (lo >= hi) continue;
+        fe power = f_pow_u64(&FR, &tau, (uint64_t)lo);
+        for (size_t i = lo; i < hi; i++) {
+            uint64_t repr[4];
+            f_to_canonical(&FR, repr, &power);
+            g1j acc;
+            g1j_set_identity(&acc);
+            for (int w = 0; w < WIN; w++) {
+                unsigned d = (unsigned)((repr[w / 8] >> (8 * (w % 8))) & 0xff);
+                if (d) g1j_add_mixed(&acc, &acc, &table[w * DIG + d]);
+            }
+            g1j_to_affine((g1a*)(out_xy + 8 * i), &acc);
+            f_mul(&FR, &power, &power, &tau);
+        }
+    }
+    free(table);
+}
+
 /* ------------------------------------------------------------------ multiexp -------------------- */
 static inline uint64_t get_at(int segment, int c, const uint64_t repr[4]) {
     int skip_bits = segment * c;

@@ -51,13 +51,8 @@ def witness(cs, n, seed):
 
 
 def srs(co, n):
-    """g[i] = tau^i G: the scalar multiplications by the C oracle (one-term multiexps), spot-checked against the
-    big-int model"""
-    gen = affine_arr([bn.G1_GENERATOR])
-    g = np.empty((n, 8), dtype=np.uint64)
-    power = 1
-    for i in range(n):
-        g[i] = co.g1_to_affine(co.best_multiexp(fr_arr([power]), gen))
-        power = power * TAU % P
-    assert affine_pt(g[3]) == bn.g1_mul(bn.G1_GENERATOR, pow(TAU, 3, P))
+    """g[i] = tau^i G by the C oracle's fixed-base multiplication, spot-checked against the big-int model"""
+    g = co.g1_powers_of_tau(fr_arr([TAU])[0], n, threads=min(16, co.max_threads()))
+    for i in (0, 3, n - 1):
+        assert affine_pt(g[i]) == bn.g1_mul(bn.G1_GENERATOR, pow(TAU, i, P))
     return g

@@ -125,3 +125,36 @@ def test_create_proof_argument_checks(ctx, setup):
         _prove(ctx, setup, advice, [[0] * dom.n])
     with pytest.raises(ValueError):
         prover.keygen(ctx, dom, params, cs, [[0] * dom.n], None)
+
+
+def test_full_size_proof_verifies(ctx, co):
+    """k = 19, the reference's circuit size (/root/reference/zkevm-circuits/src/constant.rs:10): SRS of 2^19 points
+    with its Lagrange form from the device's G1 transform, key generation, create_proof over 2^19 rows and the 2^21
+    extended domain, and the verifier model on the resulting bytes"""
+    import time
+    k = 19
+    cs = _circuit()
+    dom = zk.Domain(ctx, cs.degree(), k)
+    t0 = time.perf_counter()
+    g = _srs(co, dom.n)
+    t1 = time.perf_counter()
+    params = prover.ParamsKZG(ctx, dom, g)
+    t2 = time.perf_counter()
+    advice, instance, fixed, asm = _witness(cs, dom.n, 19)
+    pk = prover.keygen(ctx, dom, params, cs, fixed, asm)
+    t3 = time.perf_counter()
+    proof = prover.create_proof(ctx, dom, params, pk, advice, instance, prover.FieldRng(19), prover.Blake2bWrite())
+    t4 = time.perf_counter()
+    vk = {"fixed_commitments": pk.fixed_commitments, "permutation_commitments": pk.permutation_commitments,
+          "transcript_repr": pk.transcript_repr}
+    vm.verify_proof(cs, k, vk, instance, proof, TAU)
+    print(f"k=19: srs {t1 - t0:.1f} s (CPU), params {t2 - t1:.1f} s, keygen {t3 - t2:.1f} s, create_proof {t4 - t3:.1f} s "
+          f"(host conversions included), verify {time.perf_counter() - t4:.1f} s")
+    bad = bytearray(proof)
+    bad[40] ^= 1
+    with pytest.raises(vm.VerifyError):
+        vm.verify_proof(cs, k, vk, instance, bytes(bad), TAU)
+    for p in pk.pointers():
+        ctx.free(p)
+    params.close()
+    dom.close()

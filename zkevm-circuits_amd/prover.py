@@ -42,7 +42,10 @@ def fq_from_mont_limbs(limbs) -> int:
 
 
 def fr_limbs(vals) -> np.ndarray:
-    return np.array([fr_to_mont_limbs(v) for v in vals], dtype=np.uint64).reshape(len(vals), 4)
+    """canonical integers -> (len, 4) Montgomery limbs"""
+    r = evalh_host.R256
+    buf = b"".join((v % P * r % P).to_bytes(32, "little") for v in vals)
+    return np.frombuffer(buf, dtype=np.uint64).reshape(-1, 4).copy()
 
 
 def compress_point(xy) -> bytes:
