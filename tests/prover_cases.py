@@ -56,3 +56,60 @@ def srs(co, n):
     for i in (0, 3, n - 1):
         assert affine_pt(g[i]) == bn.g1_mul(bn.G1_GENERATOR, pow(TAU, i, P))
     return g
+
+
+def wide_circuit(units, degree9=False):
+    """`units` copies of the circuit above side by side, each with a fifth advice column d = a(-1) + b (a gate with a
+    negative rotation), one lookup per unit, three permutation columns per unit plus the shared instance column;
+    with degree9 one gate polynomial of degree nine (extended domain 8n)."""
+    from zkevm_circuits_amd.plonk import Advice, Challenge, Constant, Fixed, Product, Sub, Sum
+    q, q_acc, q_prev = Fixed(0), Fixed(1), Fixed(4)
+    cs = plonk.ConstraintSystem(num_fixed_columns=5, num_advice_columns=5 * units, num_instance_columns=1, num_challenges=1)
+    for u in range(units):
+        a, b, c, s, d = (Advice(5 * u + j) for j in range(5))
+        mul = Sub(Product(a, b), c)
+        polys = [Product(q, mul), Product(q, Product(Challenge(0), mul))]
+        if degree9 and u == 0:
+            high = Product(q, mul)
+            for term in (a, b, c, s, d, a):
+                high = Product(high, Sum(term, Constant(u + 1)))
+            polys.append(high)
+        cs.gates.append(polys)
+        cs.gates.append([Product(q_acc, Sub(Sub(Advice(5 * u + 3, 1), s), c)),
+                         Product(q_prev, Sub(Sub(d, Advice(5 * u, -1)), b))])
+        cs.lookups.append(plonk.Lookup([Product(q, a), Product(q, b)], [Fixed(2), Fixed(3)]))
+        cs.permutation_columns += [(plonk.ANY_ADVICE, 5 * u + 3), (plonk.ANY_ADVICE, 5 * u), (plonk.ANY_ADVICE, 5 * u + 2)]
+    cs.permutation_columns.append((plonk.ANY_INSTANCE, 0))
+    return cs
+
+
+def wide_witness(cs, n, seed, units):
+    usable = n - (cs.blinding_factors() + 1)
+    m = min(usable - 2, 500)
+    rng = np.random.default_rng(seed)
+    advice, public = [], []
+    asm = keygen.Assembly(n, len(cs.permutation_columns))       # argument columns: (s, a, c) per unit, then the instance
+    inst_col = 3 * units
+    for u in range(units):
+        a = [int(v) for v in rng.integers(0, 11, size=m)] + [0] * (usable - m)
+        a[0], a[3], a[7] = 2, 8, 3
+        a[4] = a[1]
+        b = [v * v for v in a]
+        c = [v * w for v, w in zip(a, b)]
+        s = [5 + u]
+        for i in range(m):
+            s.append(s[-1] + c[i])
+        s += [0] * (usable - len(s))
+        d = [0] + [a[i - 1] + b[i] for i in range(1, m)] + [0] * (usable - m)
+        advice += [a, b, c, s, d]
+        public += [5 + u, s[m]]
+        asm.copy(3 * u, 0, inst_col, 2 * u)
+        asm.copy(3 * u, m, inst_col, 2 * u + 1)
+        asm.copy(3 * u + 1, 1, 3 * u + 1, 4)
+        asm.copy(3 * u + 2, 0, 3 * u + 1, 3)
+        if u:
+            asm.copy(3 * u + 1, 7, 3 * (u - 1) + 1, 7)        # a cell shared between neighbouring units
+    fixed = [[1] * m + [0] * (n - m), [1] * m + [0] * (n - m),
+             [i if i < usable else 0 for i in range(n)], [i * i if i < usable else 0 for i in range(n)],
+             [0] + [1] * (m - 1) + [0] * (n - m)]
+    return advice, [public], fixed, asm

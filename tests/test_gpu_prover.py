@@ -6,7 +6,7 @@ import pytest
 
 import bn254 as bn
 import verifier_model as vm
-from prover_cases import TAU, circuit as _circuit, srs as _srs, witness as _witness
+from prover_cases import TAU, circuit as _circuit, srs as _srs, wide_circuit, wide_witness, witness as _witness
 from util import golden
 
 from zkevm_circuits_amd import ffi, prover
@@ -154,6 +154,33 @@ def test_full_size_proof_verifies(ctx, co):
     bad[40] ^= 1
     with pytest.raises(vm.VerifyError):
         vm.verify_proof(cs, k, vk, instance, bytes(bad), TAU)
+    for p in pk.pointers():
+        ctx.free(p)
+    params.close()
+    dom.close()
+
+
+@pytest.mark.parametrize("k,units,degree9", [(9, 3, False), (10, 16, True)])
+def test_wide_circuit_proof_verifies(ctx, co, k, units, degree9):
+    """many columns (80 advice, 16 lookups, 49 permutation columns in seven sets at 16 units), a degree-nine gate (extended domain 8n), rotations
+    -1 / 0 / +1: the fused evaluate_h program against the verifier's expression-by-expression evaluation"""
+    cs = wide_circuit(units, degree9)
+    assert cs.degree() == (9 if degree9 else 5)
+    dom = zk.Domain(ctx, cs.degree(), k)
+    assert dom.extended_k == k + (3 if degree9 else 2)
+    params = prover.ParamsKZG(ctx, dom, _srs(co, dom.n))
+    advice, instance, fixed, asm = wide_witness(cs, dom.n, k, units)
+    pk = prover.keygen(ctx, dom, params, cs, fixed, asm)
+    vk = {"fixed_commitments": pk.fixed_commitments, "permutation_commitments": pk.permutation_commitments,
+          "transcript_repr": pk.transcript_repr}
+    proof = prover.create_proof(ctx, dom, params, pk, advice, instance, prover.FieldRng(k), prover.Blake2bWrite())
+    vm.verify_proof(cs, k, vk, instance, proof, TAU)
+    # one wrong cell in the last unit: d != a(-1) + b on one row
+    advice = [list(col) for col in advice]
+    advice[5 * (units - 1) + 4][9] += 1
+    proof = prover.create_proof(ctx, dom, params, pk, advice, instance, prover.FieldRng(k), prover.Blake2bWrite())
+    with pytest.raises(vm.VerifyError):
+        vm.verify_proof(cs, k, vk, instance, proof, TAU)
     for p in pk.pointers():
         ctx.free(p)
     params.close()
