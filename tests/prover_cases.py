@@ -83,9 +83,10 @@ def wide_circuit(units, degree9=False):
     return cs
 
 
-def wide_witness(cs, n, seed, units):
+def wide_witness(cs, n, seed, units, active_rows=500, as_arrays=False):
+    """as_arrays: advice columns as (usable, 4) Montgomery limb arrays (zero below the active rows) instead of lists"""
     usable = n - (cs.blinding_factors() + 1)
-    m = min(usable - 2, 500)
+    m = min(usable - 2, active_rows)
     rng = np.random.default_rng(seed)
     advice, public = [], []
     asm = keygen.Assembly(n, len(cs.permutation_columns))       # argument columns: (s, a, c) per unit, then the instance
@@ -112,4 +113,12 @@ def wide_witness(cs, n, seed, units):
     fixed = [[1] * m + [0] * (n - m), [1] * m + [0] * (n - m),
              [i if i < usable else 0 for i in range(n)], [i * i if i < usable else 0 for i in range(n)],
              [0] + [1] * (m - 1) + [0] * (n - m)]
+    if as_arrays:
+        arrays = []
+        for col in advice:
+            arr = np.zeros((usable, 4), dtype=np.uint64)
+            arr[:m + 1] = fr_arr(col[:m + 1])
+            assert not any(col[m + 1:])
+            arrays.append(arr)
+        advice = arrays
     return advice, [public], fixed, asm

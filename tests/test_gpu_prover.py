@@ -185,3 +185,29 @@ def test_wide_circuit_proof_verifies(ctx, co, k, units, degree9):
         ctx.free(p)
     params.close()
     dom.close()
+
+
+def test_full_size_wide_proof_verifies(ctx, co):
+    """k = 19 with 16 units: 80 advice columns, 16 lookups, 49 permutation columns, a degree-nine gate, i.e. 136
+    coset extensions to 2^22, evaluate_h over 2^22 rows, eight quotient pieces; 26 GB resident"""
+    import time
+    k, units = 19, 16
+    cs = wide_circuit(units, True)
+    dom = zk.Domain(ctx, cs.degree(), k)
+    assert dom.extended_k == 22
+    params = prover.ParamsKZG(ctx, dom, _srs(co, dom.n))
+    advice, instance, fixed, asm = wide_witness(cs, dom.n, k, units, active_rows=3000, as_arrays=True)
+    t0 = time.perf_counter()
+    pk = prover.keygen(ctx, dom, params, cs, fixed, asm)
+    t1 = time.perf_counter()
+    proof = prover.create_proof(ctx, dom, params, pk, advice, instance, prover.FieldRng(k), prover.Blake2bWrite())
+    t2 = time.perf_counter()
+    vk = {"fixed_commitments": pk.fixed_commitments, "permutation_commitments": pk.permutation_commitments,
+          "transcript_repr": pk.transcript_repr}
+    vm.verify_proof(cs, k, vk, instance, proof, TAU)
+    print(f"k=19 wide: keygen {t1 - t0:.1f} s, create_proof {t2 - t1:.1f} s (host conversions included), "
+          f"verify {time.perf_counter() - t2:.1f} s, proof {len(proof)} bytes")
+    for p in pk.pointers():
+        ctx.free(p)
+    params.close()
+    dom.close()

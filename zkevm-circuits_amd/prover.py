@@ -210,8 +210,9 @@ def keygen(ctx, dom, params: ParamsKZG, cs: ConstraintSystem, fixed, assembly) -
 
 
 def create_proof(ctx, dom, params: ParamsKZG, pk: ProvingKey, advice, instance, rng: FieldRng, transcript: Blake2bWrite):
-    """One circuit.  advice: per column the values of the usable rows (canonical integers; the remaining rows are
-    blinding); instance: per column at most that many values.  Writes the proof into `transcript`."""
+    """One circuit.  advice: per column the values of the usable rows (a list of canonical integers, or a
+    (usable rows, 4) uint64 array of Montgomery limbs; the remaining rows are blinding); instance: per column at most
+    that many canonical integers.  Writes the proof into `transcript` and returns its bytes."""
     cs = pk.cs
     n, en = dom.n, dom.extended_len
     bf = cs.blinding_factors()
@@ -220,6 +221,8 @@ def create_proof(ctx, dom, params: ParamsKZG, pk: ProvingKey, advice, instance, 
         raise ValueError("InvalidInstances / advice columns do not match the constraint system")
     if any(len(c) != usable for c in advice) or any(len(c) > usable for c in instance):
         raise ValueError("InstanceTooLarge / advice columns must hold the usable rows")
+    if any(isinstance(c, np.ndarray) and (c.dtype != np.uint64 or c.shape != (usable, 4)) for c in advice):
+        raise ValueError("an advice column given as an array holds (usable rows, 4) uint64 Montgomery limbs")
     omega = fr_from_mont_limbs(dom.constant(0))
     owned = []
 
@@ -247,7 +250,14 @@ def create_proof(ctx, dom, params: ParamsKZG, pk: ProvingKey, advice, instance, 
             for v in col:
                 transcript.common_scalar(v)
             inst.append(upload_ints(list(col) + [0] * (n - len(col))))
-        adv = [upload_ints(list(col) + [rng.fr() for _ in range(n - usable)]) for col in advice]
+        adv = []
+        for col in advice:                                      # the unusable rows of every column are blinding
+            blinding = [rng.fr() for _ in range(n - usable)]
+            if isinstance(col, np.ndarray):
+                adv.append(ctx.upload(np.concatenate([col, fr_limbs(blinding)])))
+                owned.append(adv[-1])
+            else:
+                adv.append(upload_ints(list(col) + blinding))
         for _ in adv:
             rng.fr()                                            # one Blind per column: drawn, unused by KZG
         if adv:
