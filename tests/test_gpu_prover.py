@@ -187,11 +187,13 @@ def test_wide_circuit_proof_verifies(ctx, co, k, units, degree9):
     dom.close()
 
 
-def test_full_size_wide_proof_verifies(ctx, co):
-    """k = 19 with 16 units: 80 advice columns, 16 lookups, 49 permutation columns, a degree-nine gate, i.e. 136
-    coset extensions to 2^22, evaluate_h over 2^22 rows, eight quotient pieces; 26 GB resident"""
+@pytest.mark.parametrize("units", [16, 76])
+def test_full_size_wide_proof_verifies(ctx, co, units):
+    """k = 19 with 16 units: 80 advice columns, 16 lookups, 49 permutation columns, a degree-nine gate, i.e. 146
+    coset extensions to 2^22, evaluate_h over 2^22 rows, eight quotient pieces.  With 76 units the column counts of the
+    reference's SuperCircuit estimate: 380 advice columns, 76 lookups, 229 permutation columns in 33 sets."""
     import time
-    k, units = 19, 16
+    k = 19
     cs = wide_circuit(units, True)
     dom = zk.Domain(ctx, cs.degree(), k)
     assert dom.extended_k == 22
@@ -200,13 +202,17 @@ def test_full_size_wide_proof_verifies(ctx, co):
     t0 = time.perf_counter()
     pk = prover.keygen(ctx, dom, params, cs, fixed, asm)
     t1 = time.perf_counter()
-    proof = prover.create_proof(ctx, dom, params, pk, advice, instance, prover.FieldRng(k), prover.Blake2bWrite())
+    phases = {}
+    proof = prover.create_proof(ctx, dom, params, pk, advice, instance, prover.FieldRng(k), prover.Blake2bWrite(), phases)
     t2 = time.perf_counter()
     vk = {"fixed_commitments": pk.fixed_commitments, "permutation_commitments": pk.permutation_commitments,
           "transcript_repr": pk.transcript_repr}
     vm.verify_proof(cs, k, vk, instance, proof, TAU)
-    print(f"k=19 wide: keygen {t1 - t0:.1f} s, create_proof {t2 - t1:.1f} s (host conversions included), "
-          f"verify {time.perf_counter() - t2:.1f} s, proof {len(proof)} bytes")
+    print(f"k=19 wide, {units} units: keygen {t1 - t0:.1f} s, create_proof {t2 - t1:.1f} s (host conversions included), "
+          f"verify {time.perf_counter() - t2:.1f} s, proof {len(proof)} bytes; phases "
+          + ", ".join(f"{name} {sec:.2f}" for name, sec in phases.items()))
+    assert set(phases) == {"advice", "lookup_permuted", "permutation_product", "lookup_product", "random_poly", "quotient",
+                           "evaluations", "multiopen"}
     for p in pk.pointers():
         ctx.free(p)
     params.close()

@@ -120,6 +120,13 @@ class FieldRng:
     def fr(self) -> int:
         return int.from_bytes(self.g.bytes(64), "little") % P
 
+    def limbs(self, n: int) -> np.ndarray:
+        """n field elements at once as (n, 4) Montgomery limbs: residues uniform below 2^252 (< r), which is as good a
+        stand-in for a polynomial with random coefficients and keeps 2^k draws out of the interpreter"""
+        a = self.g.integers(0, 1 << 64, size=(n, 4), dtype=np.uint64)
+        a[:, 3] &= np.uint64(0x0FFFFFFFFFFFFFFF)
+        return a
+
 
 def collect_queries(cs: ConstraintSystem):
     """(advice_queries, fixed_queries, instance_queries) as [(column, rotation)], each in order of first appearance."""
@@ -209,10 +216,12 @@ def keygen(ctx, dom, params: ParamsKZG, cs: ConstraintSystem, fixed, assembly) -
     return pk
 
 
-def create_proof(ctx, dom, params: ParamsKZG, pk: ProvingKey, advice, instance, rng: FieldRng, transcript: Blake2bWrite):
+def create_proof(ctx, dom, params: ParamsKZG, pk: ProvingKey, advice, instance, rng: FieldRng, transcript: Blake2bWrite,
+                 timings: dict | None = None):
     """One circuit.  advice: per column the values of the usable rows (a list of canonical integers, or a
     (usable rows, 4) uint64 array of Montgomery limbs; the remaining rows are blinding); instance: per column at most
-    that many canonical integers.  Writes the proof into `transcript` and returns its bytes."""
+    that many canonical integers.  Writes the proof into `transcript` and returns its bytes.  timings: filled with the wall
+    seconds of each phase (the device is synchronised at every phase boundary, only when given)."""
     cs = pk.cs
     n, en = dom.n, dom.extended_len
     bf = cs.blinding_factors()
@@ -239,11 +248,25 @@ def create_proof(ctx, dom, params: ParamsKZG, pk: ProvingKey, advice, instance, 
     def limb(v):
         return np.array(fr_to_mont_limbs(v), dtype=np.uint64)
 
+    import time
+    clock = [time.perf_counter(), None]
+
+    def mark(phase):
+        """closes the running phase and opens `phase`"""
+        if timings is None:
+            return
+        ctx.sync()
+        now = time.perf_counter()
+        if clock[1] is not None:
+            timings[clock[1]] = timings.get(clock[1], 0.0) + now - clock[0]
+        clock[0], clock[1] = now, phase
+
     def blind_rows(d_col, first_row):
         ctx.upload(fr_limbs([rng.fr() for _ in range(n - first_row)]), d_col + first_row * 32)
 
     try:
         # ---- instances and advice ---------------------------------------------------------------------------
+        mark("advice")
         transcript.common_scalar(pk.transcript_repr)
         inst = []
         for col in instance:
@@ -268,6 +291,7 @@ def create_proof(ctx, dom, params: ParamsKZG, pk: ProvingKey, advice, instance, 
         theta = transcript.squeeze_challenge()
 
         # ---- lookups: compressed expressions, permuted columns ----------------------------------------------
+        mark("lookup_permuted")
         lookups = []
         for lk in cs.lookups:
             d_in, d_tb, d_pa, d_ps = alloc(n), alloc(n), alloc(n), alloc(n)
@@ -285,6 +309,7 @@ def create_proof(ctx, dom, params: ParamsKZG, pk: ProvingKey, advice, instance, 
         gamma = transcript.squeeze_challenge()
 
         # ---- permutation argument ---------------------------------------------------------------------------
+        mark("permutation_product")
         chunk = cs.permutation_chunk_len()
         pcols = cs.permutation_columns
         sets = cs.num_permutation_sets()
@@ -305,6 +330,7 @@ def create_proof(ctx, dom, params: ParamsKZG, pk: ProvingKey, advice, instance, 
                 transcript.write_point(jac)
 
         # ---- lookup grand products --------------------------------------------------------------------------
+        mark("lookup_product")
         for lk in lookups:
             d_z = alloc(n)
             dom.lookup_product_dev(lk[0], lk[1], lk[2], lk[3], limb(beta), limb(gamma), d_z)
@@ -314,12 +340,15 @@ def create_proof(ctx, dom, params: ParamsKZG, pk: ProvingKey, advice, instance, 
             transcript.write_point(params.commit_lagrange([d_z])[0])
 
         # ---- vanishing argument: random polynomial ----------------------------------------------------------
-        d_random = upload_ints([rng.fr() for _ in range(n)])
+        mark("random_poly")
+        d_random = ctx.upload(rng.limbs(n))
+        owned.append(d_random)
         rng.fr()
         transcript.write_point(params.commit([d_random])[0])
         y = transcript.squeeze_challenge()
 
         # ---- coefficient form and extended cosets -----------------------------------------------------------
+        mark("quotient")
         per_lookup = [(lk[4], lk[2], lk[3]) for lk in lookups]
         coeff_polys = adv + inst + [p for t in per_lookup for p in t] + perm_z
         for p in coeff_polys:
@@ -353,6 +382,7 @@ def create_proof(ctx, dom, params: ParamsKZG, pk: ProvingKey, advice, instance, 
         x = transcript.squeeze_challenge()
 
         # ---- evaluations at x -------------------------------------------------------------------------------
+        mark("evaluations")
         adv_q, fix_q, _ = collect_queries(cs)
         last_rot = -(bf + 1)
         xn = pow(x, n, P)
@@ -382,6 +412,7 @@ def create_proof(ctx, dom, params: ParamsKZG, pk: ProvingKey, advice, instance, 
                 transcript.write_scalar(evals[q])
 
         # ---- multi-open: queries in upstream's order ---------------------------------------------------------
+        mark("multiopen")
         order = list(groups["advice"]) + list(groups["perm"])
         for z, pa, ps in per_lookup:
             order += [(z, 0), (pa, 0), (ps, 0), (pa, -1), (z, 1)]
@@ -391,6 +422,7 @@ def create_proof(ctx, dom, params: ParamsKZG, pk: ProvingKey, advice, instance, 
         outs = shplonk.ProverSHPLONK(ctx, params.g, n).create_proof(polys, queries, transcript)
         owned.extend(outs)
         ctx.sync()
+        mark(None)
     finally:
         for p in owned:
             ctx.free(p)
