@@ -58,7 +58,7 @@ def srs(co, n):
     return g
 
 
-def wide_circuit(units, degree9=False):
+def wide_circuit(units, degree9=False, extra_gates=0):
     """`units` copies of the circuit above side by side, each with a fifth advice column d = a(-1) + b (a gate with a
     negative rotation), one lookup per unit, three permutation columns per unit plus the shared instance column;
     with degree9 one gate polynomial of degree nine (extended domain 8n)."""
@@ -74,6 +74,16 @@ def wide_circuit(units, degree9=False):
             for term in (a, b, c, s, d, a):
                 high = Product(high, Sum(term, Constant(u + 1)))
             polys.append(high)
+        # extra_gates more polynomials per unit, each the satisfied q (a b - c) times up to six seeded factors
+        # (column at a rotation + constant): they vanish on the circuit's rows, and their values on the extended domain,
+        # which the quotient is made of, depend on every factor
+        g_rng = np.random.default_rng(1000 + u)
+        for g in range(extra_gates):
+            poly = Product(q, mul)
+            for _ in range(1 + g % 6):
+                col, rot = 5 * u + int(g_rng.integers(0, 5)), int(g_rng.integers(-1, 2))
+                poly = Product(poly, Sum(Advice(col, rot), Constant(int(g_rng.integers(1, 1 << 30)))))
+            polys.append(poly)
         cs.gates.append(polys)
         cs.gates.append([Product(q_acc, Sub(Sub(Advice(5 * u + 3, 1), s), c)),
                          Product(q_prev, Sub(Sub(d, Advice(5 * u, -1)), b))])

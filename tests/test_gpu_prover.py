@@ -187,14 +187,16 @@ def test_wide_circuit_proof_verifies(ctx, co, k, units, degree9):
     dom.close()
 
 
-@pytest.mark.parametrize("units", [16, 76])
-def test_full_size_wide_proof_verifies(ctx, co, units):
+@pytest.mark.parametrize("units,extra_gates", [(16, 0), (76, 0), (76, 40)])
+def test_full_size_wide_proof_verifies(ctx, co, units, extra_gates):
     """k = 19 with 16 units: 80 advice columns, 16 lookups, 49 permutation columns, a degree-nine gate, i.e. 146
     coset extensions to 2^22, evaluate_h over 2^22 rows, eight quotient pieces.  With 76 units the column counts of the
-    reference's SuperCircuit estimate: 380 advice columns, 76 lookups, 229 permutation columns in 33 sets."""
+    reference's SuperCircuit estimate: 380 advice columns, 76 lookups, 229 permutation columns in 33 sets; with 40 extra
+    gate polynomials per unit also its estimated 3000 gate polynomials of degree up to nine."""
     import time
     k = 19
-    cs = wide_circuit(units, True)
+    cs = wide_circuit(units, True, extra_gates)
+    assert cs.blinding_factors() == 5
     dom = zk.Domain(ctx, cs.degree(), k)
     assert dom.extended_k == 22
     params = prover.ParamsKZG(ctx, dom, _srs(co, dom.n))
@@ -208,7 +210,7 @@ def test_full_size_wide_proof_verifies(ctx, co, units):
     vk = {"fixed_commitments": pk.fixed_commitments, "permutation_commitments": pk.permutation_commitments,
           "transcript_repr": pk.transcript_repr}
     vm.verify_proof(cs, k, vk, instance, proof, TAU)
-    print(f"k=19 wide, {units} units: keygen {t1 - t0:.1f} s, create_proof {t2 - t1:.1f} s (host conversions included), "
+    print(f"k=19 wide, {units} units, {sum(len(g) for g in cs.gates)} gate polynomials: keygen {t1 - t0:.1f} s, create_proof {t2 - t1:.1f} s (host conversions included), "
           f"verify {time.perf_counter() - t2:.1f} s, proof {len(proof)} bytes; phases "
           + ", ".join(f"{name} {sec:.2f}" for name, sec in phases.items()))
     assert set(phases) == {"advice", "lookup_permuted", "permutation_product", "lookup_product", "random_poly", "quotient",

@@ -115,7 +115,25 @@ class ConstraintSystem:
     permutation_columns: list = field(default_factory=list)  # [(ANY_*, index)]
     minimum_degree: int | None = None
 
+    def _memo(self, name, compute):
+        """degree() and blinding_factors() walk every expression; callers ask for them per device call, so the values
+        are kept until the lists of gates / lookups change length"""
+        key = (len(self.gates), sum(len(g) for g in self.gates), len(self.lookups), self.minimum_degree)
+        cache = self.__dict__.setdefault("_memo_cache", {})
+        if cache.get("key") != key:
+            cache.clear()
+            cache["key"] = key
+        if name not in cache:
+            cache[name] = compute()
+        return cache[name]
+
     def degree(self) -> int:
+        return self._memo("degree", self._degree)
+
+    def blinding_factors(self) -> int:
+        return self._memo("blinding_factors", self._blinding_factors)
+
+    def _degree(self) -> int:
         d = 3  # permutation argument's required degree
         for lk in self.lookups:
             d = max(d, lk.required_degree())
@@ -124,7 +142,7 @@ class ConstraintSystem:
                 d = max(d, expr_degree(poly))
         return max(d, self.minimum_degree or 1)
 
-    def blinding_factors(self) -> int:
+    def _blinding_factors(self) -> int:
         per_col = {}
         q = set()
         for g in self.gates:
