@@ -167,6 +167,7 @@ def main():
     ap.add_argument("--skip-cpu", action="store_true")
     ap.add_argument("--skip-extras", action="store_true",
                     help="only the timed steps: the kernel averages of a rocprofv3 run then describe exactly the timed region")
+    ap.add_argument("--skip-proof", action="store_true", help="leave out the whole-proof measurement (create_proof_k19)")
     ap.add_argument("--evalh-k", type=int, default=K)
     args = ap.parse_args()
 
@@ -251,8 +252,39 @@ def main():
             split = measure_evalh_split(ctx, dom, stream, gen, world, rank)
             if evalh is not None:
                 evalh["split_by_coset"] = split
+    if world == 1 and not args.skip_extras and not args.skip_proof:
+        extra["create_proof_k19"] = measure_create_proof(ctx, bid)
     finish(args, ctx, dist, world, rank, device_index, bid, scalars, n, en, elapsed, msm_ms, ntt_ms, acc_us, acc_launches, sort_us,
            merge_us, reduce_us, ntt_us, extra, evalh)
+
+
+def measure_create_proof(ctx, bid):
+    """One whole `create_proof` (zkevm_circuits_amd/prover.py) at k = 19 for a satisfied constraint system with the column
+    counts estimated for the reference's SuperCircuit (380 advice, 76 lookups, 229 permutation columns, 3345 gate
+    polynomials of degree up to nine).  The SRS here is the benchmark's unstructured table, so this proof is timed, not
+    verified; tests/test_gpu_prover.py runs the same call over a structured SRS and verifies the bytes."""
+    from zkevm_circuits_amd import prover
+    units, k = 76, K
+    cs = synthetic.satisfied_cs(units, True, 40)
+    dom = zk.Domain(ctx, cs.degree(), k)
+    params = prover.ParamsKZG.from_registered(ctx, dom, bid, bid)
+    advice, instance, fixed, asm = synthetic.satisfied_witness(cs, dom.n, k, units, active_rows=3000, as_arrays=True)
+    t0 = time.perf_counter()
+    pk = prover.keygen(ctx, dom, params, cs, fixed, asm)
+    ctx.sync()
+    t1 = time.perf_counter()
+    phases = {}
+    proof = prover.create_proof(ctx, dom, params, pk, advice, instance, prover.FieldRng(k), prover.Blake2bWrite(), phases)
+    t2 = time.perf_counter()
+    for p in pk.pointers():
+        ctx.free(p)
+    dom.close()
+    return {"seconds": t2 - t1, "keygen_seconds": t1 - t0, "phases_s": phases, "proof_bytes": len(proof),
+            "shape": {"k": k, "extended_k": k + 3, "advice": cs.num_advice_columns, "fixed": cs.num_fixed_columns,
+                      "lookups": len(cs.lookups), "permutation_columns": len(cs.permutation_columns),
+                      "gate_polynomials": sum(len(g) for g in cs.gates), "degree": cs.degree()},
+            "note": "wall time of one proof on one GPU including the Python host side and the 6.4 GB upload of the witness; "
+                    "synthetic satisfied circuit, not the SuperCircuit; timed here, verified in tests/test_gpu_prover.py"}
 
 
 def measure_extras(ctx, dom, bid, stream, gen, n, en, extra):

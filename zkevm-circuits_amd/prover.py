@@ -167,6 +167,13 @@ class ParamsKZG:
         self.g = ctx.register_bases(g_affine)
         self.g_lagrange = ctx.register_bases(kg.g_to_lagrange(ctx, dom, g_affine))
 
+    @classmethod
+    def from_registered(cls, ctx, dom, g: int, g_lagrange: int):
+        """over tables that are registered already (the caller releases them; `close` must not be called)"""
+        self = cls.__new__(cls)
+        self.ctx, self.k, self.n, self.g, self.g_lagrange = ctx, dom.k, dom.n, g, g_lagrange
+        return self
+
     def commit(self, d_polys):
         return self.ctx.msm_batch_dev(self.g, list(d_polys), self.n)
 
