@@ -125,3 +125,68 @@ def test_two_ranks_match_the_unsharded_pipeline():
     assert ok_split, "base-range split MSM differs from the whole MSM"
     assert ok_h, "coset-split evaluate_h differs from the whole-domain evaluate_h"
     assert owners == 2
+
+
+def _prover_worker(rank, world, port, q):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for p in (root, os.path.join(root, "oracle"), os.path.join(root, "tests")):
+        sys.path.insert(0, p)
+    import torch  # noqa: F401
+    import zkhip_pkg
+    zk = zkhip_pkg.load()
+    import coracle
+    import prover_cases as pc
+    import verifier_model as vm
+    from zkevm_circuits_amd import prover
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        ctx = zk.Context(0)
+        results = []
+        for k, units, degree9 in ((8, 1, False), (9, 3, True)):
+            cs = pc.wide_circuit(units, degree9, 3)
+            dom = zk.Domain(ctx, cs.degree(), k)
+            params = prover.ParamsKZG(ctx, dom, pc.srs(coracle, dom.n))
+            advice, instance, fixed, asm = pc.wide_witness(cs, dom.n, k, units)
+            pk = prover.keygen(ctx, dom, params, cs, fixed, asm)
+            sharded = prover.create_proof(ctx, dom, params, pk, advice, instance, prover.FieldRng(k), prover.Blake2bWrite(),
+                                          dist=dist)
+            if rank == 0:
+                whole = prover.create_proof(ctx, dom, params, pk, advice, instance, prover.FieldRng(k), prover.Blake2bWrite())
+                vk = {"fixed_commitments": pk.fixed_commitments, "permutation_commitments": pk.permutation_commitments,
+                      "transcript_repr": pk.transcript_repr}
+                vm.verify_proof(cs, k, vk, instance, sharded, pc.TAU)
+                results.append(sharded == whole)
+            dist.barrier()
+            for p in pk.pointers():
+                ctx.free(p)
+            params.close()
+            dom.close()
+        if rank == 0:
+            q.put(results)
+        dist.barrier()
+        ctx.close()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_create_the_same_proof_as_one():
+    """create_proof with the commitments column-sharded and the quotient numerator coset-sharded over two ranks: the
+    bytes equal the single-rank proof (extended domains 4n and 8n) and pass the verifier model"""
+    world = 2
+    mpctx = mp.get_context("spawn")
+    q = mpctx.Queue()
+    port = _free_port()
+    procs = [mpctx.Process(target=_prover_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    try:
+        results = q.get(timeout=240)
+    finally:
+        for p in procs:
+            p.join(timeout=120)
+    assert all(p.exitcode == 0 for p in procs)
+    assert results == [True, True]

@@ -22,7 +22,7 @@ import hashlib
 
 import numpy as np
 
-from . import evalh_host, ffi, keygen as kg, shplonk
+from . import evalh_host, ffi, keygen as kg, sharding, shplonk
 from .evalh_host import fr_to_mont_limbs
 from .plonk import ANY_ADVICE, ANY_FIXED, ANY_INSTANCE, FR_MODULUS, ConstraintSystem
 
@@ -174,11 +174,20 @@ class ParamsKZG:
         self.ctx, self.k, self.n, self.g, self.g_lagrange = ctx, dom.k, dom.n, g, g_lagrange
         return self
 
-    def commit(self, d_polys):
-        return self.ctx.msm_batch_dev(self.g, list(d_polys), self.n)
+    def _commit(self, bid, d_polys, dist):
+        d_polys = list(d_polys)
+        if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+            return self.ctx.msm_batch_dev(bid, d_polys, self.n)
+        # columns are independent: rank r commits columns r, r + world, ..; the points are gathered in column order
+        mine = sharding.columns_for_rank(len(d_polys), dist.get_rank(), dist.get_world_size())
+        local = self.ctx.msm_batch_dev(bid, [d_polys[c] for c in mine], self.n) if mine else []
+        return sharding.gather_commitments(dict(zip(mine, local)), len(d_polys), dist)
 
-    def commit_lagrange(self, d_polys):
-        return self.ctx.msm_batch_dev(self.g_lagrange, list(d_polys), self.n)
+    def commit(self, d_polys, dist=None):
+        return self._commit(self.g, d_polys, dist)
+
+    def commit_lagrange(self, d_polys, dist=None):
+        return self._commit(self.g_lagrange, d_polys, dist)
 
     def close(self):
         self.ctx.release_bases(self.g)
@@ -224,11 +233,14 @@ def keygen(ctx, dom, params: ParamsKZG, cs: ConstraintSystem, fixed, assembly) -
 
 
 def create_proof(ctx, dom, params: ParamsKZG, pk: ProvingKey, advice, instance, rng: FieldRng, transcript: Blake2bWrite,
-                 timings: dict | None = None):
+                 timings: dict | None = None, dist=None):
     """One circuit.  advice: per column the values of the usable rows (a list of canonical integers, or a
     (usable rows, 4) uint64 array of Montgomery limbs; the remaining rows are blinding); instance: per column at most
     that many canonical integers.  Writes the proof into `transcript` and returns its bytes.  timings: filled with the wall
-    seconds of each phase (the device is synchronised at every phase boundary, only when given)."""
+    seconds of each phase (the device is synchronised at every phase boundary, only when given).
+    dist: an initialised torch.distributed module with one rank per GPU: every rank calls with the same arguments, the
+    commitments are computed column-sharded and the quotient numerator coset-sharded (zkevm_circuits_amd/sharding.py), the
+    rest is replicated; every rank returns the same bytes as a single-rank call."""
     cs = pk.cs
     n, en = dom.n, dom.extended_len
     bf = cs.blinding_factors()
@@ -291,7 +303,7 @@ def create_proof(ctx, dom, params: ParamsKZG, pk: ProvingKey, advice, instance, 
         for _ in adv:
             rng.fr()                                            # one Blind per column: drawn, unused by KZG
         if adv:
-            for jac in params.commit_lagrange(adv):
+            for jac in params.commit_lagrange(adv, dist):
                 transcript.write_point(jac)
         challenges = [transcript.squeeze_challenge() for _ in range(cs.num_challenges)]
         ch_limbs = fr_limbs(challenges) if challenges else np.zeros((0, 4), dtype=np.uint64)
@@ -309,7 +321,7 @@ def create_proof(ctx, dom, params: ParamsKZG, pk: ProvingKey, advice, instance, 
             blind_rows(d_pa, usable)
             blind_rows(d_ps, usable)
             rng.fr(), rng.fr()
-            for jac in params.commit_lagrange([d_pa, d_ps]):
+            for jac in params.commit_lagrange([d_pa, d_ps], dist):
                 transcript.write_point(jac)
             lookups.append([d_in, d_tb, d_pa, d_ps, 0])
         beta = transcript.squeeze_challenge()
@@ -333,7 +345,7 @@ def create_proof(ctx, dom, params: ParamsKZG, pk: ProvingKey, advice, instance, 
             rng.fr()
             perm_z.append(d_z)
         if perm_z:
-            for jac in params.commit_lagrange(perm_z):
+            for jac in params.commit_lagrange(perm_z, dist):
                 transcript.write_point(jac)
 
         # ---- lookup grand products --------------------------------------------------------------------------
@@ -344,7 +356,9 @@ def create_proof(ctx, dom, params: ParamsKZG, pk: ProvingKey, advice, instance, 
             blind_rows(d_z, usable + 1)
             rng.fr()
             lk[4] = d_z
-            transcript.write_point(params.commit_lagrange([d_z])[0])
+        if lookups:
+            for jac in params.commit_lagrange([lk[4] for lk in lookups], dist):
+                transcript.write_point(jac)
 
         # ---- vanishing argument: random polynomial ----------------------------------------------------------
         mark("random_poly")
@@ -360,23 +374,59 @@ def create_proof(ctx, dom, params: ParamsKZG, pk: ProvingKey, advice, instance, 
         coeff_polys = adv + inst + [p for t in per_lookup for p in t] + perm_z
         for p in coeff_polys:
             dom.lagrange_to_coeff_dev(p)
-        ext = {}
-        for p in coeff_polys:
-            ext[p] = alloc(en)
-            dom.coeff_to_extended_dev(p, ext[p])
-
         call = evalh_host.EvalhCall(cs)
-        call.fixed = pk.polys.fixed_cosets
-        call.advice = [ext[p] for p in adv]
-        call.instance = [ext[p] for p in inst]
         call.challenges = ch_limbs
         call.y, call.beta, call.gamma, call.theta = limb(y), limb(beta), limb(gamma), limb(theta)
-        call.l0, call.l_last, call.l_active = pk.polys.l0, pk.polys.l_last, pk.polys.l_active_row
-        call.lookups = [tuple(ext[p] for p in t) for t in per_lookup]
-        call.perm_sigma = pk.polys.permutation_cosets
-        call.perm_z = [ext[p] for p in perm_z]
         d_h = alloc(en)
-        dom.evaluate_h(call.build(ffi.MEM_DEVICE, ffi.FORM_EXTENDED), d_h)
+        sharded = dist is not None and dist.is_initialized() and dist.get_world_size() > 1
+
+        def fill(of_poly, of_key):
+            """of_poly: coefficient polynomial -> its evaluations; of_key: extended key vector -> the same rows of it"""
+            call.fixed = [of_key(p) for p in pk.polys.fixed_cosets]
+            call.advice = [of_poly(p) for p in adv]
+            call.instance = [of_poly(p) for p in inst]
+            call.l0, call.l_last, call.l_active = (of_key(p) for p in (pk.polys.l0, pk.polys.l_last, pk.polys.l_active_row))
+            call.lookups = [tuple(of_poly(p) for p in t) for t in per_lookup]
+            call.perm_sigma = [of_key(p) for p in pk.polys.permutation_cosets]
+            call.perm_z = [of_poly(p) for p in perm_z]
+
+        if not sharded:
+            def extend(p):
+                d = alloc(en)
+                dom.coeff_to_extended_dev(p, d)
+                return d
+            fill(extend, lambda p: p)
+            dom.evaluate_h(call.build(ffi.MEM_DEVICE, ffi.FORM_EXTENDED), d_h)
+        else:
+            import torch
+
+            def evaluate(cosets):
+                """this rank's cosets of the numerator, every column in the compact layout of those cosets"""
+                if not cosets:
+                    return torch.empty((0, 4), dtype=torch.int64, device="cuda")
+                rows = n * len(cosets)
+
+                def of_poly(p):
+                    d = alloc(rows)
+                    dom.coeff_to_cosets_dev(p, cosets, d)
+                    return d
+
+                def of_key(p):
+                    d = alloc(rows)
+                    dom.extended_to_cosets_dev(p, cosets, d)
+                    return d
+                fill(of_poly, of_key)
+                call.cosets = cosets
+                out = torch.empty((rows, 4), dtype=torch.int64, device="cuda")
+                torch.cuda.synchronize()
+                dom.evaluate_h(call.build(ffi.MEM_DEVICE, ffi.FORM_EXTENDED), out.data_ptr())
+                ctx.sync()
+                return out
+            pieces = sharding.evaluate_h_by_cosets(dom.extended_k, dom.k, evaluate, dist)
+            torch.cuda.synchronize()
+            for cosets, rows in pieces:
+                dom.cosets_to_extended_dev(rows.data_ptr(), cosets, d_h)
+            ctx.sync()
         dom.divide_by_vanishing_poly_dev(d_h)
         pieces = dom.quotient_poly_degree
         d_hc = alloc(n * pieces)
@@ -384,7 +434,7 @@ def create_proof(ctx, dom, params: ParamsKZG, pk: ProvingKey, advice, instance, 
         h_pieces = [d_hc + i * n * 32 for i in range(pieces)]
         for _ in h_pieces:
             rng.fr()
-        for jac in params.commit(h_pieces):
+        for jac in params.commit(h_pieces, dist):
             transcript.write_point(jac)
         x = transcript.squeeze_challenge()
 

@@ -47,11 +47,13 @@ def gather_commitments(local: dict, num_columns: int, dist=None):
     import torch
     world = dist.get_world_size()
     mine = torch.from_numpy(out.view(np.int64).copy())
+    if dist.get_backend() == "nccl":            # RCCL moves device memory only
+        mine = mine.cuda()
     gathered = [torch.empty_like(mine) for _ in range(world)]
     dist.all_gather(gathered, mine)
     res = np.zeros_like(out)
     for r, g in enumerate(gathered):
-        arr = g.numpy().view(np.uint64)
+        arr = g.cpu().numpy().view(np.uint64)
         for c in columns_for_rank(num_columns, r, world):
             res[c] = arr[c]
     return res
