@@ -252,17 +252,22 @@ def main():
             split = measure_evalh_split(ctx, dom, stream, gen, world, rank)
             if evalh is not None:
                 evalh["split_by_coset"] = split
-    if world == 1 and not args.skip_extras and not args.skip_proof:
-        extra["create_proof_k19"] = measure_create_proof(ctx, bid)
+    if not args.skip_extras and not args.skip_proof:
+        try:
+            extra["create_proof_k19"] = measure_create_proof(ctx, bid, dist if world > 1 else None)
+        except Exception as exc:                          # reported, never allowed to lose the line above it
+            extra["create_proof_k19"] = {"error": f"{type(exc).__name__}: {exc}"}
     finish(args, ctx, dist, world, rank, device_index, bid, scalars, n, en, elapsed, msm_ms, ntt_ms, acc_us, acc_launches, sort_us,
            merge_us, reduce_us, ntt_us, extra, evalh)
 
 
-def measure_create_proof(ctx, bid):
+def measure_create_proof(ctx, bid, dist_=None):
     """One whole `create_proof` (zkevm_circuits_amd/prover.py) at k = 19 for a satisfied constraint system with the column
     counts estimated for the reference's SuperCircuit (380 advice, 76 lookups, 229 permutation columns, 3345 gate
     polynomials of degree up to nine).  The SRS here is the benchmark's unstructured table, so this proof is timed, not
-    verified; tests/test_gpu_prover.py runs the same call over a structured SRS and verifies the bytes."""
+    verified; tests/test_gpu_prover.py runs the same call over a structured SRS and verifies the bytes.  With several ranks
+    the commitments are column-sharded and the quotient numerator coset-sharded (every rank holds the whole witness and
+    key, as the partition of the extended domain by coset needs); seconds = the slowest rank."""
     from zkevm_circuits_amd import prover
     units, k = 76, K
     cs = synthetic.satisfied_cs(units, True, 40)
@@ -274,16 +279,28 @@ def measure_create_proof(ctx, bid):
     ctx.sync()
     t1 = time.perf_counter()
     phases = {}
-    proof = prover.create_proof(ctx, dom, params, pk, advice, instance, prover.FieldRng(k), prover.Blake2bWrite(), phases)
-    t2 = time.perf_counter()
+    keygen_seconds = t1 - t0
+    if dist_ is not None:
+        dist_.barrier()
+        t1 = time.perf_counter()
+    proof = prover.create_proof(ctx, dom, params, pk, advice, instance, prover.FieldRng(k), prover.Blake2bWrite(), phases,
+                                dist=dist_)
+    seconds = time.perf_counter() - t1
     for p in pk.pointers():
         ctx.free(p)
     dom.close()
-    return {"seconds": t2 - t1, "keygen_seconds": t1 - t0, "phases_s": phases, "proof_bytes": len(proof),
+    ranks = 1
+    if dist_ is not None:
+        ranks = dist_.get_world_size()
+        t = torch.tensor([seconds], dtype=torch.float64, device="cuda")
+        dist_.all_reduce(t, op=dist_.ReduceOp.MAX)
+        seconds = float(t.cpu()[0])
+    return {"seconds": seconds, "ranks": ranks, "keygen_seconds": keygen_seconds, "phases_s": phases, "proof_bytes": len(proof),
             "shape": {"k": k, "extended_k": k + 3, "advice": cs.num_advice_columns, "fixed": cs.num_fixed_columns,
                       "lookups": len(cs.lookups), "permutation_columns": len(cs.permutation_columns),
                       "gate_polynomials": sum(len(g) for g in cs.gates), "degree": cs.degree()},
-            "note": "wall time of one proof on one GPU including the Python host side and the 6.4 GB upload of the witness; "
+            "note": "wall time of one proof (slowest rank) including the Python host side and the 6.4 GB upload of the witness; "
+                    "with several ranks only the commitments and the quotient numerator are sharded, the rest is replicated; "
                     "synthetic satisfied circuit, not the SuperCircuit; timed here, verified in tests/test_gpu_prover.py"}
 
 
