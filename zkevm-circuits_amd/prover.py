@@ -24,7 +24,7 @@ import numpy as np
 
 from . import evalh_host, ffi, keygen as kg, sharding, shplonk
 from .evalh_host import fr_to_mont_limbs
-from .plonk import ANY_ADVICE, ANY_FIXED, ANY_INSTANCE, FR_MODULUS, ConstraintSystem
+from .plonk import ANY_ADVICE, ANY_FIXED, ANY_INSTANCE, FR_MODULUS, ConstraintSystem, Evaluator
 
 P = FR_MODULUS
 FQ_MODULUS = 0x30644E72E131A029B85045B68181585D97816A916871CA8D3C208C16D87CFD47
@@ -203,6 +203,7 @@ class ProvingKey:
         self.fixed_values = []                # device pointers, Lagrange basis
         self.fixed_commitments, self.permutation_commitments = [], []      # (x, y) integers
         self.transcript_repr = 0
+        self.ev = None                        # plonk.Evaluator, built once per key as upstream's `ProvingKey::ev`
 
     def pointers(self):
         return self.polys.pointers() + self.fixed_values
@@ -217,6 +218,7 @@ def keygen(ctx, dom, params: ParamsKZG, cs: ConstraintSystem, fixed, assembly) -
         raise ValueError("fixed columns do not match the constraint system")
     pk = ProvingKey()
     pk.cs = cs
+    pk.ev = Evaluator(cs)
     fixed_limbs = [fr_limbs(c) for c in fixed]
     pk.polys = kg.keygen_polys(ctx, dom, fixed_limbs, assembly if cs.permutation_columns else None, cs.blinding_factors())
     pk.fixed_values = [ctx.upload(a) for a in fixed_limbs]
@@ -259,11 +261,6 @@ def create_proof(ctx, dom, params: ParamsKZG, pk: ProvingKey, advice, instance, 
         owned.append(p)
         return p
 
-    def upload_ints(vals):
-        p = ctx.upload(fr_limbs(vals))
-        owned.append(p)
-        return p
-
     def limb(v):
         return np.array(fr_to_mont_limbs(v), dtype=np.uint64)
 
@@ -287,19 +284,26 @@ def create_proof(ctx, dom, params: ParamsKZG, pk: ProvingKey, advice, instance, 
         # ---- instances and advice ---------------------------------------------------------------------------
         mark("advice")
         transcript.common_scalar(pk.transcript_repr)
-        inst = []
-        for col in instance:
+        # every polynomial that goes to coefficient form and to the extended domain later lives in one block, so that
+        # those transforms run as batches: advice | instance | per lookup (z, a', s') | permutation z
+        n_adv, n_inst, n_lk, sets = len(advice), len(instance), len(cs.lookups), cs.num_permutation_sets()
+        total = n_adv + n_inst + 3 * n_lk + sets
+        block = alloc(n * max(total, 1))
+        slot = [block + i * n * 32 for i in range(total)]
+        adv, inst = slot[:n_adv], slot[n_adv:n_adv + n_inst]
+        lk_slots = [slot[n_adv + n_inst + 3 * i:n_adv + n_inst + 3 * i + 3] for i in range(n_lk)]
+        perm_z = slot[total - sets:]
+        for col, d in zip(instance, inst):
             for v in col:
                 transcript.common_scalar(v)
-            inst.append(upload_ints(list(col) + [0] * (n - len(col))))
-        adv = []
-        for col in advice:                                      # the unusable rows of every column are blinding
-            blinding = [rng.fr() for _ in range(n - usable)]
+            ctx.upload(fr_limbs(list(col) + [0] * (n - len(col))), d)
+        for col, d in zip(advice, adv):                         # the unusable rows of every column are blinding
+            blinding = fr_limbs([rng.fr() for _ in range(n - usable)])
             if isinstance(col, np.ndarray):
-                adv.append(ctx.upload(np.concatenate([col, fr_limbs(blinding)])))
-                owned.append(adv[-1])
+                ctx.upload(col, d)
+                ctx.upload(blinding, d + usable * 32)
             else:
-                adv.append(upload_ints(list(col) + blinding))
+                ctx.upload(np.concatenate([fr_limbs(col), blinding]), d)
         for _ in adv:
             rng.fr()                                            # one Blind per column: drawn, unused by KZG
         if adv:
@@ -312,8 +316,8 @@ def create_proof(ctx, dom, params: ParamsKZG, pk: ProvingKey, advice, instance, 
         # ---- lookups: compressed expressions, permuted columns ----------------------------------------------
         mark("lookup_permuted")
         lookups = []
-        for lk in cs.lookups:
-            d_in, d_tb, d_pa, d_ps = alloc(n), alloc(n), alloc(n), alloc(n)
+        for lk, (_, d_pa, d_ps) in zip(cs.lookups, lk_slots):
+            d_in, d_tb = alloc(n), alloc(n)
             for exprs, d_out in ((lk.input_expressions, d_in), (lk.table_expressions, d_tb)):
                 call = evalh_host.lookup_compress_call(cs, exprs, pk.fixed_values, adv, inst, ch_limbs, limb(theta))
                 dom.evaluate_h(call.build(ffi.MEM_DEVICE, ffi.FORM_EXTENDED), d_out)
@@ -331,27 +335,23 @@ def create_proof(ctx, dom, params: ParamsKZG, pk: ProvingKey, advice, instance, 
         mark("permutation_product")
         chunk = cs.permutation_chunk_len()
         pcols = cs.permutation_columns
-        sets = cs.num_permutation_sets()
         lagrange_of = {ANY_ADVICE: adv, ANY_FIXED: pk.fixed_values, ANY_INSTANCE: inst}
-        perm_z, last_z = [], 1
-        for s in range(sets):
+        last_z = 1
+        for s, d_z in enumerate(perm_z):
             cols = pcols[s * chunk:(s + 1) * chunk]
-            d_z = alloc(n)
             dom.permutation_product_dev([lagrange_of[kind][i] for kind, i in cols],
                                         pk.polys.permutations[s * chunk:s * chunk + len(cols)], limb(beta), limb(gamma),
                                         limb(pow(FR_DELTA, s * chunk, P)), limb(last_z), d_z)
             blind_rows(d_z, usable + 1)
             last_z = fr_from_mont_limbs(ctx.download(d_z + usable * 32, (1, 4))[0])
             rng.fr()
-            perm_z.append(d_z)
         if perm_z:
             for jac in params.commit_lagrange(perm_z, dist):
                 transcript.write_point(jac)
 
         # ---- lookup grand products --------------------------------------------------------------------------
         mark("lookup_product")
-        for lk in lookups:
-            d_z = alloc(n)
+        for lk, (d_z, _, _) in zip(lookups, lk_slots):
             dom.lookup_product_dev(lk[0], lk[1], lk[2], lk[3], limb(beta), limb(gamma), d_z)
             blind_rows(d_z, usable + 1)
             rng.fr()
@@ -371,10 +371,11 @@ def create_proof(ctx, dom, params: ParamsKZG, pk: ProvingKey, advice, instance, 
         # ---- coefficient form and extended cosets -----------------------------------------------------------
         mark("quotient")
         per_lookup = [(lk[4], lk[2], lk[3]) for lk in lookups]
-        coeff_polys = adv + inst + [p for t in per_lookup for p in t] + perm_z
-        for p in coeff_polys:
-            dom.lagrange_to_coeff_dev(p)
-        call = evalh_host.EvalhCall(cs)
+        assert [p for t in per_lookup for p in t] == slot[n_adv + n_inst:total - sets]
+        BATCH = 64
+        for s0 in range(0, total, BATCH):
+            dom.lagrange_to_coeff_dev(slot[s0], min(BATCH, total - s0))
+        call = evalh_host.EvalhCall(cs, pk.ev)
         call.challenges = ch_limbs
         call.y, call.beta, call.gamma, call.theta = limb(y), limb(beta), limb(gamma), limb(theta)
         d_h = alloc(en)
@@ -391,11 +392,10 @@ def create_proof(ctx, dom, params: ParamsKZG, pk: ProvingKey, advice, instance, 
             call.perm_z = [of_poly(p) for p in perm_z]
 
         if not sharded:
-            def extend(p):
-                d = alloc(en)
-                dom.coeff_to_extended_dev(p, d)
-                return d
-            fill(extend, lambda p: p)
+            ext_block = alloc(en * max(total, 1))
+            for s0 in range(0, total, BATCH):
+                dom.coeff_to_extended_dev(slot[s0], ext_block + s0 * en * 32, min(BATCH, total - s0))
+            fill(lambda p: ext_block + (p - block) // (n * 32) * en * 32, lambda p: p)
             dom.evaluate_h(call.build(ffi.MEM_DEVICE, ffi.FORM_EXTENDED), d_h)
         else:
             import torch
