@@ -219,3 +219,44 @@ def test_full_size_wide_proof_verifies(ctx, co, units, extra_gates):
         ctx.free(p)
     params.close()
     dom.close()
+
+
+@pytest.mark.parametrize("with_lookup,with_copy", [(False, False), (True, False), (False, True)])
+def test_minimal_circuits(ctx, co, with_lookup, with_copy):
+    """no lookups, no permutation argument, no instance column, no challenge: every optional part of the proof absent in
+    turn (quotient degree 2 without a lookup: extended domain 2n)"""
+    from zkevm_circuits_amd import keygen, plonk
+    from zkevm_circuits_amd.plonk import Advice, Fixed, Product, Sub
+    k = 6
+    cs = plonk.ConstraintSystem(num_fixed_columns=2, num_advice_columns=2)
+    cs.gates = [[Product(Fixed(0), Sub(Product(Advice(0), Advice(0)), Advice(1)))]]
+    if with_lookup:
+        cs.lookups = [plonk.Lookup([Advice(0)], [Fixed(1)])]
+    if with_copy:
+        cs.permutation_columns = [(plonk.ANY_ADVICE, 0), (plonk.ANY_ADVICE, 1)]
+    dom = zk.Domain(ctx, cs.degree(), k)
+    assert dom.extended_k == k + (2 if with_lookup else 1)
+    n = dom.n
+    usable = n - (cs.blinding_factors() + 1)
+    a = [(3 * i) % 7 for i in range(usable)]
+    a[5], a[9] = 4, 16                                   # b[5] = a[5]^2 = a[9]
+    b = [v * v for v in a]
+    fixed = [[1] * usable + [0] * (n - usable), [i if i < usable else 0 for i in range(n)]]
+    asm = None
+    if with_copy:
+        asm = keygen.Assembly(n, 2)
+        asm.copy(1, 5, 0, 9)
+    params = prover.ParamsKZG(ctx, dom, _srs(co, n))
+    pk = prover.keygen(ctx, dom, params, cs, fixed, asm)
+    vk = {"fixed_commitments": pk.fixed_commitments, "permutation_commitments": pk.permutation_commitments,
+          "transcript_repr": pk.transcript_repr}
+    proof = prover.create_proof(ctx, dom, params, pk, [a, b], [], prover.FieldRng(3), prover.Blake2bWrite())
+    vm.verify_proof(cs, k, vk, [], proof, TAU)
+    b[11] += 1
+    proof = prover.create_proof(ctx, dom, params, pk, [a, b], [], prover.FieldRng(3), prover.Blake2bWrite())
+    with pytest.raises(vm.VerifyError):
+        vm.verify_proof(cs, k, vk, [], proof, TAU)
+    for p in pk.pointers():
+        ctx.free(p)
+    params.close()
+    dom.close()
