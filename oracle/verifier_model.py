@@ -155,8 +155,17 @@ def verify_proof(cs, k: int, vk: dict, instance, proof: bytes, tau: int) -> None
             raise VerifyError("InstanceTooLarge")
         for v in col:
             t.common_scalar(v)
-    advice_c = [t.read_point() for _ in range(cs.num_advice_columns)]
-    challenges = [t.squeeze_challenge() for _ in range(cs.num_challenges)]
+    advice_c = [None] * cs.num_advice_columns
+    challenges = [0] * cs.num_challenges
+    adv_phase = cs.advice_column_phase or [0] * cs.num_advice_columns
+    chl_phase = cs.challenge_phase or [0] * cs.num_challenges
+    for phase in sorted(set(adv_phase) | set(chl_phase)):       # per phase: its commitments, then its challenges
+        for c in range(cs.num_advice_columns):
+            if adv_phase[c] == phase:
+                advice_c[c] = t.read_point()
+        for c in range(cs.num_challenges):
+            if chl_phase[c] == phase:
+                challenges[c] = t.squeeze_challenge()
     theta = t.squeeze_challenge()
     lk_permuted = [(t.read_point(), t.read_point()) for _ in cs.lookups]
     beta = t.squeeze_challenge()

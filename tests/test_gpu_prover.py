@@ -260,3 +260,48 @@ def test_minimal_circuits(ctx, co, with_lookup, with_copy):
         ctx.free(p)
     params.close()
     dom.close()
+
+
+def test_two_phase_circuit(ctx, co):
+    """a second-phase advice column that depends on a first-phase challenge (r = c0 a, the shape of the reference's
+    challenge-compressed columns, /root/reference/zkevm-circuits/src/core_circuit.rs:153-154 and src/util.rs:63-67): the
+    witness callable runs once per phase, the commitments and challenges interleave per phase in the transcript"""
+    from zkevm_circuits_amd import keygen, plonk
+    from zkevm_circuits_amd.plonk import Advice, Challenge, Fixed, Product, Sub
+    k = 6
+    cs = plonk.ConstraintSystem(num_fixed_columns=1, num_advice_columns=3, num_challenges=2,
+                                advice_column_phase=[0, 1, 0], challenge_phase=[0, 1])
+    rel = Sub(Advice(1), Product(Challenge(0), Advice(0)))
+    cs.gates = [[Product(Fixed(0), rel), Product(Fixed(0), Product(Challenge(1), Product(rel, Advice(2, 1))))]]
+    cs.permutation_columns = [(plonk.ANY_ADVICE, 1), (plonk.ANY_ADVICE, 0)]
+    assert [ph for ph, _, _ in cs.phases()] == [0, 1]
+    dom = zk.Domain(ctx, cs.degree(), k)
+    n = dom.n
+    usable = n - (cs.blinding_factors() + 1)
+    a = [(5 * i + 1) % 11 for i in range(usable)]
+    a[3] = a[2]
+    other = [i * i for i in range(usable)]
+    calls = []
+
+    def witness(phase, challenges):
+        calls.append((phase, list(challenges)))
+        r = [challenges[0] * v % P for v in a] if phase == 1 else [0] * usable      # unknown in the first phase
+        return [a, r, other]
+    asm = keygen.Assembly(n, 2)
+    asm.copy(0, 2, 0, 3)                                 # r[2] = r[3], true because a[2] = a[3]
+    params = prover.ParamsKZG(ctx, dom, _srs(co, n))
+    pk = prover.keygen(ctx, dom, params, cs, [[1] * usable + [0] * (n - usable)], asm)
+    vk = {"fixed_commitments": pk.fixed_commitments, "permutation_commitments": pk.permutation_commitments,
+          "transcript_repr": pk.transcript_repr}
+    proof = prover.create_proof(ctx, dom, params, pk, witness, [], prover.FieldRng(3), prover.Blake2bWrite())
+    assert [c[0] for c in calls] == [0, 1] and calls[0][1] == [0, 0] and calls[1][1][0] != 0 and calls[1][1][1] == 0
+    vm.verify_proof(cs, k, vk, [], proof, TAU)
+    # a second-phase column computed from anything but the real challenge fails
+    proof = prover.create_proof(ctx, dom, params, pk, lambda ph, ch: [a, [7 * v for v in a], other], [], prover.FieldRng(3),
+                                prover.Blake2bWrite())
+    with pytest.raises(vm.VerifyError):
+        vm.verify_proof(cs, k, vk, [], proof, TAU)
+    for p in pk.pointers():
+        ctx.free(p)
+    params.close()
+    dom.close()

@@ -114,6 +114,17 @@ class ConstraintSystem:
     lookups: list = field(default_factory=list)        # list[Lookup]
     permutation_columns: list = field(default_factory=list)  # [(ANY_*, index)]
     minimum_degree: int | None = None
+    advice_column_phase: list | None = None            # phase of each advice column (None: all in the first phase)
+    challenge_phase: list | None = None                # phase after which each challenge is squeezed (None: the first)
+
+    def phases(self):
+        """[(phase, its advice columns, its challenges)] in proving order"""
+        adv = self.advice_column_phase or [0] * self.num_advice_columns
+        chl = self.challenge_phase or [0] * self.num_challenges
+        if len(adv) != self.num_advice_columns or len(chl) != self.num_challenges:
+            raise ValueError("phase lists do not match the column / challenge counts")
+        return [(ph, [c for c, p in enumerate(adv) if p == ph], [c for c, p in enumerate(chl) if p == ph])
+                for ph in sorted(set(adv) | set(chl))]
 
     def _memo(self, name, compute):
         """degree() and blinding_factors() walk every expression; callers ask for them per device call, so the values

@@ -12,7 +12,7 @@ What stays on the host is what upstream does on single field elements: the trans
 Differences from upstream that a byte-for-byte comparison would have to remove (none of them touches the device work):
 the verifying key's `transcript_repr` is a stand-in digest of its commitments (upstream hashes a debug print of the
 key), the random polynomial of the vanishing argument is drawn coefficient by coefficient from the one RNG (upstream
-draws it chunk-parallel from per-thread streams), all advice columns belong to the first phase, and the order of the
+draws it chunk-parallel from per-thread streams), and the order of the
 column queries follows first appearance in gates, lookups and permutation columns.  The compressed point encoding
 follows halo2curves 0.6.1 as published (little-endian x, sign of y in bit 6 and identity in bit 7 of the last byte).
 """
@@ -237,8 +237,10 @@ def keygen(ctx, dom, params: ParamsKZG, cs: ConstraintSystem, fixed, assembly) -
 def create_proof(ctx, dom, params: ParamsKZG, pk: ProvingKey, advice, instance, rng: FieldRng, transcript: Blake2bWrite,
                  timings: dict | None = None, dist=None):
     """One circuit.  advice: per column the values of the usable rows (a list of canonical integers, or a
-    (usable rows, 4) uint64 array of Montgomery limbs; the remaining rows are blinding); instance: per column at most
-    that many canonical integers.  Writes the proof into `transcript` and returns its bytes.  timings: filled with the wall
+    (usable rows, 4) uint64 array of Montgomery limbs; the remaining rows are blinding), or a callable
+    (phase, challenges so far) -> such a list, called once per phase of `cs.phases()` as upstream re-runs witness
+    synthesis per phase (only the phase's own columns are read from it); instance: per column at most that many
+    canonical integers.  Writes the proof into `transcript` and returns its bytes.  timings: filled with the wall
     seconds of each phase (the device is synchronised at every phase boundary, only when given).
     dist: an initialised torch.distributed module with one rank per GPU: every rank calls with the same arguments, the
     commitments are computed column-sharded and the quotient numerator coset-sharded (zkevm_circuits_amd/sharding.py), the
@@ -247,12 +249,12 @@ def create_proof(ctx, dom, params: ParamsKZG, pk: ProvingKey, advice, instance, 
     n, en = dom.n, dom.extended_len
     bf = cs.blinding_factors()
     usable = n - (bf + 1)
-    if len(advice) != cs.num_advice_columns or len(instance) != cs.num_instance_columns:
+    if (not callable(advice) and len(advice) != cs.num_advice_columns) or len(instance) != cs.num_instance_columns:
         raise ValueError("InvalidInstances / advice columns do not match the constraint system")
-    if any(len(c) != usable for c in advice) or any(len(c) > usable for c in instance):
-        raise ValueError("InstanceTooLarge / advice columns must hold the usable rows")
-    if any(isinstance(c, np.ndarray) and (c.dtype != np.uint64 or c.shape != (usable, 4)) for c in advice):
-        raise ValueError("an advice column given as an array holds (usable rows, 4) uint64 Montgomery limbs")
+    if any(len(c) > usable for c in instance):
+        raise ValueError("InstanceTooLarge")
+    if not callable(advice) and any(len(c) != usable for c in advice):
+        raise ValueError("an advice column holds the usable rows (integers, or (usable rows, 4) uint64 limbs)")
     omega = fr_from_mont_limbs(dom.constant(0))
     owned = []
 
@@ -286,7 +288,7 @@ def create_proof(ctx, dom, params: ParamsKZG, pk: ProvingKey, advice, instance, 
         transcript.common_scalar(pk.transcript_repr)
         # every polynomial that goes to coefficient form and to the extended domain later lives in one block, so that
         # those transforms run as batches: advice | instance | per lookup (z, a', s') | permutation z
-        n_adv, n_inst, n_lk, sets = len(advice), len(instance), len(cs.lookups), cs.num_permutation_sets()
+        n_adv, n_inst, n_lk, sets = cs.num_advice_columns, len(instance), len(cs.lookups), cs.num_permutation_sets()
         total = n_adv + n_inst + 3 * n_lk + sets
         block = alloc(n * max(total, 1))
         slot = [block + i * n * 32 for i in range(total)]
@@ -297,19 +299,28 @@ def create_proof(ctx, dom, params: ParamsKZG, pk: ProvingKey, advice, instance, 
             for v in col:
                 transcript.common_scalar(v)
             ctx.upload(fr_limbs(list(col) + [0] * (n - len(col))), d)
-        for col, d in zip(advice, adv):                         # the unusable rows of every column are blinding
-            blinding = fr_limbs([rng.fr() for _ in range(n - usable)])
-            if isinstance(col, np.ndarray):
-                ctx.upload(col, d)
-                ctx.upload(blinding, d + usable * 32)
-            else:
-                ctx.upload(np.concatenate([fr_limbs(col), blinding]), d)
-        for _ in adv:
-            rng.fr()                                            # one Blind per column: drawn, unused by KZG
-        if adv:
-            for jac in params.commit_lagrange(adv, dist):
-                transcript.write_point(jac)
-        challenges = [transcript.squeeze_challenge() for _ in range(cs.num_challenges)]
+        # per phase: the phase's columns are assigned (from the challenges of the phases before), blinded, committed
+        # and written, then the phase's challenges are squeezed
+        challenges = [0] * cs.num_challenges
+        for phase, columns, phase_challenges in cs.phases():
+            assigned = advice(phase, list(challenges)) if callable(advice) else advice
+            for c in columns:                                   # the unusable rows of every column are blinding
+                col, d = assigned[c], adv[c]
+                if len(col) != usable or (isinstance(col, np.ndarray) and (col.dtype != np.uint64 or col.shape != (usable, 4))):
+                    raise ValueError("an advice column holds the usable rows (integers, or (usable rows, 4) uint64 limbs)")
+                blinding = fr_limbs([rng.fr() for _ in range(n - usable)])
+                if isinstance(col, np.ndarray):
+                    ctx.upload(col, d)
+                    ctx.upload(blinding, d + usable * 32)
+                else:
+                    ctx.upload(np.concatenate([fr_limbs(col), blinding]), d)
+            for _ in columns:
+                rng.fr()                                        # one Blind per column: drawn, unused by KZG
+            if columns:
+                for jac in params.commit_lagrange([adv[c] for c in columns], dist):
+                    transcript.write_point(jac)
+            for c in phase_challenges:
+                challenges[c] = transcript.squeeze_challenge()
         ch_limbs = fr_limbs(challenges) if challenges else np.zeros((0, 4), dtype=np.uint64)
         theta = transcript.squeeze_challenge()
 
