@@ -3,6 +3,7 @@ format, and the multi-GPU partition helpers."""
 import random
 
 import numpy as np
+import pytest
 
 import bn254 as bn
 import halo2_model as hm
@@ -141,3 +142,34 @@ def test_shplonk_intermediate_sets_match_model():
     for points in ([5], [5, 9], [2, 3, 11, 17]):
         ev = [int(x) for x in rng.integers(0, 2 ** 62, size=len(points))]
         assert shplonk.lagrange_interpolate(points, ev) == hm.lagrange_interpolate(points, ev)
+
+
+def test_constraint_system_phases_and_memoised_degree():
+    from zkevm_circuits_amd import plonk
+    from zkevm_circuits_amd.plonk import Advice, Fixed, Product
+    cs = plonk.ConstraintSystem(num_fixed_columns=1, num_advice_columns=3, num_challenges=3,
+                                advice_column_phase=[0, 1, 0], challenge_phase=[0, 0, 1])
+    assert cs.phases() == [(0, [0, 2], [0, 1]), (1, [1], [2])]
+    assert plonk.ConstraintSystem(num_advice_columns=2, num_challenges=1).phases() == [(0, [0, 1], [0])]
+    with pytest.raises(ValueError):
+        plonk.ConstraintSystem(num_advice_columns=2, advice_column_phase=[0]).phases()
+    # degree() / blinding_factors() are cached and follow the gate list when it grows
+    assert cs.degree() == 3 and cs.blinding_factors() == 5
+    poly = Fixed(0)
+    for rot in range(-3, 3):
+        poly = Product(poly, Advice(0, rot))
+    cs.gates.append([poly])
+    assert cs.degree() == 7 and cs.blinding_factors() == 6 + 2
+    cs.lookups.append(plonk.Lookup([poly], [Fixed(0)]))
+    assert cs.degree() == 2 + 7 + 1
+
+
+def test_collect_queries_order():
+    from zkevm_circuits_amd import plonk, prover
+    from zkevm_circuits_amd.plonk import Advice, Fixed, Instance, Product, Sum
+    cs = plonk.ConstraintSystem(num_fixed_columns=2, num_advice_columns=3, num_instance_columns=1)
+    cs.gates = [[Product(Fixed(1), Sum(Advice(2, 1), Advice(0))), Product(Advice(2, 1), Instance(0, -1))]]
+    cs.lookups = [plonk.Lookup([Advice(0)], [Fixed(0)])]
+    cs.permutation_columns = [(plonk.ANY_ADVICE, 1), (plonk.ANY_INSTANCE, 0), (plonk.ANY_ADVICE, 0)]
+    adv, fix, inst = prover.collect_queries(cs)
+    assert adv == [(2, 1), (0, 0), (1, 0)] and fix == [(1, 0), (0, 0)] and inst == [(0, -1), (0, 0)]
