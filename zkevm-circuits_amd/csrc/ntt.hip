@@ -1,7 +1,7 @@
 // Radix-2^r Stockham NTT over BN254 Fr for gfx950.
 //
 // A transform of N = 2^L points runs as ceil(L / 8) out-of-place passes.  Pass p has radix R = 2^r and
-// Ns = product of the earlier radices; workgroup tiles are R x J elements (R*J = 2048, 64 KiB of LDS):
+// Ns = product of the earlier radices; workgroup tiles are R x J elements (R*J = 1024 elements):
 //   load   x[t][c] = in[(j0 + c) + t * N/R] * w_N^(t * ((j0+c) mod Ns) * N/(Ns R))      (J*32 B segments)
 //   R-point DIF butterflies on every column in LDS, twiddles w_R^k from an LDS table
 //   store  out[(j / Ns) * Ns * R + (j mod Ns) + q * Ns] = X[q]                           (natural order)
@@ -28,7 +28,7 @@
 namespace zkhip {
 
 constexpr int NTT_THREADS = 256;
-constexpr int TILE_LOG = 11;
+constexpr int TILE_LOG = 10;
 
 
 struct NttPassArgs {
@@ -511,7 +511,7 @@ int ntt_run(zkhip_ctx* ctx, const NttPlan* plan, const fe* src, size_t src_strid
     uint32_t logNs = 0;
     TimedRegion tr(ctx, "ntt");
     if (L >= TILE_LOG) {
-        // tile kernel: every pass has radix 2^5 .. 2^8 and a full 2048-element tile
+        // tile kernel: every pass has radix 2^3 .. 2^8 and a full tile of 2^TILE_LOG elements
         uint64_t k32[4];
         memcpy(k32, FrParams::TWO5, 32);
         for (uint32_t p = 0; p < npass; p++) {
