@@ -506,7 +506,7 @@ def finish(args, ctx, dist, world, rank, local_rank, bid, scalars, n, en, elapse
                              # and the last two read boundary twiddle tables (8 MB and 64 MB) by gather; the doubling of
                              # FETCH_SIZE that gfx950 needs for streaming reads over-counts those gathers, so this is an
                              # upper bound (profiles/r01_pmc_summary_v5.txt: 61.9e3 KiB read, 65.6e3 KiB written per launch)
-                             "traffic": 581.0e6, "traffic_unit": "bytes per transform (FETCH_SIZE x2 + WRITE_SIZE over its 3 launches, measured offline)",
+                             "traffic": 586.5e6, "traffic_unit": "bytes per transform (FETCH_SIZE x2 + WRITE_SIZE over its 3 launches, measured offline)",
                              "algorithmic_bytes": ntt_bytes,
                              # the transform is multiplier-bound, not HBM-bound: (M/2) log2 M butterfly products, two
                              # twiddle products per element between passes, the zeta scaling of 2/3 of the inputs
