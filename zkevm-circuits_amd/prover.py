@@ -336,9 +336,12 @@ def create_proof(ctx, dom, params: ParamsKZG, pk: ProvingKey, advice, instance, 
             blind_rows(d_pa, usable)
             blind_rows(d_ps, usable)
             rng.fr(), rng.fr()
-            for jac in params.commit_lagrange([d_pa, d_ps], dist):
-                transcript.write_point(jac)
             lookups.append([d_in, d_tb, d_pa, d_ps, 0])
+        # no challenge is squeezed between the lookups, so their commitments go out as one pipelined batch, written in
+        # upstream's order (a' then s' of each lookup)
+        if lookups:
+            for jac in params.commit_lagrange([p for lk in lookups for p in (lk[2], lk[3])], dist):
+                transcript.write_point(jac)
         beta = transcript.squeeze_challenge()
         gamma = transcript.squeeze_challenge()
 
