@@ -244,7 +244,8 @@ def create_proof(ctx, dom, params: ParamsKZG, pk: ProvingKey, advice, instance, 
     seconds of each phase (the device is synchronised at every phase boundary, only when given).
     dist: an initialised torch.distributed module with one rank per GPU: every rank calls with the same arguments, the
     commitments are computed column-sharded and the quotient numerator coset-sharded (zkevm_circuits_amd/sharding.py), the
-    rest is replicated; every rank returns the same bytes as a single-rank call."""
+    rest is replicated; every rank returns the same bytes as a single-rank call.  A rank that raises (a lookup input
+    outside its table, say) does so on every rank alike, since all ranks hold the same witness."""
     cs = pk.cs
     n, en = dom.n, dom.extended_len
     bf = cs.blinding_factors()
