@@ -4,7 +4,7 @@ tests/golden/gen_proof_golden.py."""
 import numpy as np
 
 import bn254 as bn
-from util import affine_arr, affine_pt, fr_arr
+from util import affine_pt, fr_arr
 
 from zkevm_circuits_amd import keygen, plonk, synthetic
 
