@@ -389,14 +389,17 @@ struct EvalQuery {
     const fe* coeff;
     fe x, x_per;
 };
+// Coefficients per lane of the batched kernel: with many queries in flight there are lanes enough, and a longer Horner
+// run amortises the lane's x_per^t (up to 2 log2(t) products) over four times as many coefficients.
+constexpr int EPB_PER = 64;
 __global__ void __launch_bounds__(PO_THREADS) eval_poly_batch_kernel(const EvalQuery* queries, size_t n, fe* partial) {
     __shared__ fe sh[PO_THREADS];
     const EvalQuery q = queries[blockIdx.y];
     const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const size_t base = t * EP_PER;
+    const size_t base = t * EPB_PER;
     fe acc = Fr::zero();
     if (base < n) {
-        const size_t hi = base + EP_PER < n ? base + EP_PER : n;
+        const size_t hi = base + EPB_PER < n ? base + EPB_PER : n;
         for (size_t i = hi; i-- > base;) acc = Fr::add(Fr::mul(acc, q.x), load_fe(q.coeff + i));
         fe p = Fr::one(), b = q.x_per;
         for (size_t e = t; e; e >>= 1) {
@@ -590,7 +593,7 @@ int zkhip_eval_polynomials_dev(zkhip_ctx* ctx, const uint64_t* const* d_coeffs, 
     if (n == 0) return ZKHIP_OK;
     for (uint32_t i = 0; i < count; i++) ZK_CHECK(ctx, d_coeffs[i], "eval_polynomials: null polynomial %u", i);
     ZK_HIP(ctx, hipSetDevice(ctx->device));
-    const size_t lanes = (n + EP_PER - 1) / EP_PER;
+    const size_t lanes = (n + EPB_PER - 1) / EPB_PER;
     const size_t nblocks = (lanes + PO_THREADS - 1) / PO_THREADS;
     const uint32_t chunk_max = 16384;   // queries per launch (gridDim.y limit is 65535)
     std::vector<EvalQuery> q(std::min(count, chunk_max));
@@ -604,7 +607,7 @@ int zkhip_eval_polynomials_dev(zkhip_ctx* ctx, const uint64_t* const* d_coeffs, 
             q[i].coeff = (const fe*)d_coeffs[first + i];
             memcpy(q[i].x.l, points + 4 * (size_t)(first + i), 32);
             uint64_t x_per[4];
-            h_pow(HFR, x_per, points + 4 * (size_t)(first + i), EP_PER);
+            h_pow(HFR, x_per, points + 4 * (size_t)(first + i), EPB_PER);
             memcpy(q[i].x_per.l, x_per, 32);
         }
         fe* d_part = (fe*)((unsigned char*)ctx->scratch + qbytes);
