@@ -214,7 +214,7 @@ def test_full_size_wide_proof_verifies(ctx, co, units, extra_gates):
           f"verify {time.perf_counter() - t2:.1f} s, proof {len(proof)} bytes; phases "
           + ", ".join(f"{name} {sec:.2f}" for name, sec in phases.items()))
     assert set(phases) == {"advice", "lookup_permuted", "permutation_product", "lookup_product", "random_poly", "quotient",
-                           "evaluations", "multiopen"}
+                           "quotient_evaluate_h", "quotient_pieces", "evaluations", "multiopen"}
     for p in pk.pointers():
         ctx.free(p)
     params.close()

@@ -411,6 +411,7 @@ def create_proof(ctx, dom, params: ParamsKZG, pk: ProvingKey, advice, instance, 
             for s0 in range(0, total, BATCH):
                 dom.coeff_to_extended_dev(slot[s0], ext_block + s0 * en * 32, min(BATCH, total - s0))
             fill(lambda p: ext_block + (p - block) // (n * 32) * en * 32, lambda p: p)
+            mark("quotient_evaluate_h")
             dom.evaluate_h(call.build(ffi.MEM_DEVICE, ffi.FORM_EXTENDED), d_h)
         else:
             import torch
@@ -442,6 +443,7 @@ def create_proof(ctx, dom, params: ParamsKZG, pk: ProvingKey, advice, instance, 
             for cosets, rows in pieces:
                 dom.cosets_to_extended_dev(rows.data_ptr(), cosets, d_h)
             ctx.sync()
+        mark("quotient_pieces")
         dom.divide_by_vanishing_poly_dev(d_h)
         pieces = dom.quotient_poly_degree
         d_hc = alloc(n * pieces)
