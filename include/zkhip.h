@@ -220,6 +220,12 @@ int zkhip_evaluate_h_last_stats(zkhip_ctx* ctx, uint64_t out[4]);
  *     a(X) by (X - point); the remainder a(point) is dropped, as upstream drops it.  d_out must not overlap d_poly. */
 int zkhip_batch_invert_dev(zkhip_ctx* ctx, int field, uint64_t* d_a, size_t n);
 int zkhip_prefix_product_dev(zkhip_ctx* ctx, const uint64_t* d_m, uint64_t* d_out, size_t n, const uint64_t init[4]);
+/* zkhip_prefix_product_dev for callers that cannot allocate device memory (code under HIP graph capture, tight serving
+ * loops, harnesses that forbid hipMalloc).  It has no counterpart in the reference.  Same arguments and results as
+ * zkhip_prefix_product_dev; the per-block totals live in a static device array of 256 KiB per GPU instead of the
+ * context's growable scratch buffer, so the call performs no hipMalloc / hipFree.  n is limited to 2^24 elements
+ * (ZKHIP_ERR_INVALID beyond).  All contexts on one GPU share that array: calls that overlap on one GPU race. */
+int zkhip_prefix_product_noalloc_dev(zkhip_ctx* ctx, const uint64_t* d_m, uint64_t* d_out, size_t n, const uint64_t init[4]);
 int zkhip_permutation_product_dev(zkhip_domain* dom, const uint64_t* const* d_values, const uint64_t* const* d_sigmas,
                                   uint32_t num_cols, const uint64_t beta[4], const uint64_t gamma[4],
                                   const uint64_t delta_start[4], const uint64_t z0[4], uint64_t* d_z);

@@ -9,6 +9,7 @@ using namespace zkhip;
 namespace zkhip {
 int msm_init(zkhip_ctx* ctx);
 void msm_drop_ctx(zkhip_ctx* ctx);
+int poly_ops_init(zkhip_ctx* ctx);
 
 int set_error(zkhip_ctx* ctx, int code, const char* fmt, ...) {
     char buf[512];
@@ -122,7 +123,7 @@ int zkhip_create(int device, zkhip_ctx** out) {
         return ZKHIP_ERR_HIP;
     }
     ctx->stream = ctx->own_stream;
-    if (ntt_init(ctx) != ZKHIP_OK || msm_init(ctx) != ZKHIP_OK) {
+    if (ntt_init(ctx) != ZKHIP_OK || msm_init(ctx) != ZKHIP_OK || poly_ops_init(ctx) != ZKHIP_OK) {
         delete ctx;
         return ZKHIP_ERR_HIP;
     }

@@ -458,7 +458,43 @@ static int prefix_product_dev(zkhip_ctx* ctx, const fe* d_m, fe* d_out, fe* d_to
 
 }  // namespace zkhip
 
+// ---- running product for callers that cannot allocate ---------------------------------------------------
+// Block totals of zkhip_prefix_product_noalloc_dev: one element per block of PP_BLOCK inputs.  The array belongs to the
+// code object, so every GPU the library runs on holds its own copy at its own address for the life of the process.
+// Host code never passes the array's name to a kernel (on the host it is a stand-in, not a device address):
+// poly_ops_init resolves the address once per device and the entry point hands that pointer to the kernels.
+constexpr size_t PPNA_MAX_N = (size_t)1 << 24;
+constexpr size_t PPNA_MAX_BLOCKS = PPNA_MAX_N / zkhip::PP_BLOCK;
+static __device__ __align__(256) unsigned char scratch[PPNA_MAX_BLOCKS * 32];
+constexpr int PPNA_MAX_DEVICES = 64;
+static void* g_static_totals[PPNA_MAX_DEVICES];   // device address of `scratch` on each device, nullptr until resolved
+
+namespace zkhip {
+// called by zkhip_create with the context's device current
+int poly_ops_init(zkhip_ctx* ctx) {
+    if (ctx->device < 0 || ctx->device >= PPNA_MAX_DEVICES) return ZKHIP_OK;   // the no-alloc entry point reports it
+    if (g_static_totals[ctx->device]) return ZKHIP_OK;
+    void* ptr = nullptr;
+    ZK_HIP(ctx, hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch)));
+    g_static_totals[ctx->device] = ptr;
+    return ZKHIP_OK;
+}
+}  // namespace zkhip
+
 extern "C" {
+
+int zkhip_prefix_product_noalloc_dev(zkhip_ctx* ctx, const uint64_t* d_m, uint64_t* d_out, size_t n, const uint64_t init[4]) {
+    if (!ctx) return ZKHIP_ERR_INVALID;
+    ZK_CHECK(ctx, (d_m && d_out && init) || n == 0, "prefix_product_noalloc: null pointer");
+    ZK_CHECK(ctx, n <= PPNA_MAX_N, "prefix_product_noalloc: %zu elements, the static block-total buffer holds at most %zu",
+             n, PPNA_MAX_N);
+    ZK_CHECK(ctx, ctx->device >= 0 && ctx->device < PPNA_MAX_DEVICES && g_static_totals[ctx->device],
+             "prefix_product_noalloc: the static buffer was not resolved on device %d", ctx->device);
+    ZK_HIP(ctx, hipSetDevice(ctx->device));
+    // every block total the second and third kernel read is written by the first kernel of this same call, so nothing
+    // left over from an earlier call is ever read and nothing needs clearing
+    return prefix_product_dev(ctx, (const fe*)d_m, (fe*)d_out, (fe*)g_static_totals[ctx->device], n, fe_from(init));
+}
 
 int zkhip_batch_invert_dev(zkhip_ctx* ctx, int field, uint64_t* d_a, size_t n) {
     if (!ctx) return ZKHIP_ERR_INVALID;

@@ -29,7 +29,7 @@ EXPORTS = [
     "zkhip_extended_to_coeff_dev", "zkhip_divide_by_vanishing_poly_dev",
     "zkhip_evaluate_h", "zkhip_evaluate_h_last_stats",
     "zkhip_coeff_to_cosets_dev", "zkhip_extended_to_cosets_dev", "zkhip_cosets_to_extended_dev",
-    "zkhip_batch_invert_dev", "zkhip_prefix_product_dev", "zkhip_permutation_product_dev", "zkhip_lookup_product_dev",
+    "zkhip_batch_invert_dev", "zkhip_prefix_product_dev", "zkhip_prefix_product_noalloc_dev", "zkhip_permutation_product_dev", "zkhip_lookup_product_dev",
     "zkhip_eval_polynomial_dev", "zkhip_eval_polynomials_dev", "zkhip_poly_lincomb_dev", "zkhip_kate_division_dev", "zkhip_lookup_permute_dev", "zkhip_permutation_sigma_dev",
     "zkhip_timing_enable", "zkhip_timing_reset", "zkhip_timing_get",
 ]
@@ -290,6 +290,11 @@ class Context:
     def prefix_product_dev(self, d_m: int, d_out: int, n: int, init):
         init = u64(init)
         self._ck(self._l.zkhip_prefix_product_dev(self.h, C.c_void_p(d_m), C.c_void_p(d_out), C.c_size_t(n), _p(init)))
+
+    def prefix_product_noalloc_dev(self, d_m: int, d_out: int, n: int, init):
+        """prefix_product_dev over the library's static block-total buffer: no device allocation, n <= 2^24"""
+        init = u64(init)
+        self._ck(self._l.zkhip_prefix_product_noalloc_dev(self.h, C.c_void_p(d_m), C.c_void_p(d_out), C.c_size_t(n), _p(init)))
 
     def eval_polynomial_dev(self, d_coeff: int, n: int, x):
         x = u64(x)
