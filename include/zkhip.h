@@ -191,6 +191,15 @@ int zkhip_evaluate_h(zkhip_domain* dom, const zkhip_evalh_desc* desc, uint64_t* 
  * out[1] field multiplications, out[2] column reads, out[3] value slots (for throughput accounting; no reference
  * counterpart). */
 int zkhip_evaluate_h_last_stats(zkhip_ctx* ctx, uint64_t out[4]);
+/* The fused program depends on the graphs and counts of the descriptor only, so the context keeps it per shape (upstream
+ * builds `Evaluator` once per proving key, `ProvingKey::ev`); a later call of the same shape links it against its column
+ * pointers and allocates nothing for device-resident extended columns.  out[0] = programs built, out[1] = calls served
+ * from the cache, on this context so far (no reference counterpart). */
+int zkhip_evaluate_h_cache_stats(zkhip_ctx* ctx, uint64_t out[2]);
+/* Builds and keeps the program of the descriptor's shape without evaluating anything: `Evaluator::new(cs)` as key
+ * generation runs it (`ProvingKey::ev`).  Only the counts, the graphs and the permutation column kinds / indices of the
+ * descriptor are read; every polynomial pointer may be NULL. */
+int zkhip_evaluate_h_prepare(zkhip_domain* dom, const zkhip_evalh_desc* desc);
 
 /* ------------------------------------------------------------------ grand products and openings -----
  * The prover steps adjacent to the hot path (the rest of `plonk::prover::create_proof`, reached from

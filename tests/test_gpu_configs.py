@@ -1,0 +1,159 @@
+"""GPU suite, the benchmark's configurations that the kernel-level parity tests do not reach by themselves:
+  * the aggregation circuit's sizes (k = 22: the fast setting of /root/reference/prover/src/constants.rs:33-36, bases and
+    domains four to eight times the SuperCircuit's; /root/reference/aggregate-zkevm/src/main.rs:203,213),
+  * the fast_test SuperCircuit shape (k = 15, extended domain 8n, about 230 advice columns;
+    /root/reference/zkevm-circuits/benches/benchmark_list/call_trace.rs:15-17),
+  * a k = 19 stand-in that carries the SuperCircuit's hard features together (keccak rotations up to +204, 32 blinding
+    factors, ten-column lookups into advice tables, second-phase columns and three challenges), proved and verified,
+  * MSM base sets with duplicate points, P / -P pairs and the identity, which drive the bucket pipeline through the
+    P = +-Q branches of its point additions."""
+import time
+
+import numpy as np
+import pytest
+
+import bn254 as bn
+import verifier_model as vm
+from prover_cases import TAU, srs as _srs
+from test_gpu_parity import check_coset_extension_properties, check_evaluate_h_sampled_rows
+from util import affine_pt, fq_arr, fq_ints, fr_arr, fr_ints, rand_fr, witness_like
+
+from zkevm_circuits_amd import prover, synthetic
+import zkevm_circuits_amd as zk
+
+pytestmark = pytest.mark.gpu
+P = bn.FR_MODULUS
+
+
+# ------------------------------------------------------------------------------------------------ aggregation sizes
+def test_aggregation_size_msm_known_answer(ctx):
+    """2^22 bases (i+1)G, uniform and witness-like scalars: sum_i s_i (i+1) G against one scalar multiplication"""
+    n = 1 << 22
+    rng = np.random.default_rng(22)
+    bid = ctx.register_bases(ctx.g1_multiples(n))
+    to_mont = lambda c: ctx.field_binop(0, 2, c, np.repeat(fr_arr([(1 << 256) % P]), len(c), axis=0))
+    weights = np.arange(1, n + 1, dtype=object)
+    for name in ("uniform", "witness"):
+        sc = rand_fr(rng, n) if name == "uniform" else witness_like(rng, n, to_mont)
+        k = int(np.dot(np.array(fr_ints(sc), dtype=object), weights)) % P
+        assert affine_pt(ctx.g1_to_affine(ctx.msm(bid, sc))) == bn.g1_mul(bn.G1_GENERATOR, k), name
+    ctx.release_bases(bid)
+
+
+def test_aggregation_size_coset_extension(ctx, co):
+    """2^22 -> 2^23 (quotient degree 2): sampled outputs against big-int Horner, inversion, linearity"""
+    check_coset_extension_properties(ctx, co, 22, 3, 23)
+
+
+def test_aggregation_size_evaluate_h_sampled_rows(ctx):
+    """k = 22, extended domain 2^23: a halo2-base-like constraint system (24 advice columns, gates of degree three over
+    rotations 0..3, 26 permutation columns, no lookup) on sampled rows against the big-int model"""
+    cs = synthetic.synthetic_cs(num_advice=24, num_fixed=4, num_instance=1, num_gate_polys=24, max_degree=3,
+                                rotations=(0, 1, 2, 3), num_lookups=0, num_perm_cols=26)
+    assert cs.degree() == 3 and cs.num_permutation_sets() == 26
+    check_evaluate_h_sampled_rows(ctx, 22, cs)
+
+
+# ------------------------------------------------------------------------------------------------ whole proofs
+def _prove_and_verify(ctx, co, k, cs, seed, active_rows, label):
+    dom = zk.Domain(ctx, cs.degree(), k)
+    params = prover.ParamsKZG(ctx, dom, _srs(co, dom.n))
+    advice, instance, fixed, asm = synthetic.standin_witness(cs, dom.n, seed, active_rows=active_rows)
+    t0 = time.perf_counter()
+    pk = prover.keygen(ctx, dom, params, cs, fixed, asm)
+    t1 = time.perf_counter()
+    phases = {}
+    proof = prover.create_proof(ctx, dom, params, pk, advice, instance, prover.FieldRng(seed), prover.Blake2bWrite(), phases)
+    t2 = time.perf_counter()
+    vk = {"fixed_commitments": pk.fixed_commitments, "permutation_commitments": pk.permutation_commitments,
+          "transcript_repr": pk.transcript_repr}
+    vm.verify_proof(cs, k, vk, instance, proof, TAU)
+    print(f"{label}: k={k} extended_k={dom.extended_k}, {cs.num_advice_columns} advice columns, {len(cs.lookups)} lookups, "
+          f"{len(cs.permutation_columns)} permutation columns in {cs.num_permutation_sets()} sets, "
+          f"{sum(len(g) for g in cs.gates)} gate polynomials, blinding_factors {cs.blinding_factors()}: "
+          f"keygen {t1 - t0:.2f} s, create_proof {t2 - t1:.2f} s, verify {time.perf_counter() - t2:.1f} s, "
+          f"proof {len(proof)} bytes; phases " + ", ".join(f"{name} {sec:.2f}" for name, sec in phases.items()))
+    # a proof over a witness with one wrong cell in a keccak-like lane (or, without lanes, a wide lookup's second-phase
+    # compression) does not verify
+    info = cs._standin
+    bad_col = info["lanes"][0][2] if info["lanes"] else info["second"][1]
+
+    def broken(phase, challenges):
+        cols = list(advice(phase, challenges))
+        if phase == 1 or info["lanes"]:
+            a = cols[bad_col].copy()
+            a[20, 0] ^= np.uint64(1)
+            cols[bad_col] = a
+        return cols
+    bad = prover.create_proof(ctx, dom, params, pk, broken, instance, prover.FieldRng(seed), prover.Blake2bWrite())
+    with pytest.raises(vm.VerifyError):
+        vm.verify_proof(cs, k, vk, instance, bad, TAU)
+    for p in pk.pointers():
+        ctx.free(p)
+    params.close()
+    dom.close()
+
+
+def test_fast_test_shape_proof_verifies(ctx, co):
+    """the fast_test SuperCircuit's shape (no keccak, no fixed-table circuit): k = 15, extended domain 2^18, 234 advice
+    columns in two phases, 43 lookups of which three are eight columns wide, three challenges"""
+    cs = synthetic.standin_cs(units=40, lanes=0, wide_lookups=3, lookup_width=8, extra_gates=4)
+    assert cs.degree() == 9 and cs.num_advice_columns == 234 and len(cs.lookups) == 43
+    _prove_and_verify(ctx, co, 15, cs, 15, 2000, "fast_test shape")
+
+
+def test_supercircuit_standin_proof_verifies(ctx, co):
+    """k = 19, extended domain 2^22: 52 units + 8 keccak-like lanes (rotations 0..11, 12..204 in steps of 12, -12, hence 32
+    blinding factors and a last rotation of -33 in the permutation argument) + 8 ten-column lookups into advice tables +
+    two second-phase columns and three challenges, 2000 extra gate polynomials of degree up to nine"""
+    cs = synthetic.standin_cs(units=52, lanes=8, wide_lookups=8, lookup_width=10, extra_gates=38)
+    assert cs.degree() == 9 and cs.blinding_factors() == 32 and cs.num_advice_columns == 376 and len(cs.lookups) == 60
+    assert sum(len(g) for g in cs.gates) > 2000
+    _prove_and_verify(ctx, co, 19, cs, 19, 3000, "SuperCircuit stand-in")
+
+
+# ------------------------------------------------------------------------------------------------ degenerate base sets
+def _degenerate_bases(ctx, rng, n):
+    """n bases drawn from {+-G, +-2G, +-3G, the identity}: (points as (n, 8) limbs, their multipliers of G)"""
+    table = ctx.g1_multiples(3)                                  # G, 2G, 3G
+    neg = table.copy()
+    neg[:, 4:] = fq_arr([(bn.FQ_MODULUS - y) % bn.FQ_MODULUS for y in fq_ints(table[:, 4:])])
+    pts = np.concatenate([table, neg, np.zeros((1, 8), dtype=np.uint64)])
+    mult = np.array([1, 2, 3, -1, -2, -3, 0], dtype=np.int64)
+    pick = rng.integers(0, 7, size=n)
+    return pts[pick], mult[pick]
+
+
+@pytest.mark.parametrize("n", [4099, 1 << 19])
+def test_msm_with_duplicate_negated_and_identity_bases(ctx, co, n):
+    """Base sets made of seven distinct values -- G, 2G, 3G, their negatives and the identity -- so that nearly every
+    addition inside a bucket meets an equal point, its negative or the identity.  Scalars: (a) all in {1, 2, 3}, i.e. one
+    window with three buckets of n / 3 entries each, where the slot sums of a bucket (a few dozen entries each) collide
+    often enough that the merge levels add equal and opposite partial sums too; (b) uniform, every window in use.
+    Against the closed form (sum_i s_i m_i) G and, at the small size, the C oracle's Pippenger."""
+    rng = np.random.default_rng(n)
+    bases, mult = _degenerate_bases(ctx, rng, n)
+    bid = ctx.register_bases(bases)
+    small = np.zeros((n, 4), dtype=np.uint64)
+    small[:, 0] = rng.integers(1, 4, size=n, dtype=np.uint64)
+    to_mont = lambda c: ctx.field_binop(0, 2, c, np.repeat(fr_arr([(1 << 256) % P]), len(c), axis=0))
+    m_obj = mult.astype(object)
+    for name, sc in (("small", to_mont(small)), ("uniform", rand_fr(rng, n))):
+        k = int(np.dot(np.array(fr_ints(sc), dtype=object), m_obj)) % P
+        got = ctx.g1_to_affine(ctx.msm(bid, sc))
+        exp = bn.g1_mul(bn.G1_GENERATOR, k) if k else None
+        assert affine_pt(got) == exp, name
+        if n < 10000:
+            assert np.array_equal(got, co.g1_to_affine(co.best_multiexp(sc, bases, threads=4))), name
+    ctx.release_bases(bid)
+    # a base set that cancels exactly (every point followed by its negative), all scalars equal: the sum is the identity
+    half = bases[: n // 2]
+    negd = half.copy()
+    ys = fq_ints(half[:, 4:])
+    negd[:, 4:] = fq_arr([(bn.FQ_MODULUS - y) % bn.FQ_MODULUS for y in ys])
+    pairs = np.empty((2 * len(half), 8), dtype=np.uint64)
+    pairs[0::2], pairs[1::2] = half, negd
+    bid = ctx.register_bases(pairs)
+    same = np.repeat(rand_fr(rng, 1), len(pairs), axis=0)
+    assert not ctx.g1_to_affine(ctx.msm(bid, same)).any()
+    ctx.release_bases(bid)

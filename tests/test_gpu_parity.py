@@ -248,8 +248,10 @@ def test_domain_vs_oracle_batched(ctx, co, j, k):
 def test_coset_extension_full_size_properties(ctx, co, ext_k):
     """k = 19 -> 2^21 / 2^22: (a) a few outputs against direct evaluation p(zeta * w^i) by Horner on big ints,
     (b) extended_to_coeff inverts coeff_to_extended, (c) linearity."""
-    k = 19
-    j = 5 if ext_k == 21 else 9
+    check_coset_extension_properties(ctx, co, 19, 5 if ext_k == 21 else 9, ext_k)
+
+
+def check_coset_extension_properties(ctx, co, k, j, ext_k):
     d = zk.Domain(ctx, j, k)
     assert d.extended_k == ext_k
     rng = np.random.default_rng(ext_k)
@@ -332,6 +334,33 @@ def test_evaluate_h_vs_oracle(ctx, co, k, kw):
     # quotient tail: divide by the vanishing polynomial, back to coefficients
     assert np.array_equal(d.extended_to_coeff(d.divide_by_vanishing_poly(exp)),
                           od.extended_to_coeff(od.divide_by_vanishing_poly(exp)))
+    d.close()
+
+
+def test_evaluate_h_program_is_built_once_per_shape(ctx, co):
+    """The fused program is kept per constraint-system shape (upstream: `ProvingKey::ev`): a second call with other
+    columns, challenges and another extended size reuses it, a different shape builds its own, and every result still
+    equals the oracle's."""
+    cs = synthetic.synthetic_cs(num_advice=10, num_gate_polys=24, num_lookups=2, num_perm_cols=5, seed=77)
+    ev = plonk.Evaluator(cs)
+    before = ctx.evaluate_h_cache_stats()
+    for rnd, k in ((1, 7), (2, 7), (3, 8)):
+        d, od = zk.Domain(ctx, cs.degree(), k), co.Domain(cs.degree(), k, threads=8)
+        call, _, ext = _random_call(cs, np.random.default_rng(100 + rnd), d.n, d.extended_len, od)
+        call.ev = ev
+        call.advice, call.instance, call.lookups = ext["advice"], ext["instance"], ext["lookups"]
+        desc = call.build(ffi.MEM_HOST, ffi.FORM_EXTENDED)
+        assert np.array_equal(d.evaluate_h(desc), od.evaluate_h(desc))
+        d.close()
+    after = ctx.evaluate_h_cache_stats()
+    assert after["builds"] - before["builds"] == 1 and after["hits"] - before["hits"] == 2
+    cs2 = synthetic.synthetic_cs(num_advice=10, num_gate_polys=24, num_lookups=2, num_perm_cols=5, seed=78)
+    d, od = zk.Domain(ctx, cs2.degree(), 7), co.Domain(cs2.degree(), 7, threads=8)
+    call, _, ext = _random_call(cs2, np.random.default_rng(5), d.n, d.extended_len, od)
+    call.advice, call.instance, call.lookups = ext["advice"], ext["instance"], ext["lookups"]
+    desc = call.build(ffi.MEM_HOST, ffi.FORM_EXTENDED)
+    assert np.array_equal(d.evaluate_h(desc), od.evaluate_h(desc))
+    assert ctx.evaluate_h_cache_stats()["builds"] - after["builds"] == 1
     d.close()
 
 
@@ -1228,10 +1257,12 @@ def test_evaluate_h_full_size_sampled_rows(ctx, kw):
     """k = 19 with all columns resident on the device -- the benchmark's constraint system (extended domain 2^21, 143
     columns) and a degree-9 one (extended domain 2^22, as the SuperCircuit): rows sampled over the whole domain (first,
     last, wrap-around neighbours of the rotations, random) against the big-int model evaluated on those rows only"""
+    check_evaluate_h_sampled_rows(ctx, 19, synthetic.synthetic_cs(**kw))
+
+
+def check_evaluate_h_sampled_rows(ctx, k, cs):
     import torch
     import halo2_model as hm
-    k = 19
-    cs = synthetic.synthetic_cs(**kw)
     d = zk.Domain(ctx, cs.degree(), k)
     en = d.extended_len
     gen = torch.Generator(device="cuda")

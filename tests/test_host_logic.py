@@ -81,6 +81,21 @@ def test_constraint_system_quantities():
     assert hm.EvaluationDomain(9, 19).extended_k == 22
 
 
+def test_blinding_factors_count_the_equality_query():
+    """a permutation column queried by gates only at rotations 1, 2, 3 is also queried at rotation 0 by enable_equality:
+    four distinct queries, blinding_factors = 4 + 2"""
+    cs = plonk.ConstraintSystem(num_fixed_columns=1, num_advice_columns=2)
+    e = plonk.Advice(0, 1)
+    for r in (2, 3):
+        e = plonk.Sum(e, plonk.Advice(0, r))
+    cs.gates = [[plonk.Product(plonk.Fixed(0), e)]]
+    assert cs.blinding_factors() == 5
+    cs.permutation_columns = [(plonk.ANY_ADVICE, 0)]
+    assert cs.blinding_factors() == 6
+    cs.permutation_columns = [(plonk.ANY_ADVICE, 1), (plonk.ANY_FIXED, 0)]
+    assert cs.blinding_factors() == 5
+
+
 def test_wire_format_roundtrip():
     cs = synthetic.synthetic_cs(num_gate_polys=8)
     ev = plonk.Evaluator(cs)
@@ -173,3 +188,62 @@ def test_collect_queries_order():
     cs.permutation_columns = [(plonk.ANY_ADVICE, 1), (plonk.ANY_INSTANCE, 0), (plonk.ANY_ADVICE, 0)]
     adv, fix, inst = prover.collect_queries(cs)
     assert adv == [(2, 1), (0, 0), (1, 0)] and fix == [(1, 0), (0, 0)] and inst == [(0, -1), (0, 0)]
+
+
+def _eval_on_row(e, cols, challenges, i, n):
+    t = e[0]
+    if t == "const":
+        return e[1]
+    if t in ("fixed", "advice", "instance"):
+        return cols[t][e[1]][(i + e[2]) % n]
+    if t == "challenge":
+        return challenges[e[1]]
+    if t == "neg":
+        return -_eval_on_row(e[1], cols, challenges, i, n) % P
+    if t == "scaled":
+        return _eval_on_row(e[1], cols, challenges, i, n) * e[2] % P
+    a, b = _eval_on_row(e[1], cols, challenges, i, n), _eval_on_row(e[2], cols, challenges, i, n)
+    return (a + b) % P if t == "sum" else a * b % P
+
+
+def test_standin_witness_satisfies_its_constraint_system():
+    """what `MockProver::assert_satisfied` checks, for the SuperCircuit stand-in of the benchmark and the GPU suite: every
+    gate polynomial vanishes on every usable row (the unusable rows hold random values, as the prover's blinding rows
+    do), every lookup input row is a row of its table, the copy constraints hold; the shape carries the keccak rotation
+    set, 32 blinding factors, wide lookups into advice tables and second-phase columns"""
+    from zkevm_circuits_amd.synthetic import fr_from_limbs_rows
+    k = 10
+    n = 1 << k
+    cs = synthetic.standin_cs(units=3, lanes=2, wide_lookups=2, lookup_width=8, extra_gates=3)
+    assert cs.degree() == 9 and cs.blinding_factors() == 32 and cs.num_challenges == 3
+    assert [len(c) for _, c, _ in cs.phases()] == [cs.num_advice_columns - 2, 2]
+    rots = {r for g in cs.gates for p in g for (t, _, r) in _queries(p) if t == "advice"}
+    assert {204, -12, 11} <= rots
+    assert max(len(lk.input_expressions) for lk in cs.lookups) == 8
+    advice_for, instance, fixed, asm = synthetic.standin_witness(cs, n, 5, active_rows=400)
+    usable = n - (cs.blinding_factors() + 1)
+    challenges = [random.Random(9).randrange(P) for _ in range(3)]
+    first, second = advice_for(0, [0, 0, 0]), advice_for(1, challenges)
+    assert all(np.array_equal(a, b) for a, b in zip(first[:-2], second[:-2])) and not first[-1].any()
+    rnd = random.Random(1)
+    cols = {"advice": [fr_from_limbs_rows(a) + [rnd.randrange(P) for _ in range(n - usable)] for a in second],
+            "fixed": [[v % P for v in c] for c in fixed],
+            "instance": [list(c) + [0] * (n - len(c)) for c in instance]}
+    for gate in cs.gates:
+        for poly in gate:
+            assert all(_eval_on_row(poly, cols, challenges, i, n) == 0 for i in range(usable))
+    for lk in cs.lookups:
+        table = {tuple(_eval_on_row(e, cols, challenges, i, n) for e in lk.table_expressions) for i in range(usable)}
+        assert all(tuple(_eval_on_row(e, cols, challenges, i, n) for e in lk.input_expressions) in table for i in range(usable))
+    name = {plonk.ANY_ADVICE: "advice", plonk.ANY_FIXED: "fixed", plonk.ANY_INSTANCE: "instance"}
+    for c, (kind, idx) in enumerate(cs.permutation_columns):
+        for r in range(usable):
+            c2, r2 = int(asm.map_col[c][r]), int(asm.map_row[c][r])
+            k2, i2 = cs.permutation_columns[c2]
+            assert cols[name[kind]][idx][r] == cols[name[k2]][i2][r2]
+
+
+def _queries(e):
+    out = set()
+    plonk._walk_queries(e, out)
+    return out

@@ -10,6 +10,7 @@ namespace zkhip {
 int msm_init(zkhip_ctx* ctx);
 void msm_drop_ctx(zkhip_ctx* ctx);
 int poly_ops_init(zkhip_ctx* ctx);
+void evalh_drop_ctx(zkhip_ctx* ctx);
 
 int set_error(zkhip_ctx* ctx, int code, const char* fmt, ...) {
     char buf[512];
@@ -136,6 +137,7 @@ void zkhip_destroy(zkhip_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     msm_drop_ctx(ctx);
+    evalh_drop_ctx(ctx);
     for (auto& kv : ctx->timers)
         for (auto& pr : kv.second.pending) {
             (void)hipEventDestroy(pr.first);

@@ -5,6 +5,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <map>
+#include <memory>
 #include <string>
 #include <vector>
 #include "../../include/zkhip.h"
@@ -13,6 +14,7 @@
 namespace zkhip {
 
 struct NttPlan;
+struct EvalhProgram;
 
 struct TimingSlot {
     double total_us = 0;
@@ -37,6 +39,14 @@ struct zkhip_ctx {
     std::vector<zkhip::NttPlan*> plans;   // cached per (log_n, omega)
     // program of the last evaluate_h call: instructions, multiplications, column reads, value slots
     uint64_t evalh_stats[4] = {0, 0, 0, 0};
+    // evaluate_h programs by shape (hash of the graphs and counts), built once like upstream's `ProvingKey::ev`; the
+    // linked program, scalars, constants and spilled slots of a call live in grow-only device buffers
+    std::map<std::pair<uint64_t, uint64_t>, std::shared_ptr<zkhip::EvalhProgram>> evalh_cache;
+    uint64_t evalh_builds = 0, evalh_cache_hits = 0;
+    void* evalh_buf[4] = {nullptr, nullptr, nullptr, nullptr};
+    size_t evalh_buf_bytes[4] = {0, 0, 0, 0};
+    std::vector<uint32_t> evalh_linked;
+    bool evalh_attr_set = false;
 };
 
 namespace zkhip {

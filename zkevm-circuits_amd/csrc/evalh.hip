@@ -26,6 +26,7 @@
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include "domain.h"
 #include "wide.cuh"
 
@@ -750,44 +751,313 @@ static bool graph_arrays_ok(const zkhip_graph* g) {
     return (g->constants || !g->num_constants) && (g->rotations || !g->num_rotations) && (g->calc_words || !g->num_calc_words);
 }
 
+// The fused program of one constraint-system shape, slots assigned, operands still symbolic (column numbers, rotation
+// indices).  It depends on the graphs and on the counts of the descriptor only -- not on challenges, column pointers or
+// the coset list -- so it is built once per shape and kept in the context (upstream builds `Evaluator` once per proving
+// key); a call links it against its column pointers, which is one pass over the operands.
+struct EvalhProgram {
+    std::vector<uint32_t> words;     // IW words per instruction
+    std::vector<uint64_t> consts;    // merged constant table, already in the 2^261 Montgomery domain
+    std::vector<int32_t> rots;
+    uint32_t result = W_ACC, lds_slots = 1, n_slots = 1, n_cols = 0;
+    uint64_t stats[4] = {0, 0, 0, 0};
+};
+
+// Position of every column group in the unified column table:
+// fixed | advice | instance | l0 l_last l_active | X | perm z | perm sigma | per lookup (z, a', s')
+struct ColLayout {
+    uint32_t c_l0 = 0, c_x = 0, c_z0 = 0, c_sigma0 = 0, c_lk0 = 0, total = 0;
+    ColLayout(const zkhip_evalh_desc* d, bool lagrange) {
+        uint32_t c = d->num_fixed + d->num_advice + d->num_instance;
+        c_l0 = c;
+        if (!lagrange) c += 3;
+        if (d->num_perm_sets) {
+            c_x = c++;
+            c_z0 = c;
+            c += d->num_perm_sets;
+            c_sigma0 = c;
+            c += d->num_perm_columns;
+        }
+        c_lk0 = c;
+        total = c + 3 * d->num_lookups;
+    }
+};
+
+// two independent 64-bit mixes over everything the program depends on
+struct ShapeHash {
+    uint64_t a = 0x9E3779B97F4A7C15ull, b = 0xC2B2AE3D27D4EB4Full;
+    void word(uint64_t w) {
+        a = (a ^ w) * 0x100000001B3ull;
+        a ^= a >> 29;
+        b = (b + w + 0x632BE59BD9B4E019ull) * 0xD6E8FEB86659FD93ull;
+        b ^= b >> 32;
+    }
+    void bytes(const void* p, size_t n) {
+        const unsigned char* q = (const unsigned char*)p;
+        word(n);
+        size_t i = 0;
+        for (; i + 8 <= n; i += 8) {
+            uint64_t w;
+            memcpy(&w, q + i, 8);
+            word(w);
+        }
+        uint64_t w = 0;
+        if (i < n) {
+            memcpy(&w, q + i, n - i);
+            word(w);
+        }
+    }
+    void graph(const zkhip_graph* g) {
+        word(g->num_calculations);
+        bytes(g->constants, (size_t)g->num_constants * 32);
+        bytes(g->rotations, (size_t)g->num_rotations * 4);
+        bytes(g->calc_words, (size_t)g->num_calc_words * 4);
+    }
+};
+
+static int build_program(zkhip_ctx* ctx, const zkhip_evalh_desc* desc, bool lagrange, uint32_t lds_budget, bool do_fuse,
+                         EvalhProgram& out) {
+    const ColLayout L(desc, lagrange);
+    const uint32_t c_l0 = L.c_l0, c_last = L.c_l0 + 1, c_active = L.c_l0 + 2;
+    Builder b;
+    const uint32_t ONE = Builder::scalar(SC_ONE), BETA = Builder::scalar(SC_BETA), GAMMA = Builder::scalar(SC_GAMMA);
+    // ---- 1. custom gates -----------------------------------------------------------------------------
+    if (desc->custom_gates) {
+        const zkhip_graph* g = desc->custom_gates;
+        Lowering lw(b, g, desc, true);
+        uint32_t res;
+        if (!lw.run(res)) return set_error(ctx, ZKHIP_ERR_INVALID, "evaluate_h: %s", lw.err.c_str());
+        if (res != W_ACC) b.emit(0, DST_ACC_V, res);   // a gates graph whose value is not the running Horner
+    }
+
+    // ---- 2. permutation argument ---------------------------------------------------------------------
+    // scalars after the challenges: beta * delta^c per permutation column (filled in per call)
+    const uint32_t sc_perm0 = SC_CHALLENGE0 + desc->num_challenges;
+    if (desc->num_perm_sets) {
+        const uint32_t c_x = L.c_x, c_z0 = L.c_z0, c_sigma0 = L.c_sigma0;
+        std::vector<uint32_t> pcol(desc->num_perm_columns);
+        for (uint32_t c = 0; c < desc->num_perm_columns; c++) {
+            const uint32_t kind = desc->perm_column_kind[c], ci = desc->perm_column_index[c];
+            if (kind == 2) { ZK_CHECK(ctx, ci < desc->num_fixed, "evaluate_h: permutation fixed column out of range"); pcol[c] = ci; }
+            else if (kind == 3) { ZK_CHECK(ctx, ci < desc->num_advice, "evaluate_h: permutation advice column out of range"); pcol[c] = desc->num_fixed + ci; }
+            else if (kind == 4) { ZK_CHECK(ctx, ci < desc->num_instance, "evaluate_h: permutation instance column out of range"); pcol[c] = desc->num_fixed + desc->num_advice + ci; }
+            else return set_error(ctx, ZKHIP_ERR_INVALID, "evaluate_h: permutation column kind %u", kind);
+        }
+        const int32_t last_rot = -((int32_t)desc->blinding_factors + 1);
+        const uint32_t nsets = desc->num_perm_sets;
+        // l_0(X) * (1 - z_0(X))
+        b.fold(b.mul(b.sub(ONE, b.col(c_z0, 0)), b.col(c_l0, 0)));
+        // l_last(X) * (z_l(X)^2 - z_l(X))
+        {
+            const uint32_t zl = b.col(c_z0 + nsets - 1, 0);
+            b.fold(b.mul(b.mul_sub(zl, zl, zl), b.col(c_last, 0)));
+        }
+        // l_0(X) * (z_i(X) - z_{i-1}(omega^last X))
+        for (uint32_t s = 1; s < nsets; s++)
+            b.fold(b.mul(b.sub(b.col(c_z0 + s, 0), b.col(c_z0 + s - 1, last_rot)), b.col(c_l0, 0)));
+        // l_active(X) * (z_i(omega X) prod (p + beta s_j + gamma) - z_i(X) prod (p + delta^j beta X + gamma));
+        // current_delta of column c on row idx = beta * zeta * extended_omega^idx * delta^c = (beta * delta^c) * X[idx]
+        for (uint32_t s = 0; s < nsets; s++) {
+            const uint32_t c0 = s * desc->perm_chunk_len, c1 = std::min(c0 + desc->perm_chunk_len, desc->num_perm_columns);
+            uint32_t left = b.col(c_z0 + s, 1), right = b.col(c_z0 + s, 0);
+            for (uint32_t c = c0; c < c1; c++) {
+                const uint32_t val = b.col(pcol[c], 0);
+                left = b.mul(left, b.add(b.mul_add(BETA, b.col(c_sigma0 + c, 0), val), GAMMA));
+                right = b.mul(right, b.add(b.mul_add(b.col(c_x, 0), Builder::scalar(sc_perm0 + c), val), GAMMA));
+            }
+            b.fold(b.mul(b.sub(left, right), b.col(c_active, 0)));
+        }
+    }
+
+    // ---- 3. lookup arguments -------------------------------------------------------------------------
+    for (uint32_t i = 0; i < desc->num_lookups; i++) {
+        const zkhip_graph* g = &desc->lookups[i].graph;
+        const uint32_t c_z = L.c_lk0 + 3 * i, c_a = c_z + 1, c_s = c_z + 2;
+        Lowering lw(b, g, desc, false);
+        uint32_t table_value;
+        if (!lw.run(table_value)) return set_error(ctx, ZKHIP_ERR_INVALID, "evaluate_h: %s", lw.err.c_str());
+        const uint32_t Z = b.col(c_z, 0), A = b.col(c_a, 0), S = b.col(c_s, 0);
+        const uint32_t a_minus_s = b.sub(A, S);
+        // l_0(X) * (1 - z(X))
+        b.fold(b.mul(b.sub(ONE, Z), b.col(c_l0, 0)));
+        // l_last(X) * (z(X)^2 - z(X))
+        b.fold(b.mul(b.mul_sub(Z, Z, Z), b.col(c_last, 0)));
+        // l_active(X) * (z(omega X) (a'(X) + beta) (s'(X) + gamma) - z(X) * table_value)
+        {
+            const uint32_t left = b.mul(b.mul(b.col(c_z, 1), b.add(A, BETA)), b.add(S, GAMMA));
+            const uint32_t diff = b.sub(left, b.mul(Z, table_value));
+            b.fold(b.mul(diff, b.col(c_active, 0)));
+        }
+        // l_0(X) * (a'(X) - s'(X))
+        b.fold(b.mul(a_minus_s, b.col(c_l0, 0)));
+        // l_active(X) * (a'(X) - s'(X)) * (a'(X) - a'(omega^-1 X))
+        b.fold(b.mul(b.mul(a_minus_s, b.sub(A, b.col(c_a, -1))), b.col(c_active, 0)));
+    }
+    ZK_CHECK(ctx, L.total < (1u << 16) && b.rots.size() < (1u << 12), "evaluate_h: too many columns or rotations");
+    ZK_CHECK(ctx, b.n_virtual < (1u << 28), "evaluate_h: program too large");
+
+    // ---- peephole fusion, slots -----------------------------------------------------------------------
+    uint32_t result = W_ACC, lds_slots = 1, n_slots = 1;
+    Builder::FuseStats fuse;
+    if (do_fuse) ZK_CHECK(ctx, b.fuse_products(result, fuse), "evaluate_h: internal error, a fused value left its bound");
+    assign_slots(b.words, result, b.n_virtual, lds_budget, lds_slots, n_slots);
+    // one multiplication = one product of two operands (an instruction with a second product counts two)
+    size_t nmul = 0, ncol = 0, nspill = 0;
+    const size_t ni = b.words.size() / IW;
+    for (size_t pc = 0; pc < ni; pc++) {
+        const uint32_t* w = &b.words[pc * IW];
+        ZK_CHECK(ctx, w[1] == DST_ACC_V || w[1] < DST_ACC, "evaluate_h: too many value slots");
+        nmul += ((w[0] & F_MUL) != 0) + ((w[0] & F_MUL2) != 0);
+        for (size_t q = 2; q < IW; q++) {
+            if ((w[q] >> 28) == K_COL) ncol++;
+            if ((w[q] >> 28) == K_SLOT && (w[q] & 0x0fffffffu) >= lds_slots) nspill++;
+        }
+        if (w[1] != DST_ACC_V && w[1] >= lds_slots) nspill++;
+    }
+    if (getenv("ZKHIP_DEBUG"))
+        fprintf(stderr, "[zkhip] evaluate_h program: %zu instructions (%zu products, %zu of them second products sharing a "
+                        "reduction, %zu multiply-adds formed; %zu column reads, %zu spill accesses), %u columns, "
+                        "%zu rotations, %u values -> %u slots (%u in LDS)\n",
+                ni, nmul, fuse.two_products, fuse.multiply_adds, ncol, nspill, L.total, b.rots.size(), b.n_virtual,
+                n_slots, lds_slots);
+    // constants move to the interpreter's 2^261 Montgomery domain: x R -> 32 x R
+    {
+        uint64_t k32[4];
+        memcpy(k32, FrParams::TWO5, 32);
+        for (size_t i = 0; i + 4 <= b.consts.size(); i += 4) h_mul(HFR, &b.consts[i], &b.consts[i], k32);
+    }
+    out.words.swap(b.words);
+    out.consts.swap(b.consts);
+    out.rots.swap(b.rots);
+    out.result = result;
+    out.lds_slots = lds_slots;
+    out.n_slots = n_slots;
+    out.n_cols = L.total;
+    out.stats[0] = ni;
+    out.stats[1] = nmul;
+    out.stats[2] = ncol;
+    out.stats[3] = n_slots;
+    return ZKHIP_OK;
+}
+
+// grow-only device buffers of the context for the linked program, its scalars and constants and the spilled value slots:
+// after the first call of a shape, evaluate_h over device-resident extended columns allocates nothing
+static int grow(zkhip_ctx* ctx, void*& p, size_t& have, size_t need) {
+    if (need <= have) return ZKHIP_OK;
+    if (p) {
+        ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        ZK_HIP(ctx, hipFree(p));
+        p = nullptr;
+        have = 0;
+    }
+    need = (need + need / 4 + 0xffff) & ~(size_t)0xffff;
+    ZK_HIP(ctx, hipMalloc(&p, need));
+    have = need;
+    return ZKHIP_OK;
+}
+
+// The program of the descriptor's shape: from the context's cache, or built now and kept.
+static int get_program(zkhip_ctx* ctx, const zkhip_evalh_desc* desc, bool lagrange, std::shared_ptr<EvalhProgram>& prog) {
+    const char* env_slots = getenv("ZKHIP_EVALH_LDS_SLOTS");
+    // on-chip budget per lane: one register slot + four LDS slots of 36 B (nine digits): four 256-lane workgroups per CU
+    const uint32_t lds_budget = env_slots && *env_slots ? (uint32_t)atoi(env_slots) : 5;
+    const char* env_fuse = getenv("ZKHIP_EVALH_FUSE");   // "0" keeps every product an instruction of its own
+    const bool do_fuse = !(env_fuse && *env_fuse == '0');
+    ShapeHash sh;
+    sh.word(((uint64_t)desc->basis << 32) | lds_budget | ((uint64_t)do_fuse << 31));
+    sh.word(((uint64_t)desc->num_fixed << 32) | desc->num_advice);
+    sh.word(((uint64_t)desc->num_instance << 32) | desc->num_challenges);
+    sh.word(desc->custom_gates ? 1 : 0);
+    if (desc->custom_gates) sh.graph(desc->custom_gates);
+    sh.word(desc->num_lookups);
+    for (uint32_t i = 0; i < desc->num_lookups; i++) sh.graph(&desc->lookups[i].graph);
+    sh.word(((uint64_t)desc->num_perm_sets << 32) | desc->num_perm_columns);
+    if (desc->num_perm_sets) {
+        sh.word(((uint64_t)desc->perm_chunk_len << 32) | desc->blinding_factors);
+        sh.bytes(desc->perm_column_kind, (size_t)desc->num_perm_columns * 4);
+        sh.bytes(desc->perm_column_index, (size_t)desc->num_perm_columns * 4);
+    }
+    const std::pair<uint64_t, uint64_t> key(sh.a, sh.b);
+    auto it = ctx->evalh_cache.find(key);
+    if (it != ctx->evalh_cache.end()) {
+        prog = it->second;
+        ctx->evalh_cache_hits++;
+        return ZKHIP_OK;
+    }
+    ctx->evalh_builds++;
+    prog = std::make_shared<EvalhProgram>();
+    int rc = build_program(ctx, desc, lagrange, lds_budget, do_fuse, *prog);
+    if (rc) return rc;
+    if (ctx->evalh_cache.size() >= 4096) ctx->evalh_cache.clear();
+    ctx->evalh_cache[key] = prog;
+    return ZKHIP_OK;
+}
+
+// what every use of a descriptor's shape fields checks before the program is built or looked up
+static int check_shape(zkhip_ctx* ctx, const zkhip_evalh_desc* desc) {
+    ZK_CHECK(ctx, desc->basis <= 1, "evaluate_h: basis %u", desc->basis);
+    ZK_CHECK(ctx, !desc->num_lookups || desc->lookups, "evaluate_h: lookups missing");
+    if (desc->num_perm_sets) {
+        ZK_CHECK(ctx, desc->perm_chunk_len >= 1, "evaluate_h: perm_chunk_len = 0");
+        ZK_CHECK(ctx, desc->perm_column_kind && desc->perm_column_index, "evaluate_h: permutation arrays missing");
+        ZK_CHECK(ctx, (desc->num_perm_columns + desc->perm_chunk_len - 1) / desc->perm_chunk_len == desc->num_perm_sets,
+                 "evaluate_h: %u permutation columns in chunks of %u do not make %u sets", desc->num_perm_columns,
+                 desc->perm_chunk_len, desc->num_perm_sets);
+    }
+    if (desc->custom_gates) ZK_CHECK(ctx, graph_arrays_ok(desc->custom_gates), "evaluate_h: graph arrays missing");
+    for (uint32_t i = 0; i < desc->num_lookups; i++)
+        ZK_CHECK(ctx, graph_arrays_ok(&desc->lookups[i].graph), "evaluate_h: graph arrays missing");
+    if (desc->basis == ZKHIP_BASIS_LAGRANGE)
+        ZK_CHECK(ctx, desc->custom_gates && !desc->num_lookups && !desc->num_perm_sets && !desc->num_cosets &&
+                          desc->poly_form == ZKHIP_FORM_EXTENDED,
+                 "evaluate_h: the Lagrange basis takes one graph, columns as given, no lookup / permutation / coset arguments");
+    return ZKHIP_OK;
+}
+
+void evalh_drop_ctx(zkhip_ctx* ctx) {
+    ctx->evalh_cache.clear();
+    for (int i = 0; i < 4; i++) {
+        if (ctx->evalh_buf[i]) (void)hipFree(ctx->evalh_buf[i]);
+        ctx->evalh_buf[i] = nullptr;
+        ctx->evalh_buf_bytes[i] = 0;
+    }
+}
+
 }  // namespace zkhip
+
+extern "C" int zkhip_evaluate_h_prepare(zkhip_domain* dom, const zkhip_evalh_desc* desc) {
+    if (!dom) return ZKHIP_ERR_INVALID;
+    zkhip_ctx* ctx = dom->ctx;
+    ZK_CHECK(ctx, desc, "evaluate_h_prepare: null descriptor");
+    int rc = check_shape(ctx, desc);
+    if (rc) return rc;
+    std::shared_ptr<EvalhProgram> prog;
+    return get_program(ctx, desc, desc->basis == ZKHIP_BASIS_LAGRANGE, prog);
+}
 
 extern "C" int zkhip_evaluate_h(zkhip_domain* dom, const zkhip_evalh_desc* desc, uint64_t* out) {
     if (!dom) return ZKHIP_ERR_INVALID;
     zkhip_ctx* ctx = dom->ctx;
     ZK_CHECK(ctx, desc && out, "evaluate_h: null descriptor or output");
     ZK_CHECK(ctx, desc->mem <= 1 && desc->poly_form <= 1, "evaluate_h: bad mem / poly_form");
+    int rc = check_shape(ctx, desc);
+    if (rc) return rc;
+    // Lagrange basis: a graph evaluated over the 2^k rows of the circuit itself (rotations move single rows), what the
+    // prover does with the lookup expressions before it sorts them
     const bool lagrange = desc->basis == ZKHIP_BASIS_LAGRANGE;
-    ZK_CHECK(ctx, desc->basis <= 1, "evaluate_h: basis %u", desc->basis);
-    if (lagrange) {
-        // a graph evaluated over the 2^k rows of the circuit itself (rotations move single rows): what the prover does
-        // with the lookup expressions before it sorts them
-        ZK_CHECK(ctx, desc->custom_gates && !desc->num_lookups && !desc->num_perm_sets && !desc->num_cosets &&
-                          desc->poly_form == ZKHIP_FORM_EXTENDED,
-                 "evaluate_h: the Lagrange basis takes one graph, columns as given, no lookup / permutation / coset arguments");
-    } else {
-        ZK_CHECK(ctx, desc->l0 && desc->l_last && desc->l_active_row, "evaluate_h: l0 / l_last / l_active_row missing");
-    }
+    if (!lagrange) ZK_CHECK(ctx, desc->l0 && desc->l_last && desc->l_active_row, "evaluate_h: l0 / l_last / l_active_row missing");
     ZK_CHECK(ctx, !desc->num_fixed || desc->fixed_cosets, "evaluate_h: fixed_cosets missing");
     ZK_CHECK(ctx, !desc->num_advice || desc->advice, "evaluate_h: advice missing");
     ZK_CHECK(ctx, !desc->num_instance || desc->instance, "evaluate_h: instance missing");
     ZK_CHECK(ctx, !desc->num_challenges || desc->challenges, "evaluate_h: challenges missing");
-    ZK_CHECK(ctx, !desc->num_lookups || desc->lookups, "evaluate_h: lookups missing");
-    if (desc->num_perm_sets) {
-        ZK_CHECK(ctx, desc->perm_chunk_len >= 1, "evaluate_h: perm_chunk_len = 0");
-        ZK_CHECK(ctx, desc->perm_column_kind && desc->perm_column_index && desc->perm_sigma_cosets && desc->perm_product_cosets,
-                 "evaluate_h: permutation arrays missing");
-        ZK_CHECK(ctx, (desc->num_perm_columns + desc->perm_chunk_len - 1) / desc->perm_chunk_len == desc->num_perm_sets,
-                 "evaluate_h: %u permutation columns in chunks of %u do not make %u sets", desc->num_perm_columns,
-                 desc->perm_chunk_len, desc->num_perm_sets);
-    }
+    if (desc->num_perm_sets)
+        ZK_CHECK(ctx, desc->perm_sigma_cosets && desc->perm_product_cosets, "evaluate_h: permutation arrays missing");
     ZK_HIP(ctx, hipSetDevice(ctx->device));
     const uint32_t ek = dom->extended_k, k = dom->k;
     const size_t n = (size_t)1 << k;
     const bool host = desc->mem == ZKHIP_MEM_HOST;
     const bool coeff = desc->poly_form == ZKHIP_FORM_COEFF;
     Arena ar{ctx, {}};
-    int rc;
     // Rows evaluated: the whole extended domain, or a subset of its cosets in compact layout.  A rotation by r moves
     // r * 2^e extended rows and so stays inside a coset; in the compact layout it moves r * num_cosets rows.
     const bool compact = desc->num_cosets != 0;
@@ -798,6 +1068,11 @@ extern "C" int zkhip_evaluate_h(zkhip_domain* dom, const zkhip_evalh_desc* desc,
     uint32_t log_rows = k;
     while ((1u << (log_rows - k)) < cl.num) log_rows++;
     const size_t size = (size_t)1 << log_rows;
+
+    // ---- the program of this shape: from the context's cache, or built now --------------------------------------
+    std::shared_ptr<EvalhProgram> prog;
+    if ((rc = get_program(ctx, desc, lagrange, prog))) return rc;
+    memcpy(ctx->evalh_stats, prog->stats, sizeof ctx->evalh_stats);
 
     // Bring one polynomial to an extended coset on the device.  `ext_in`: already extended.
     fe *tmp0 = nullptr, *tmp1 = nullptr;
@@ -835,7 +1110,9 @@ extern "C" int zkhip_evaluate_h(zkhip_domain* dom, const zkhip_evalh_desc* desc,
     };
 
     // ---- unified column table: fixed | advice | instance | l0 l_last l_active | X | perm z | perm sigma | lookups ----
+    const ColLayout L(desc, lagrange);
     std::vector<const fe*> cols;
+    cols.reserve(L.total);
     auto push = [&](const uint64_t* p, bool ext_in) -> int {
         const fe* d;
         int r = resolve(p, ext_in, &d);
@@ -849,26 +1126,9 @@ extern "C" int zkhip_evaluate_h(zkhip_domain* dom, const zkhip_evalh_desc* desc,
         if ((rc = push(desc->advice[i], !coeff))) return rc;
     for (uint32_t i = 0; i < desc->num_instance; i++)
         if ((rc = push(desc->instance[i], !coeff))) return rc;
-    const uint32_t c_l0 = (uint32_t)cols.size();
     if (!lagrange && ((rc = push(desc->l0, true)) || (rc = push(desc->l_last, true)) || (rc = push(desc->l_active_row, true))))
         return rc;
-    const uint32_t c_last = c_l0 + 1, c_active = c_l0 + 2;
-
-    Builder b;
-    const uint32_t ONE = Builder::scalar(SC_ONE), BETA = Builder::scalar(SC_BETA), GAMMA = Builder::scalar(SC_GAMMA);
-    // ---- 1. custom gates -----------------------------------------------------------------------------
-    if (desc->custom_gates) {
-        const zkhip_graph* g = desc->custom_gates;
-        ZK_CHECK(ctx, graph_arrays_ok(g), "evaluate_h: graph arrays missing");
-        Lowering lw(b, g, desc, true);
-        uint32_t res;
-        if (!lw.run(res)) return set_error(ctx, ZKHIP_ERR_INVALID, "evaluate_h: %s", lw.err.c_str());
-        if (res != W_ACC) b.emit(0, DST_ACC_V, res);   // a gates graph whose value is not the running Horner
-    }
-
-    // ---- 2. permutation argument ---------------------------------------------------------------------
     std::vector<uint64_t> extra_scalars;   // after the challenges: beta * delta^c per permutation column
-    const uint32_t sc_perm0 = SC_CHALLENGE0 + desc->num_challenges;
     if (desc->num_perm_sets) {
         const fe* d_x;
         if (compact) {
@@ -885,22 +1145,11 @@ extern "C" int zkhip_evaluate_h(zkhip_domain* dom, const zkhip_evalh_desc* desc,
             }
             d_x = (const fe*)dom->d_xpoints;
         }
-        const uint32_t c_x = (uint32_t)cols.size();
         cols.push_back(d_x);
-        const uint32_t c_z0 = (uint32_t)cols.size();
         for (uint32_t s = 0; s < desc->num_perm_sets; s++)
             if ((rc = push(desc->perm_product_cosets[s], true))) return rc;
-        const uint32_t c_sigma0 = (uint32_t)cols.size();
-        std::vector<uint32_t> pcol(desc->num_perm_columns);
-        for (uint32_t c = 0; c < desc->num_perm_columns; c++) {
+        for (uint32_t c = 0; c < desc->num_perm_columns; c++)
             if ((rc = push(desc->perm_sigma_cosets[c], true))) return rc;
-            const uint32_t kind = desc->perm_column_kind[c], ci = desc->perm_column_index[c];
-            if (kind == 2) { ZK_CHECK(ctx, ci < desc->num_fixed, "evaluate_h: permutation fixed column out of range"); pcol[c] = ci; }
-            else if (kind == 3) { ZK_CHECK(ctx, ci < desc->num_advice, "evaluate_h: permutation advice column out of range"); pcol[c] = desc->num_fixed + ci; }
-            else if (kind == 4) { ZK_CHECK(ctx, ci < desc->num_instance, "evaluate_h: permutation instance column out of range"); pcol[c] = desc->num_fixed + desc->num_advice + ci; }
-            else return set_error(ctx, ZKHIP_ERR_INVALID, "evaluate_h: permutation column kind %u", kind);
-        }
-        // current_delta of column c on row idx = beta * zeta * extended_omega^idx * delta^c = (beta * delta^c) * X[idx]
         uint64_t cur[4], delta[4];
         memcpy(delta, FrParams::DELTA, 32);
         memcpy(cur, desc->beta, 32);
@@ -908,100 +1157,15 @@ extern "C" int zkhip_evaluate_h(zkhip_domain* dom, const zkhip_evalh_desc* desc,
             extra_scalars.insert(extra_scalars.end(), cur, cur + 4);
             h_mul(HFR, cur, cur, delta);
         }
-        const int32_t last_rot = -((int32_t)desc->blinding_factors + 1);
-        const uint32_t nsets = desc->num_perm_sets;
-        // l_0(X) * (1 - z_0(X))
-        b.fold(b.mul(b.sub(ONE, b.col(c_z0, 0)), b.col(c_l0, 0)));
-        // l_last(X) * (z_l(X)^2 - z_l(X))
-        {
-            const uint32_t zl = b.col(c_z0 + nsets - 1, 0);
-            b.fold(b.mul(b.mul_sub(zl, zl, zl), b.col(c_last, 0)));
-        }
-        // l_0(X) * (z_i(X) - z_{i-1}(omega^last X))
-        for (uint32_t s = 1; s < nsets; s++)
-            b.fold(b.mul(b.sub(b.col(c_z0 + s, 0), b.col(c_z0 + s - 1, last_rot)), b.col(c_l0, 0)));
-        // l_active(X) * (z_i(omega X) prod (p + beta s_j + gamma) - z_i(X) prod (p + delta^j beta X + gamma))
-        for (uint32_t s = 0; s < nsets; s++) {
-            const uint32_t c0 = s * desc->perm_chunk_len, c1 = std::min(c0 + desc->perm_chunk_len, desc->num_perm_columns);
-            uint32_t left = b.col(c_z0 + s, 1), right = b.col(c_z0 + s, 0);
-            for (uint32_t c = c0; c < c1; c++) {
-                const uint32_t val = b.col(pcol[c], 0);
-                left = b.mul(left, b.add(b.mul_add(BETA, b.col(c_sigma0 + c, 0), val), GAMMA));
-                right = b.mul(right, b.add(b.mul_add(b.col(c_x, 0), Builder::scalar(sc_perm0 + c), val), GAMMA));
-            }
-            b.fold(b.mul(b.sub(left, right), b.col(c_active, 0)));
-        }
     }
-
-    // ---- 3. lookup arguments -------------------------------------------------------------------------
     for (uint32_t i = 0; i < desc->num_lookups; i++) {
         const zkhip_lookup& lk = desc->lookups[i];
-        const zkhip_graph* g = &lk.graph;
-        ZK_CHECK(ctx, graph_arrays_ok(g), "evaluate_h: graph arrays missing");
-        const uint32_t c_z = (uint32_t)cols.size();
         if ((rc = push(lk.product, !coeff)) || (rc = push(lk.permuted_input, !coeff)) || (rc = push(lk.permuted_table, !coeff)))
             return rc;
-        const uint32_t c_a = c_z + 1, c_s = c_z + 2;
-        Lowering lw(b, g, desc, false);
-        uint32_t table_value;
-        if (!lw.run(table_value)) return set_error(ctx, ZKHIP_ERR_INVALID, "evaluate_h: %s", lw.err.c_str());
-        const uint32_t Z = b.col(c_z, 0), A = b.col(c_a, 0), S = b.col(c_s, 0);
-        const uint32_t a_minus_s = b.sub(A, S);
-        // l_0(X) * (1 - z(X))
-        b.fold(b.mul(b.sub(ONE, Z), b.col(c_l0, 0)));
-        // l_last(X) * (z(X)^2 - z(X))
-        b.fold(b.mul(b.mul_sub(Z, Z, Z), b.col(c_last, 0)));
-        // l_active(X) * (z(omega X) (a'(X) + beta) (s'(X) + gamma) - z(X) * table_value)
-        {
-            const uint32_t left = b.mul(b.mul(b.col(c_z, 1), b.add(A, BETA)), b.add(S, GAMMA));
-            const uint32_t diff = b.sub(left, b.mul(Z, table_value));
-            b.fold(b.mul(diff, b.col(c_active, 0)));
-        }
-        // l_0(X) * (a'(X) - s'(X))
-        b.fold(b.mul(a_minus_s, b.col(c_l0, 0)));
-        // l_active(X) * (a'(X) - s'(X)) * (a'(X) - a'(omega^-1 X))
-        b.fold(b.mul(b.mul(a_minus_s, b.sub(A, b.col(c_a, -1))), b.col(c_active, 0)));
     }
-    ZK_CHECK(ctx, cols.size() < (1u << 16) && b.rots.size() < (1u << 12), "evaluate_h: too many columns or rotations");
-    ZK_CHECK(ctx, b.n_virtual < (1u << 28), "evaluate_h: program too large");
+    ZK_CHECK(ctx, cols.size() == L.total && prog->n_cols == L.total, "evaluate_h: internal error, column table mismatch");
 
-    // ---- slots, tables, launch -----------------------------------------------------------------------
-    // on-chip budget per lane: one register slot + four LDS slots of 36 B (nine digits): four 256-lane workgroups per CU
-    const char* env_slots = getenv("ZKHIP_EVALH_LDS_SLOTS");
-    const uint32_t lds_budget = env_slots && *env_slots ? (uint32_t)atoi(env_slots) : 5;
-    uint32_t result = W_ACC, lds_slots = 1, n_slots = 1;
-    Builder::FuseStats fuse;
-    {
-        const char* env_fuse = getenv("ZKHIP_EVALH_FUSE");   // "0" keeps every product an instruction of its own
-        if (!(env_fuse && *env_fuse == '0'))
-            ZK_CHECK(ctx, b.fuse_products(result, fuse), "evaluate_h: internal error, a fused value left its bound");
-    }
-    assign_slots(b.words, result, b.n_virtual, lds_budget, lds_slots, n_slots);
-    {
-        // one multiplication = one product of two operands (an instruction with a second product counts two)
-        size_t nmul = 0, ncol = 0, nspill = 0;
-        const size_t ni = b.words.size() / IW;
-        for (size_t pc = 0; pc < ni; pc++) {
-            const uint32_t* w = &b.words[pc * IW];
-            nmul += ((w[0] & F_MUL) != 0) + ((w[0] & F_MUL2) != 0);
-            for (size_t q = 2; q < IW; q++) {
-                if ((w[q] >> 28) == K_COL) ncol++;
-                if ((w[q] >> 28) == K_SLOT && (w[q] & 0x0fffffffu) >= lds_slots) nspill++;
-            }
-            if (w[1] != DST_ACC_V && w[1] >= lds_slots) nspill++;
-        }
-        ctx->evalh_stats[0] = ni;
-        ctx->evalh_stats[1] = nmul;
-        ctx->evalh_stats[2] = ncol;
-        ctx->evalh_stats[3] = n_slots;
-        if (getenv("ZKHIP_DEBUG"))
-            fprintf(stderr, "[zkhip] evaluate_h program: %zu instructions (%zu products, %zu of them second products sharing a "
-                            "reduction, %zu multiply-adds formed; %zu column reads, %zu spill accesses), %zu columns, "
-                            "%zu rotations, %u values -> %u slots (%u in LDS)\n",
-                    ni, nmul, fuse.two_products, fuse.multiply_adds, ncol, nspill, cols.size(), b.rots.size(), b.n_virtual,
-                    n_slots, lds_slots);
-    }
-
+    // ---- scalars of this call, in the interpreter's 2^261 Montgomery domain: x R -> 32 x R ----------------------
     std::vector<uint64_t> scal((size_t)(SC_CHALLENGE0 + desc->num_challenges) * 4);
     memcpy(&scal[4 * SC_BETA], desc->beta, 32);
     memcpy(&scal[4 * SC_GAMMA], desc->gamma, 32);
@@ -1010,21 +1174,34 @@ extern "C" int zkhip_evaluate_h(zkhip_domain* dom, const zkhip_evalh_desc* desc,
     memcpy(&scal[4 * SC_ONE], HFR.r, 32);
     if (desc->num_challenges) memcpy(&scal[4 * SC_CHALLENGE0], desc->challenges, (size_t)desc->num_challenges * 32);
     scal.insert(scal.end(), extra_scalars.begin(), extra_scalars.end());
-    // scalars and constants move to the interpreter's 2^261 Montgomery domain: x R -> 32 x R
     {
         uint64_t k32[4];
         memcpy(k32, FrParams::TWO5, 32);
         for (size_t i = 0; i + 4 <= scal.size(); i += 4) h_mul(HFR, &scal[i], &scal[i], k32);
-        for (size_t i = 0; i + 4 <= b.consts.size(); i += 4) h_mul(HFR, &b.consts[i], &b.consts[i], k32);
     }
 
-    InterpArgs a;
-    memset(&a, 0, sizeof a);
-    fe *d_scal, *d_consts;
-    if ((rc = ar.upload((const fe*)scal.data(), scal.size() / 4, &d_scal))) return rc;
-    if ((rc = ar.upload((const fe*)b.consts.data(), b.consts.size() / 4, &d_consts))) return rc;
-    // link: operand words -> (header, device pointer)
+    const size_t n_instr = prog->words.size() / IW;
+    void*& d_prog_v = ctx->evalh_buf[0];
+    void*& d_scal_v = ctx->evalh_buf[1];
+    void*& d_consts_v = ctx->evalh_buf[2];
+    void*& d_spill_v = ctx->evalh_buf[3];
+    if ((rc = grow(ctx, d_prog_v, ctx->evalh_buf_bytes[0], std::max<size_t>(1, n_instr) * INS_WORDS * 4)) ||
+        (rc = grow(ctx, d_scal_v, ctx->evalh_buf_bytes[1], scal.size() * 8)) ||
+        (rc = grow(ctx, d_consts_v, ctx->evalh_buf_bytes[2], std::max<size_t>(32, prog->consts.size() * 8))))
+        return rc;
+    if (prog->n_slots > prog->lds_slots &&
+        (rc = grow(ctx, d_spill_v, ctx->evalh_buf_bytes[3], (size_t)(prog->n_slots - prog->lds_slots) * size * 36)))
+        return rc;
+    fe* d_scal = (fe*)d_scal_v;
+    fe* d_consts = (fe*)d_consts_v;
+    ZK_HIP(ctx, hipMemcpyAsync(d_scal, scal.data(), scal.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+    if (!prog->consts.empty())
+        ZK_HIP(ctx, hipMemcpyAsync(d_consts, prog->consts.data(), prog->consts.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+
+    // ---- link: operand words -> (header, device pointer) -------------------------------------------------------
     const int32_t rot_scale = (int32_t)cl.num;
+    for (int32_t r : prog->rots)
+        ZK_CHECK(ctx, std::abs((int64_t)r) * rot_scale < (1 << 26), "evaluate_h: rotation %d out of range", r);
     auto link = [&](uint32_t w, uint32_t* o) {
         const uint32_t kind = w >> 28, pl = w & 0x0fffffffu;
         uint64_t ptr = 0;
@@ -1033,7 +1210,7 @@ extern "C" int zkhip_evaluate_h(zkhip_domain* dom, const zkhip_evalh_desc* desc,
             case K_CONST: hdr = L_UNI << 28; ptr = (uint64_t)(uintptr_t)(d_consts + pl); break;
             case K_SCALAR: hdr = L_UNI << 28; ptr = (uint64_t)(uintptr_t)(d_scal + pl); break;
             case K_COL: {
-                const int32_t delta = b.rots[pl & 0xfff] * rot_scale;
+                const int32_t delta = prog->rots[pl & 0xfff] * rot_scale;
                 hdr = (L_ROW << 28) | ((uint32_t)delta & 0x0fffffffu);
                 ptr = (uint64_t)(uintptr_t)cols[pl >> 12];
                 break;
@@ -1046,14 +1223,11 @@ extern "C" int zkhip_evaluate_h(zkhip_domain* dom, const zkhip_evalh_desc* desc,
         o[1] = (uint32_t)ptr;
         o[2] = (uint32_t)(ptr >> 32);
     };
-    for (int32_t r : b.rots)
-        ZK_CHECK(ctx, std::abs((int64_t)r) * rot_scale < (1 << 26), "evaluate_h: rotation %d out of range", r);
-    const size_t n_instr = b.words.size() / IW;
-    std::vector<uint32_t> linked(n_instr * INS_WORDS, 0);
+    std::vector<uint32_t>& linked = ctx->evalh_linked;
+    linked.assign(n_instr * INS_WORDS, 0);
     for (size_t pc = 0; pc < n_instr; pc++) {
         uint32_t* o = &linked[pc * INS_WORDS];
-        const uint32_t* w = &b.words[pc * IW];
-        ZK_CHECK(ctx, w[1] == DST_ACC_V || w[1] < DST_ACC, "evaluate_h: too many value slots");
+        const uint32_t* w = &prog->words[pc * IW];
         o[0] = w[0] | ((w[1] == DST_ACC_V ? DST_ACC : w[1]) << DST_SHIFT);
         link(w[2], o + 1);
         link(w[3], o + 4);
@@ -1061,9 +1235,8 @@ extern "C" int zkhip_evaluate_h(zkhip_domain* dom, const zkhip_evalh_desc* desc,
         link(w[5], o + 10);
     }
     uint32_t res_link[3];
-    link(result, res_link);
-    uint32_t* d_prog;
-    if ((rc = ar.upload(linked.data(), linked.size(), &d_prog))) return rc;
+    link(prog->result, res_link);
+    if (n_instr) ZK_HIP(ctx, hipMemcpyAsync(d_prog_v, linked.data(), linked.size() * 4, hipMemcpyHostToDevice, ctx->stream));
     fe* d_out;
     if (host) {
         void* p;
@@ -1072,27 +1245,36 @@ extern "C" int zkhip_evaluate_h(zkhip_domain* dom, const zkhip_evalh_desc* desc,
     } else {
         d_out = (fe*)out;
     }
+    InterpArgs a;
+    memset(&a, 0, sizeof a);
     a.n_instr = (uint32_t)n_instr;
     a.result_hdr = res_link[0];
-    a.lds_slots = lds_slots;
-    if (n_slots > lds_slots) {
-        void* sp;
-        if ((rc = ar.alloc((size_t)(n_slots - lds_slots) * size * 36, &sp))) return rc;
-        a.spill = (int32_t*)sp;
-    }
+    a.lds_slots = prog->lds_slots;
+    a.spill = prog->n_slots > prog->lds_slots ? (int32_t*)d_spill_v : nullptr;
     a.log_size = log_rows;
     a.out = d_out;
-    const size_t lds_bytes = (size_t)(lds_slots > 1 ? lds_slots - 1 : 1) * EV_THREADS * 36;
-    ZK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(evalh_interp_kernel),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    const size_t lds_bytes = (size_t)(prog->lds_slots > 1 ? prog->lds_slots - 1 : 1) * EV_THREADS * 36;
+    if (!ctx->evalh_attr_set) {
+        ZK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(evalh_interp_kernel),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        ctx->evalh_attr_set = true;
+    }
     {
         TimedRegion tr(ctx, "evalh");
         hipLaunchKernelGGL(evalh_interp_kernel, dim3((unsigned)((size + EV_THREADS - 1) / EV_THREADS)), dim3(EV_THREADS),
-                           lds_bytes, ctx->stream, (const uint32_t*)d_prog, a);
+                           lds_bytes, ctx->stream, (const uint32_t*)d_prog_v, a);
         ZK_HIP(ctx, hipGetLastError());
     }
     if (host) ZK_HIP(ctx, hipMemcpyAsync(out, d_out, size * 32, hipMemcpyDeviceToHost, ctx->stream));
+    // the scalars, the linked program and the spill buffer belong to the context and are rewritten by the next call
     ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return ZKHIP_OK;
+}
+
+extern "C" int zkhip_evaluate_h_cache_stats(zkhip_ctx* ctx, uint64_t out[2]) {
+    if (!ctx || !out) return ZKHIP_ERR_INVALID;
+    out[0] = ctx->evalh_builds;
+    out[1] = ctx->evalh_cache_hits;
     return ZKHIP_OK;
 }
 

@@ -97,6 +97,20 @@ class EvalhCall:
         return d
 
 
+def prepare(dom, cs: ConstraintSystem, ev: Evaluator):
+    """Key-generation step: has the device library build (and keep) the evaluate_h program of this constraint system, as
+    upstream builds `ProvingKey::ev`.  No column data is needed: the descriptor carries counts and graphs only."""
+    call = EvalhCall(cs, ev)
+    call.fixed, call.advice, call.instance = [0] * cs.num_fixed_columns, [0] * cs.num_advice_columns, [0] * cs.num_instance_columns
+    call.challenges = np.zeros((cs.num_challenges, 4), dtype=np.uint64)
+    call.y = call.beta = call.gamma = call.theta = np.zeros(4, dtype=np.uint64)
+    call.l0 = call.l_last = call.l_active = 0
+    call.lookups = [(0, 0, 0)] * len(cs.lookups)
+    call.perm_sigma = [0] * len(cs.permutation_columns)
+    call.perm_z = [0] * cs.num_permutation_sets()
+    dom.evaluate_h_prepare(call.build(ffi.MEM_DEVICE, ffi.FORM_EXTENDED))
+
+
 def compress_graph(expressions):
     """The graph of `compress_expressions` in `plonk::lookup::prover::Argument::commit_permuted`: the expressions of one
     side of a lookup folded by Horner in theta (first expression = highest power), as upstream's Evaluator builds it for

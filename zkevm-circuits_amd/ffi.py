@@ -27,7 +27,7 @@ EXPORTS = [
     "zkhip_divide_by_vanishing_poly",
     "zkhip_lagrange_to_coeff_dev", "zkhip_coeff_to_lagrange_dev", "zkhip_coeff_to_extended_dev",
     "zkhip_extended_to_coeff_dev", "zkhip_divide_by_vanishing_poly_dev",
-    "zkhip_evaluate_h", "zkhip_evaluate_h_last_stats",
+    "zkhip_evaluate_h", "zkhip_evaluate_h_last_stats", "zkhip_evaluate_h_cache_stats", "zkhip_evaluate_h_prepare",
     "zkhip_coeff_to_cosets_dev", "zkhip_extended_to_cosets_dev", "zkhip_cosets_to_extended_dev",
     "zkhip_batch_invert_dev", "zkhip_prefix_product_dev", "zkhip_prefix_product_noalloc_dev", "zkhip_permutation_product_dev", "zkhip_lookup_product_dev",
     "zkhip_eval_polynomial_dev", "zkhip_eval_polynomials_dev", "zkhip_poly_lincomb_dev", "zkhip_kate_division_dev", "zkhip_lookup_permute_dev", "zkhip_permutation_sigma_dev",
@@ -106,10 +106,15 @@ class DescBuilder:
         self.keep = []
 
     def graph(self, g, to_mont) -> Graph:
-        """g: plonk.GraphEvaluator; to_mont: canonical int -> 4 Montgomery limbs."""
-        consts = np.array([to_mont(c) for c in g.constants], dtype=np.uint64).reshape(-1, 4)
-        rots = np.array(g.rotations, dtype=np.int32)
-        words = np.array(g.wire_words(), dtype=np.uint32)
+        """g: plonk.GraphEvaluator; to_mont: canonical int -> 4 Montgomery limbs.  The serialised arrays are kept on the
+        graph (until it grows): a proving key's graphs are serialised once, not per call."""
+        key = (len(g.constants), len(g.rotations), len(g.calculations))
+        cached = g.__dict__.get("_wire_cache")
+        if cached is None or cached[0] != key:
+            cached = (key, np.array([to_mont(c) for c in g.constants], dtype=np.uint64).reshape(-1, 4),
+                      np.array(g.rotations, dtype=np.int32), np.array(g.wire_words(), dtype=np.uint32))
+            g.__dict__["_wire_cache"] = cached
+        _, consts, rots, words = cached
         self.keep += [consts, rots, words]
         return Graph(_p(consts), len(g.constants), _p(rots) if len(rots) else None, len(rots),
                      _p(words), len(words), len(g.calculations))
@@ -329,6 +334,11 @@ class Context:
         self._ck(self._l.zkhip_evaluate_h_last_stats(self.h, _p(out)))
         return {"instructions": int(out[0]), "multiplications": int(out[1]), "column_reads": int(out[2]), "slots": int(out[3])}
 
+    def evaluate_h_cache_stats(self):
+        out = np.zeros(2, dtype=np.uint64)
+        self._ck(self._l.zkhip_evaluate_h_cache_stats(self.h, _p(out)))
+        return {"builds": int(out[0]), "hits": int(out[1])}
+
     def timing_enable(self, on=True):
         self._ck(self._l.zkhip_timing_enable(self.h, C.c_int(1 if on else 0)))
 
@@ -462,6 +472,10 @@ class Domain:
         self.ctx._ck(self._l.zkhip_lookup_product_dev(self.h, C.c_void_p(d_input), C.c_void_p(d_table),
                                                       C.c_void_p(d_permuted_input), C.c_void_p(d_permuted_table), _p(beta),
                                                       _p(gamma), C.c_void_p(d_z)))
+
+    def evaluate_h_prepare(self, desc: EvalhDesc):
+        """`Evaluator::new(cs)`: builds the program of the descriptor's shape and keeps it in the context"""
+        self.ctx._ck(self._l.zkhip_evaluate_h_prepare(self.h, C.byref(desc)))
 
     def evaluate_h(self, desc: EvalhDesc, out_dev: int | None = None):
         """`Evaluator::evaluate_h`.  Host descriptor -> numpy result; device descriptor -> writes out_dev."""

@@ -129,7 +129,8 @@ class ConstraintSystem:
     def _memo(self, name, compute):
         """degree() and blinding_factors() walk every expression; callers ask for them per device call, so the values
         are kept until the lists of gates / lookups change length"""
-        key = (len(self.gates), sum(len(g) for g in self.gates), len(self.lookups), self.minimum_degree)
+        key = (len(self.gates), sum(len(g) for g in self.gates), len(self.lookups), self.minimum_degree,
+               len(self.permutation_columns))
         cache = self.__dict__.setdefault("_memo_cache", {})
         if cache.get("key") != key:
             cache.clear()
@@ -162,6 +163,11 @@ class ConstraintSystem:
         for lk in self.lookups:
             for e in lk.input_expressions + lk.table_expressions:
                 _walk_queries(e, q)
+        # `enable_equality` queries an advice column of the permutation argument at the current rotation, and upstream's
+        # num_advice_queries counts that query like any other
+        for kind, idx in self.permutation_columns:
+            if kind == ANY_ADVICE:
+                q.add(("advice", idx, 0))
         for (t, col, _rot) in q:
             if t == "advice":
                 per_col[col] = per_col.get(col, 0) + 1

@@ -219,6 +219,7 @@ def keygen(ctx, dom, params: ParamsKZG, cs: ConstraintSystem, fixed, assembly) -
     pk = ProvingKey()
     pk.cs = cs
     pk.ev = Evaluator(cs)
+    evalh_host.prepare(dom, cs, pk.ev)       # the device program of evaluate_h, built once per key like `pk.ev`
     fixed_limbs = [fr_limbs(c) for c in fixed]
     pk.polys = kg.keygen_polys(ctx, dom, fixed_limbs, assembly if cs.permutation_columns else None, cs.blinding_factors())
     pk.fixed_values = [ctx.upload(a) for a in fixed_limbs]

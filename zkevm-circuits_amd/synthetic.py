@@ -147,3 +147,141 @@ def satisfied_witness(cs, n, seed, units, active_rows=500, as_arrays=False):
             arrays.append(arr)
         advice = arrays
     return advice, [public], fixed, asm
+
+
+# ----------------------------------------------------------------------------- SuperCircuit stand-in
+# Rotation set of the reference's keccak cell-manager columns: 0..11 inside a round, (i + 1) * 12 for i < 17 up to +204,
+# and one round back (/root/reference/zkevm-circuits/src/keccak_circuit.rs:148,158-162,
+# /root/reference/zkevm-circuits/src/keccak_circuit/param.rs:1-2).
+KECCAK_ROTATIONS = tuple(range(12)) + tuple(12 * (i + 1) for i in range(17)) + (-12,)
+
+
+def standin_cs(units=52, lanes=8, wide_lookups=8, lookup_width=10, extra_gates=0):
+    """A satisfiable stand-in for the reference's SuperCircuit that carries its hard features together, on top of
+    `satisfied_cs(units, degree9=True, extra_gates)`:
+      * `lanes` keccak-like advice columns w, each queried at the 30 rotations of KECCAK_ROTATIONS (so that
+        blinding_factors = 32 and the permutation argument's last rotation is -33), with a linear gate over all of them,
+        a product across the +204 rotation and a degree-nine gate;
+      * `wide_lookups` lookups of `lookup_width` input columns into `lookup_width` advice table columns, the shape of the
+        merged `lookup_any`s of /root/reference/zkevm-circuits/src/execution.rs:2305-2334;
+      * two second-phase advice columns and three challenges usable after the first phase
+        (/root/reference/zkevm-circuits/src/core_circuit.rs:153-154, /root/reference/zkevm-circuits/src/util.rs:63-67).
+    Column order: the units' 5 * units advice columns, per lane (w, t, u), the table columns, per wide lookup its input
+    columns, the two second-phase columns.  Fixed: the 5 of satisfied_cs, then q_k, q_w, q_2."""
+    cs = satisfied_cs(units, degree9=True, extra_gates=extra_gates)
+    base_adv = cs.num_advice_columns
+    q_k, q_w, q_2 = Fixed(5), Fixed(6), Fixed(7)
+    cs.num_fixed_columns = 8
+    cs.num_challenges = 3
+    col = base_adv
+    lane_cols = []
+    for j in range(lanes):
+        w, t, u = col, col + 1, col + 2
+        col += 3
+        lane_cols.append((w, t, u))
+        lin = Advice(t)
+        for i, r in enumerate(KECCAK_ROTATIONS):
+            lin = Sub(lin, Scaled(Advice(w, r), i + 2 + j))
+        far = Sub(Product(Advice(w, 0), Advice(w, 204)), Advice(u))
+        high = Product(q_k, far)
+        for i, r in enumerate((1, 5, 11, 12, 96, -12)):
+            high = Product(high, Sum(Advice(w, r), Constant(7 * j + i + 1)))
+        cs.gates.append([Product(q_k, lin), Product(q_k, far), high])
+    table_cols = list(range(col, col + lookup_width))
+    col += lookup_width
+    wide_inputs = []
+    for _ in range(wide_lookups):
+        ins = list(range(col, col + lookup_width))
+        col += lookup_width
+        wide_inputs.append(ins)
+        cs.lookups.append(Lookup([Product(q_w, Advice(c)) for c in ins], [Advice(c) for c in table_cols]))
+    r1, r2 = col, col + 1
+    col += 2
+    cs.num_advice_columns = col
+    x = wide_inputs[0] if wide_inputs else [0, 1, 2]
+    rlc = Sub(Sub(Sub(Advice(r1), Advice(x[0])), Product(Challenge(0), Advice(x[1]))), Product(Challenge(1), Advice(x[2])))
+    cs.gates.append([Product(q_2, rlc), Product(q_2, Sub(Advice(r2), Product(Challenge(2), Advice(0))))])
+    cs.advice_column_phase = [0] * (col - 2) + [1, 1]
+    cs.challenge_phase = [0, 0, 0]
+    cs.permutation_columns += [(ANY_ADVICE, lane_cols[0][0])] if lanes else []
+    cs.permutation_columns.append((ANY_ADVICE, r1))
+    cs._standin = dict(units=units, lanes=lane_cols, table=table_cols, wide=wide_inputs, second=(r1, r2), x=x)
+    return cs
+
+
+def standin_witness(cs, n, seed, active_rows=3000):
+    """(advice callable for `prover.create_proof`, instance, fixed, assembly) satisfying `standin_cs`.  Advice columns are
+    (usable, 4) Montgomery limb arrays, zero below the active rows; the callable fills the second-phase columns from the
+    challenges it is given."""
+    from .keygen import Assembly
+    from .prover import fr_limbs
+    from .plonk import FR_MODULUS as P
+    info = cs._standin
+    units = info["units"]
+    usable = n - (cs.blinding_factors() + 1)
+    m = min(usable - 210, active_rows)
+    assert m > 300, "not enough rows for the +204 rotation"
+    base_cs = satisfied_cs(units, degree9=True)
+    base_cs_bf = cs.blinding_factors()
+    # the units' columns: satisfied_witness sizes its rows from the constraint system's blinding factors, so hand it ours
+    shim = ConstraintSystem()
+    shim.blinding_factors = lambda: base_cs_bf
+    shim.permutation_columns = base_cs.permutation_columns
+    advice, instance, fixed, _ = satisfied_witness(shim, n, seed, units, active_rows=m, as_arrays=True)
+    rng = np.random.default_rng(seed + 1)
+    act = m + 205                                         # rows that may be non-zero
+
+    def arr(vals):
+        a = np.zeros((usable, 4), dtype=np.uint64)
+        a[:len(vals)] = fr_limbs(vals)
+        return a
+
+    first, last = 12, m                                   # q_k rows: first <= i < last (i - 12 >= 0, i + 204 < act)
+    for j, (w, t, u) in enumerate(info["lanes"]):
+        wv = [int(v) for v in rng.integers(0, 1 << 30, size=act)]
+        tv, uv = [0] * act, [0] * act
+        for i in range(first, last):
+            tv[i] = sum((k + 2 + j) * wv[i + r] for k, r in enumerate(KECCAK_ROTATIONS)) % P
+            uv[i] = wv[i] * wv[i + 204] % P
+        advice += [arr(wv), arr(tv), arr(uv)]
+    width = len(info["table"])
+    table_rows = 64
+    for j in range(width):
+        advice.append(arr([i * (j + 1) for i in range(table_rows)]))       # row 0 is all zero: what inactive rows look up
+    for ins in info["wide"]:
+        pick = [int(v) for v in rng.integers(0, table_rows, size=m)]
+        for j in range(width):
+            advice.append(arr([p * (j + 1) for p in pick]))
+    xs = [[int(v) for v in fr_from_limbs_rows(advice[c][:m])] for c in info["x"][:3]]
+    a0 = [int(v) for v in fr_from_limbs_rows(advice[0][:m])]
+    zero = np.zeros((usable, 4), dtype=np.uint64)
+    fixed = [list(c) for c in fixed]
+    fixed.append([1 if first <= i < last else 0 for i in range(n)])        # q_k
+    fixed.append([1] * m + [0] * (n - m))                                   # q_w
+    fixed.append([1] * m + [0] * (n - m))                                   # q_2
+    asm = Assembly(n, len(cs.permutation_columns))
+    inst_col = 3 * units
+    public = instance[0]
+    for u in range(units):                                                  # the copy constraints of satisfied_witness
+        asm.copy(3 * u, 0, inst_col, 2 * u)
+        asm.copy(3 * u, m, inst_col, 2 * u + 1)
+        asm.copy(3 * u + 1, 1, 3 * u + 1, 4)
+        asm.copy(3 * u + 2, 0, 3 * u + 1, 3)
+        if u:
+            asm.copy(3 * u + 1, 7, 3 * (u - 1) + 1, 7)
+
+    def advice_for(phase, challenges):
+        if phase == 0:
+            return advice + [zero, zero]
+        c0, c1, c2 = challenges[:3]
+        r1 = [(xs[0][i] + c0 * xs[1][i] + c1 * xs[2][i]) % P for i in range(m)]
+        r2 = [c2 * a0[i] % P for i in range(m)]
+        return advice + [arr(r1), arr(r2)]
+    return advice_for, [public], fixed, asm
+
+
+def fr_from_limbs_rows(rows):
+    """(len, 4) Montgomery limbs -> canonical integers"""
+    from .plonk import FR_MODULUS as P
+    rinv = pow(1 << 256, P - 2, P)
+    return [sum(int(w) << (64 * j) for j, w in enumerate(r)) * rinv % P for r in rows]
