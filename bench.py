@@ -31,10 +31,23 @@ from zkevm_circuits_amd import evalh_host, ffi, plonk, sharding, synthetic  # no
 K = 19
 LOG_EXT = 21
 MADS_PER_MUL, MADS_PER_SQR = 171, 135          # 81 + 81 + 9 and 45 + 81 + 9 v_mad_{u64_u32,i64_i32} / v_mul_lo_u32
-MADS_PER_MADD = 8 * MADS_PER_MUL + 2 * MADS_PER_SQR
-VALU_MAD_PEAK = 256 * 4 * 16 * 2.4e9           # one 32x32+64 multiply-add per lane per clock: 256 CUs x 4 SIMD16 x 2.4 GHz
-                                               # = 39.3 T/s (independent v_mad_u64_u32 chains measure 30.9 T/s on the chip)
+MADS_PER_MADD = 8 * MADS_PER_MUL + 2 * MADS_PER_SQR   # what this library's mixed addition issues (nine 29-bit digits)
+# Algorithmic price of one mixed addition: about 10 field multiplications of 8 x 8 + 8 x 8 + 8 = 136 32-bit multiply-adds
+# (the minimum over 32-bit limbs).  The roofline fraction is quoted on this count; the kernel's own count is reported beside it.
+ALG_MADS_PER_MADD = 10 * 136
+VALU_MAD_PEAK = 256 * 4 * 16 * 2.4e9           # nominal: a quarter-rate 32x32+64 multiply-add, 16 lanes per SIMD per clock,
+                                               # 256 CUs x 4 SIMDs x 2.4 GHz = 39.3 T/s
 HBM_PEAK = 8000.0                              # GB/s
+PROFILES = os.path.join(ROOT, "profiles")
+
+
+def load_profile_json(name):
+    """a summary that an earlier profiling run wrote under profiles/ (None when it is absent)"""
+    try:
+        with open(os.path.join(PROFILES, name)) as f:
+            return json.load(f)
+    except (OSError, ValueError):
+        return None
 
 
 def rand_fr_device(n, gen):
@@ -168,12 +181,20 @@ def main():
     ap.add_argument("--skip-extras", action="store_true",
                     help="only the timed steps: the kernel averages of a rocprofv3 run then describe exactly the timed region")
     ap.add_argument("--skip-proof", action="store_true", help="leave out the whole-proof measurement (create_proof_k19)")
+    ap.add_argument("--skip-replay", action="store_true", help="leave out the replay of the SuperCircuit's operator multiset")
     ap.add_argument("--evalh-k", type=int, default=K)
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # the replay is a child process with 166 GB of columns of its own: it runs before this process touches the GPU
+    replay = None
+    if not args.skip_extras and not args.skip_replay and world == 1:
+        try:
+            replay = run_replay()
+        except Exception as exc:                              # reported, never allowed to lose the bench line
+            replay = {"error": f"{type(exc).__name__}: {exc}"}
     # one rank per GPU; ZKHIP_BENCH_BACKEND=gloo rehearses the multi-rank path on a box with fewer GPUs than ranks
     backend = os.environ.get("ZKHIP_BENCH_BACKEND", "nccl")
     device_index = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
@@ -257,23 +278,26 @@ def main():
             extra["create_proof_k19"] = measure_create_proof(ctx, bid, dist if world > 1 else None)
         except Exception as exc:                          # reported, never allowed to lose the line above it
             extra["create_proof_k19"] = {"error": f"{type(exc).__name__}: {exc}"}
+    if replay is not None:
+        extra["replay_supercircuit_shape"] = replay
     finish(args, ctx, dist, world, rank, device_index, bid, scalars, n, en, elapsed, msm_ms, ntt_ms, acc_us, acc_launches, sort_us,
            merge_us, reduce_us, ntt_us, extra, evalh)
 
 
 def measure_create_proof(ctx, bid, dist_=None):
-    """One whole `create_proof` (zkevm_circuits_amd/prover.py) at k = 19 for a satisfied constraint system with the column
-    counts estimated for the reference's SuperCircuit (380 advice, 76 lookups, 229 permutation columns, 3345 gate
-    polynomials of degree up to nine).  The SRS here is the benchmark's unstructured table, so this proof is timed, not
-    verified; tests/test_gpu_prover.py runs the same call over a structured SRS and verifies the bytes.  With several ranks
-    the commitments are column-sharded and the quotient numerator coset-sharded (every rank holds the whole witness and
-    key, as the partition of the extended domain by coset needs); seconds = the slowest rank."""
+    """One whole `create_proof` (zkevm_circuits_amd/prover.py) at k = 19 for the SuperCircuit STAND-IN of
+    `synthetic.standin_cs`: a satisfied circuit with the column counts estimated for the reference's SuperCircuit and its
+    hard features together -- 376 advice columns in two phases, three challenges, 60 lookups of which eight are ten columns
+    wide into advice tables, keccak-like rotations up to +204 (32 blinding factors), about 2200 gate polynomials of degree
+    up to nine (extended domain 2^22).  The SRS here is the benchmark's unstructured table, so this proof is timed, not
+    verified; tests/test_gpu_configs.py runs the same circuit over a structured SRS and verifies the bytes.  With several
+    ranks the commitments are column-sharded and the quotient numerator coset-sharded; seconds = the slowest rank."""
     from zkevm_circuits_amd import prover
-    units, k = 76, K
-    cs = synthetic.satisfied_cs(units, True, 40)
+    k = K
+    cs = synthetic.standin_cs(units=52, lanes=8, wide_lookups=8, lookup_width=10, extra_gates=38)
     dom = zk.Domain(ctx, cs.degree(), k)
     params = prover.ParamsKZG.from_registered(ctx, dom, bid, bid)
-    advice, instance, fixed, asm = synthetic.satisfied_witness(cs, dom.n, k, units, active_rows=3000, as_arrays=True)
+    advice, instance, fixed, asm = synthetic.standin_witness(cs, dom.n, k, active_rows=3000)
     t0 = time.perf_counter()
     pk = prover.keygen(ctx, dom, params, cs, fixed, asm)
     ctx.sync()
@@ -296,12 +320,26 @@ def measure_create_proof(ctx, bid, dist_=None):
         dist_.all_reduce(t, op=dist_.ReduceOp.MAX)
         seconds = float(t.cpu()[0])
     return {"seconds": seconds, "ranks": ranks, "keygen_seconds": keygen_seconds, "phases_s": phases, "proof_bytes": len(proof),
-            "shape": {"k": k, "extended_k": k + 3, "advice": cs.num_advice_columns, "fixed": cs.num_fixed_columns,
-                      "lookups": len(cs.lookups), "permutation_columns": len(cs.permutation_columns),
+            "shape": {"k": k, "extended_k": dom.extended_k, "advice": cs.num_advice_columns, "fixed": cs.num_fixed_columns,
+                      "lookups": len(cs.lookups), "widest_lookup": max(len(lk.input_expressions) for lk in cs.lookups),
+                      "permutation_columns": len(cs.permutation_columns), "blinding_factors": cs.blinding_factors(),
+                      "phases": len(cs.phases()), "challenges": cs.num_challenges,
                       "gate_polynomials": sum(len(g) for g in cs.gates), "degree": cs.degree()},
-            "note": "wall time of one proof (slowest rank) including the Python host side and the 6.4 GB upload of the witness; "
-                    "with several ranks only the commitments and the quotient numerator are sharded, the rest is replicated; "
-                    "synthetic satisfied circuit, not the SuperCircuit; timed here, verified in tests/test_gpu_prover.py"}
+            "note": "STAND-IN, not the SuperCircuit (which cannot be instantiated without the reference's Rust halo2 fork): wall "
+                    "time of one proof (slowest rank) including the Python host side and the upload of the witness; with "
+                    "several ranks only the commitments and the quotient numerator are sharded, the rest is replicated; timed "
+                    "here, verified in tests/test_gpu_configs.py"}
+
+
+def run_replay():
+    """`replay.py` (the operator multiset of one create_proof at the SuperCircuit's estimated shape, synthetic columns) as
+    a child process; returns its JSON line"""
+    import subprocess
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "replay.py")], capture_output=True, text=True, timeout=600)
+    for ln in reversed(out.stdout.splitlines()):
+        if ln.startswith("{"):
+            return json.loads(ln)
+    raise RuntimeError(f"replay.py printed no JSON line (exit {out.returncode}): {out.stderr[-300:]}")
 
 
 def measure_extras(ctx, dom, bid, stream, gen, n, en, extra):
@@ -461,11 +499,19 @@ def finish(args, ctx, dist, world, rank, local_rank, bid, scalars, n, en, elapse
            merge_us, reduce_us, ntt_us, extra, evalh):
     split_ok = None
     if world > 1:
+        # one MSM split by base range over the ranks: every rank takes rank 0's scalars, commits its own range, the partial
+        # sums are all-gathered and folded; the fold must be the point a single GPU computes over the whole range
+        shared = scalars.clone()
+        dist.broadcast(shared, src=0)
+        torch.cuda.synchronize()
         full = sharding.msm_base_split(
-            n, lambda first, cnt: ctx.msm_range_dev(bid, first, scalars.data_ptr() + 32 * first, cnt),
+            n, lambda first, cnt: ctx.msm_range_dev(bid, first, shared.data_ptr() + 32 * first, cnt),
             ctx.g1_sum_jacobian, dist, device=torch.device("cuda", local_rank))
-        # every rank holds different scalars, so only the mechanics are checked here: the fold is a valid point
-        split_ok = bool(np.asarray(full).any())
+        single = ctx.msm_range_dev(bid, 0, shared.data_ptr(), n)
+        split_ok = bool(np.array_equal(ctx.g1_to_affine(full), ctx.g1_to_affine(single)) and np.asarray(single).any())
+        flag = torch.tensor([1 if split_ok else 0], dtype=torch.int64, device="cuda")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        split_ok = bool(int(flag.cpu()[0]))
 
     cpu = None
     if rank == 0 and world == 1 and not args.skip_cpu:
@@ -477,8 +523,19 @@ def finish(args, ctx, dist, world, rank, local_rank, bid, scalars, n, en, elapse
         ntt_bytes = 32.0 * (n + en)
         ntt_mads = (en / 2 * LOG_EXT + 2 * en * 2 + 2 * n / 3) * MADS_PER_MUL
         W = 16
-        alg_mads = float(n) * W * MADS_PER_MADD
+        adds = float(n) * W                                    # mixed additions of one accumulate launch
+        alg_mads, own_mads = adds * ALG_MADS_PER_MADD, adds * MADS_PER_MADD
         achieved = alg_mads / (acc_us * 1e-6) if acc_us else 0.0
+        own = own_mads / (acc_us * 1e-6) if acc_us else 0.0
+        probe = load_profile_json("valu_probe.json")            # tools/valu_probe on this chip (profiles/)
+        mad_peak_measured = None
+        if probe:
+            rows = [r for r in probe["rows"] if r["inst"] == "v_mad_u64_u32"]
+            mad_peak_measured = max(r["t_lane_ops_per_s"] for r in rows) * 1e12 if rows else None
+        pmc = load_profile_json("pmc_traffic.json") or {}      # tools/collect_pmc.sh + tools/pmc_to_json.py (profiles/)
+        acc_pmc, ntt_pmc = pmc.get("accumulate_kernel"), pmc.get("ntt_tile_kernel")
+        standin = extra.get("create_proof_k19") or {}
+        replay = extra.get("replay_supercircuit_shape") or {}
         line = {
             "metric": "super_circuit k=19 proof time (s) at 1/8 GPU; MSM Mpts/s, NTT GB/s",
             "value": msm_mpts, "unit": "Mpts/s (2^19 G1 MSM; NTT GB/s and per-phase figures in the extra keys)",
@@ -487,26 +544,36 @@ def finish(args, ctx, dist, world, rank, local_rank, bid, scalars, n, en, elapse
             "data": "synthetic",
             "config": {"workload": "configs[1]: 2^19 G1 MSM (uniform scalars, bases [i]G) + 2^19->2^21 coset NTT per step",
                        "k": K, "extended_k": LOG_EXT, "parallelism": f"columns x{world}" if world > 1 else "single GPU"},
+            # the metric's first quantity: NOT measured on the SuperCircuit (it needs the reference's Rust halo2 fork); two
+            # stand-ins on this GPU bracket it -- a verified-shape proof of a satisfied stand-in circuit, and the replay of
+            # the operator multiset of the estimated SuperCircuit shape on random columns
+            "proof_time_s_standin": {"create_proof_k19_standin_s": standin.get("seconds"),
+                                     "replay_supercircuit_shape_s": replay.get("total_s"),
+                                     "what": "stand-in circuits, see create_proof_k19 / replay_supercircuit_shape below"},
             "msm_ms": msm_ms, "msm_Mpts_per_s_per_gpu": n / (msm_ms * 1e-3) / 1e6,
             "msm_phases_us": {"sort": sort_us, "accumulate": acc_us, "merge": merge_us, "reduce": reduce_us},
             "coset_ntt_ms": ntt_ms, "coset_ntt_GBps": world * ntt_bytes / (ntt_ms * 1e-3) / 1e9,
             "coset_ntt_frac_of_hbm_peak": ntt_bytes / (ntt_ms * 1e-3) / 1e9 / HBM_PEAK,
-            "roofline": {"bound": "valu", "bound_note": "32x32+64 integer multiply-add issue rate of the vector ALUs: the kernel is no dense contraction (no MFMA) and moves 0.75 GB per launch (not HBM-bound)", "kernel": "accumulate_kernel", "achieved": achieved / 1e12,
-                         "peak": VALU_MAD_PEAK / 1e12, "unit": "Tmad/s", "frac": achieved / VALU_MAD_PEAK,
+            "roofline": {"bound": "valu", "bound_note": "32x32+64 integer multiply-add issue rate of the vector ALUs: the kernel is no dense contraction (no MFMA) and moves 0.75 GB per launch (not HBM-bound)", "kernel": "accumulate_kernel",
+                         # algorithmic count: 1360 multiply-adds per mixed addition (10 field products of 136)
+                         "achieved": achieved / 1e12, "peak": VALU_MAD_PEAK / 1e12, "unit": "Tmad/s", "frac": achieved / VALU_MAD_PEAK,
+                         "algorithmic": f"{n}*{W} mixed adds * {ALG_MADS_PER_MADD} multiply-adds",
+                         # the kernel's own instruction count (nine 29-bit digits: 1638 per addition), and both against the
+                         # v_mad_u64_u32 rate measured on this chip with independent chains
+                         "achieved_own_count": own / 1e12, "frac_own_count": own / VALU_MAD_PEAK,
+                         "peak_measured": mad_peak_measured / 1e12 if mad_peak_measured else None,
+                         "frac_of_measured_peak": achieved / mad_peak_measured if mad_peak_measured else None,
+                         "frac_own_count_of_measured_peak": own / mad_peak_measured if mad_peak_measured else None,
                          "avg_launch_us": acc_us, "launches": acc_launches,
-                         # HBM bytes per launch from separate rocprofv3 --pmc passes over this same command
-                         # (profiles/r01_pmc_summary_v5.txt: FETCH_SIZE 667.4e3 KiB, WRITE_SIZE 69.6e3 KiB); the
-                         # algorithmic gather is n*W 64-byte points + 4-byte entries = 571 MB
-                         "traffic": 754.7e6, "traffic_unit": "bytes per launch (FETCH_SIZE + WRITE_SIZE, measured offline)",
-                         "algorithmic": f"{n}*{W} mixed adds * {MADS_PER_MADD} multiply-adds"},
+                         # HBM bytes per launch from separate rocprofv3 --pmc passes over this command's timed region
+                         "traffic": acc_pmc["bytes_per_launch"] if acc_pmc else None,
+                         "traffic_detail": acc_pmc,
+                         "algorithmic_bytes": adds * 64 + adds * 4},
             "roofline_ntt": {"bound": "hbm", "kernel": "ntt_tile_kernel (3 passes)", "achieved": ntt_bytes / (ntt_us * 1e-6) / 1e9 if ntt_us else 0.0,
                              "peak": HBM_PEAK, "unit": "GB/s", "frac": (ntt_bytes / (ntt_us * 1e-6) / 1e9 / HBM_PEAK) if ntt_us else 0.0,
                              "avg_launch_us": ntt_us,
-                             # three passes: each reads and writes the 2^21-element buffer once (first pass reads 2^19)
-                             # and the last two read boundary twiddle tables (8 MB and 64 MB) by gather; the doubling of
-                             # FETCH_SIZE that gfx950 needs for streaming reads over-counts those gathers, so this is an
-                             # upper bound (profiles/r01_pmc_summary_v5.txt: 61.9e3 KiB read, 65.6e3 KiB written per launch)
-                             "traffic": 586.5e6, "traffic_unit": "bytes per transform (FETCH_SIZE x2 + WRITE_SIZE over its 3 launches, measured offline)",
+                             "traffic": ntt_pmc["bytes_per_transform"] if ntt_pmc else None,
+                             "traffic_detail": ntt_pmc,
                              "algorithmic_bytes": ntt_bytes,
                              # the transform is multiplier-bound, not HBM-bound: (M/2) log2 M butterfly products, two
                              # twiddle products per element between passes, the zeta scaling of 2/3 of the inputs
