@@ -299,7 +299,9 @@ def measure_create_proof(ctx, bid, dist_=None):
     params = prover.ParamsKZG.from_registered(ctx, dom, bid, bid)
     advice, instance, fixed, asm = synthetic.standin_witness(cs, dom.n, k, active_rows=3000)
     t0 = time.perf_counter()
-    pk = prover.keygen(ctx, dom, params, cs, fixed, asm)
+    ctx.reset_peak()
+    resident0 = ctx.allocated_bytes
+    pk = prover.keygen(ctx, dom, params, cs, fixed, asm, dist=dist_)
     ctx.sync()
     t1 = time.perf_counter()
     phases = {}
@@ -320,6 +322,7 @@ def measure_create_proof(ctx, bid, dist_=None):
         dist_.all_reduce(t, op=dist_.ReduceOp.MAX)
         seconds = float(t.cpu()[0])
     return {"seconds": seconds, "ranks": ranks, "keygen_seconds": keygen_seconds, "phases_s": phases, "proof_bytes": len(proof),
+            "peak_device_GB_this_rank": (ctx.peak_allocated_bytes - resident0) / 1e9,
             "shape": {"k": k, "extended_k": dom.extended_k, "advice": cs.num_advice_columns, "fixed": cs.num_fixed_columns,
                       "lookups": len(cs.lookups), "widest_lookup": max(len(lk.input_expressions) for lk in cs.lookups),
                       "permutation_columns": len(cs.permutation_columns), "blinding_factors": cs.blinding_factors(),
@@ -468,19 +471,23 @@ def measure_evalh_split(ctx, dom, stream, gen, world, rank):
     """evaluate_h of the bench configuration split by coset over the ranks (strong scaling of ONE evaluation): every
     owner evaluates its cosets on compact columns, one all-gather moves the pieces of h.  Reported next to the
     per-rank figures; the headline value does not include it."""
-    owners = min(world, 1 << (dom.extended_k - dom.k))
-    cosets = sharding.cosets_for_rank(dom.extended_k, dom.k, rank, owners) if rank < owners else []
+    parts = sharding.coset_partition(dom.extended_k, dom.k, world)
+    owners = sum(p is not None for p in parts)
+    mine = parts[rank]
     built = None
-    if cosets:
+    if mine is not None:
         with torch.cuda.stream(stream):
-            built = build_evalh(ctx, dom, gen, dom.k, cosets)
+            built = build_evalh(ctx, dom, gen, dom.k, mine[0])
         stream.synchronize()
+        if mine[2] != dom.n * len(mine[0]):               # a row range of a shared coset
+            built[3].rows = (mine[1], mine[2])
+            built = (built[3].build(ffi.MEM_DEVICE, ffi.FORM_EXTENDED),) + tuple(built[1:])
 
-    def evaluate(cs_):
+    def evaluate(cs_, row_first, row_count):
         if not cs_:
             return torch.empty((0, 4), dtype=torch.int64, device="cuda")
         dom.evaluate_h(built[0], built[1].data_ptr())
-        return built[1]
+        return built[1][:row_count]
     sharding.evaluate_h_by_cosets(dom.extended_k, dom.k, evaluate, dist)      # warm-up
     torch.cuda.synchronize()
     dist.barrier()
@@ -491,8 +498,9 @@ def measure_evalh_split(ctx, dom, stream, gen, world, rank):
     dt = time.perf_counter() - t0
     t = torch.tensor([dt], dtype=torch.float64, device="cuda")
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    return {"ranks": world, "ranks_with_cosets": owners, "cosets_per_owner": (1 << (dom.extended_k - dom.k)) // owners,
-            "seconds_including_all_gather": float(t.cpu()[0]), "rows_gathered": int(sum(p.shape[0] for _, p in pieces))}
+    return {"ranks": world, "ranks_with_rows": owners, "rows_per_owner": int(mine[2]) if mine is not None else 0,
+            "cosets": 1 << (dom.extended_k - dom.k),
+            "seconds_including_all_gather": float(t.cpu()[0]), "rows_gathered": int(sum(p.shape[0] for _, _, p in pieces))}
 
 
 def finish(args, ctx, dist, world, rank, local_rank, bid, scalars, n, en, elapsed, msm_ms, ntt_ms, acc_us, acc_launches, sort_us,

@@ -183,9 +183,14 @@ typedef struct {
      * rows, rotations move single rows, out has 2^k rows): `plonk::lookup::prover::Argument::commit_permuted`'s
      * compress_expressions, with the theta-Horner of the expressions as the graph's last calculation.                 */
     uint32_t basis;
+    /* row_count != 0: evaluate only the rows [row_first, row_first + row_count) of the domain the call works on (the
+     * extended domain, or the compact layout of `cosets`); every column is still given whole, `out` has row_count rows.
+     * More GPUs than cosets share a coset this way without exchanging neighbouring rows (no reference counterpart). */
+    uint32_t row_first, row_count;
 } zkhip_evalh_desc;
 
-/* out: 2^ext_k x 4 (host or device per desc->mem) = numerator of the quotient on the extended coset. */
+/* out: 2^ext_k x 4 (host or device per desc->mem) = numerator of the quotient on the extended coset (2^k * num_cosets rows
+ * with a coset list, row_count rows with a row window). */
 int zkhip_evaluate_h(zkhip_domain* dom, const zkhip_evalh_desc* desc, uint64_t* out);
 /* Size of the fused program the last zkhip_evaluate_h call on this context ran per extended row: out[0] instructions,
  * out[1] field multiplications, out[2] column reads, out[3] value slots (for throughput accounting; no reference

@@ -32,7 +32,7 @@ def test_struct_layout_matches_header():
     # sizes computed from the C declarations (LP64): catches a drifted ctypes mirror
     assert C.sizeof(ffi.Graph) == 48
     assert C.sizeof(ffi.Lookup) == 48 + 24
-    assert C.sizeof(ffi.EvalhDesc) == 6 * 4 + 4 * 8 + 4 * 32 + 3 * 8 + 8 + 8 + 8 + 8 + 3 * 8 + 8 + 8 + 8 + 8 + 8 + 8
+    assert C.sizeof(ffi.EvalhDesc) == 6 * 4 + 4 * 8 + 4 * 32 + 3 * 8 + 8 + 8 + 8 + 8 + 3 * 8 + 8 + 8 + 8 + 8 + 8 + 8 + 8
 
 
 def test_code_object_targets_gfx950():

@@ -72,10 +72,11 @@ def _worker(rank, world, port, q):
                 out[s::len(cosets)] = a[j::1 << e]
             return out
 
-        def evaluate(cosets):
+        def evaluate(cosets, row_first, row_count):
             if not cosets:
                 return torch.empty((0, 4), dtype=torch.int64)
             call.cosets = cosets
+            call.rows = (row_first, row_count) if row_count != n * len(cosets) else None
             call.fixed = [compact(a, cosets) for a in ext_cols["fixed"]]
             call.perm_sigma = [compact(a, cosets) for a in ext_cols["sigma"]]
             call.perm_z = [compact(a, cosets) for a in ext_cols["perm_z"]]
@@ -84,7 +85,7 @@ def _worker(rank, world, port, q):
             return torch.from_numpy(part.view(np.int64).copy())
         pieces = sharding.evaluate_h_by_cosets(dom.extended_k, k, evaluate, dist)
         h = np.zeros((en, 4), dtype=np.uint64)
-        for cosets, rows in pieces:
+        for cosets, rows in sharding.assemble_cosets(pieces, k):
             arr = rows.numpy().view(np.uint64)
             for s, j in enumerate(cosets):
                 h[j::1 << e] = arr[s::len(cosets)]
@@ -138,31 +139,60 @@ def _prover_worker(rank, world, port, q):
     import coracle
     import prover_cases as pc
     import verifier_model as vm
-    from zkevm_circuits_amd import prover
+    from zkevm_circuits_amd import keygen, plonk, prover
+    from zkevm_circuits_amd.plonk import Advice, Fixed, Product, Sub
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     dist.init_process_group("gloo", rank=rank, world_size=world)
+
+    def small_circuit(n):
+        """degree three, i.e. an extended domain of two cosets: four ranks share each coset by row ranges"""
+        cs = plonk.ConstraintSystem(num_fixed_columns=1, num_advice_columns=2)
+        cs.gates = [[Product(Fixed(0), Sub(Product(Advice(0), Advice(0)), Advice(1, 1)))]]
+        cs.permutation_columns = [(plonk.ANY_ADVICE, 0), (plonk.ANY_ADVICE, 1)]
+        usable = n - (cs.blinding_factors() + 1)
+        a = [(3 * i) % 7 for i in range(usable)]
+        a[9] = a[5] * a[5]
+        b = [0] + [v * v for v in a[:-1]]
+        asm = keygen.Assembly(n, 2)
+        asm.copy(1, 6, 0, 9)
+        return cs, [a, b], [], [[1] * (usable - 1) + [0] * (n - usable + 1)], asm
     try:
         ctx = zk.Context(0)
         results = []
-        for k, units, degree9 in ((8, 1, False), (9, 3, True)):
-            cs = pc.wide_circuit(units, degree9, 3)
+        cases = [(8, 1, False), (9, 3, True)] if world == 2 else [(9, 1, False), (10, None, None)]
+        for k, units, degree9 in cases:
+            if units is None:
+                cs, advice, instance, fixed, asm = small_circuit(1 << k)
+            else:
+                cs = pc.wide_circuit(units, degree9, 3)
+                advice, instance, fixed, asm = pc.wide_witness(cs, 1 << k, k, units)
             dom = zk.Domain(ctx, cs.degree(), k)
             params = prover.ParamsKZG(ctx, dom, pc.srs(coracle, dom.n))
-            advice, instance, fixed, asm = pc.wide_witness(cs, dom.n, k, units)
-            pk = prover.keygen(ctx, dom, params, cs, fixed, asm)
-            sharded = prover.create_proof(ctx, dom, params, pk, advice, instance, prover.FieldRng(k), prover.Blake2bWrite(),
+            # the key of the sharded prover: every rank keeps the key's extended vectors on its own cosets only
+            ctx.reset_peak()
+            base = ctx.allocated_bytes
+            pk_s = prover.keygen(ctx, dom, params, cs, fixed, asm, dist=dist)
+            sharded = prover.create_proof(ctx, dom, params, pk_s, advice, instance, prover.FieldRng(k), prover.Blake2bWrite(),
                                           dist=dist)
+            peak_sharded = ctx.peak_allocated_bytes - base
+            for p in pk_s.pointers():
+                ctx.free(p)
             if rank == 0:
+                ctx.reset_peak()
+                base = ctx.allocated_bytes
+                pk = prover.keygen(ctx, dom, params, cs, fixed, asm)
                 whole = prover.create_proof(ctx, dom, params, pk, advice, instance, prover.FieldRng(k), prover.Blake2bWrite())
+                peak_whole = ctx.peak_allocated_bytes - base
                 vk = {"fixed_commitments": pk.fixed_commitments, "permutation_commitments": pk.permutation_commitments,
                       "transcript_repr": pk.transcript_repr}
                 vm.verify_proof(cs, k, vk, instance, sharded, pc.TAU)
-                results.append(sharded == whole)
+                same_vk = pk.fixed_commitments == pk_s.fixed_commitments and pk.transcript_repr == pk_s.transcript_repr
+                results.append((sharded == whole and same_vk, peak_sharded, peak_whole, dom.extended_k - k))
+                for p in pk.pointers():
+                    ctx.free(p)
             dist.barrier()
-            for p in pk.pointers():
-                ctx.free(p)
             params.close()
             dom.close()
         if rank == 0:
@@ -173,10 +203,12 @@ def _prover_worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
-def test_two_ranks_create_the_same_proof_as_one():
-    """create_proof with the commitments column-sharded and the quotient numerator coset-sharded over two ranks: the
-    bytes equal the single-rank proof (extended domains 4n and 8n) and pass the verifier model"""
-    world = 2
+@pytest.mark.parametrize("world", [2, 4])
+def test_ranks_create_the_same_proof_as_one(world):
+    """create_proof with the commitments column-sharded and the quotient numerator coset-sharded: the bytes equal the
+    single-rank proof and pass the verifier model.  Two ranks: extended domains 4n and 8n, whole cosets per rank.  Four
+    ranks: 4n (one coset each) and 2n (two ranks share a coset by row ranges).  Each rank's peak of resident column data
+    (key generation + proof) shrinks with the share of the extended domain it holds."""
     mpctx = mp.get_context("spawn")
     q = mpctx.Queue()
     port = _free_port()
@@ -184,9 +216,18 @@ def test_two_ranks_create_the_same_proof_as_one():
     for p in procs:
         p.start()
     try:
-        results = q.get(timeout=240)
+        results = q.get(timeout=300)
     finally:
         for p in procs:
             p.join(timeout=120)
     assert all(p.exitcode == 0 for p in procs)
-    assert results == [True, True]
+    assert [r[0] for r in results] == [True, True]
+    for ok, peak_sharded, peak_whole, e in results:
+        share = max(1.0 / world, 1.0 / (1 << e))          # the part of the extended domain one rank holds
+        # the 2^k-sized polynomials (coefficient and Lagrange forms) stay whole on every rank: they come on top of the
+        # rank's share of the extended vectors, and weigh most where the extended domain is only 2n
+        assert peak_sharded < peak_whole, (peak_sharded, peak_whole, share)
+        if e >= 2:
+            assert peak_sharded < (share + 0.3) * peak_whole, (peak_sharded, peak_whole, share)
+        print(f"world {world}, extended domain 2^{e} n: peak resident {peak_sharded / 1e6:.1f} MB per rank sharded, "
+              f"{peak_whole / 1e6:.1f} MB single rank")

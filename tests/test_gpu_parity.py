@@ -923,6 +923,48 @@ def test_evaluate_h_split_by_coset_matches_whole(ctx, co, k, kw):
     d.close()
 
 
+@pytest.mark.parametrize("k,kw", [
+    (9, dict(num_advice=12, num_gate_polys=40, num_lookups=3, num_perm_cols=7)),
+    (10, dict(num_advice=40, num_fixed=8, num_gate_polys=300, max_degree=9, num_lookups=2, num_perm_cols=11)),
+])
+def test_evaluate_h_row_windows_match_whole(ctx, co, k, kw):
+    """a row window of the extended domain, and of a coset's compact layout, gives exactly those rows of the whole
+    evaluation: what ranks that share a coset compute (more GPUs than cosets), with the columns whole and no exchange of
+    neighbouring rows; windows that are no multiple of a workgroup and windows at both ends included"""
+    from zkevm_circuits_amd import sharding
+    cs = synthetic.synthetic_cs(**kw)
+    d, od = zk.Domain(ctx, cs.degree(), k), co.Domain(cs.degree(), k, threads=8)
+    e, n, en = d.extended_k - k, d.n, d.extended_len
+    rng = np.random.default_rng(k + 70)
+    call, coeff, ext = _random_call(cs, rng, n, en, od)
+    call.advice, call.instance, call.lookups = ext["advice"], ext["instance"], ext["lookups"]
+    whole = d.evaluate_h(call.build(ffi.MEM_HOST, ffi.FORM_EXTENDED))
+    for first, count in ((0, 256), (en - 512, 512), (en // 2 - 100, 777), (3, 1), (0, en)):
+        call.rows = (first, count)
+        part = d.evaluate_h(call.build(ffi.MEM_HOST, ffi.FORM_EXTENDED))
+        assert part.shape[0] == count and np.array_equal(part, whole[first:first + count]), (first, count)
+    call.rows = (en - 5, 6)
+    with pytest.raises(ffi.ZkhipError):
+        d.evaluate_h(call.build(ffi.MEM_HOST, ffi.FORM_EXTENDED))
+    # sixteen ranks over 2^e cosets: every rank a row range of one coset, from the coefficient form
+    pk = dict(fixed=call.fixed, l0=call.l0, l_last=call.l_last, l_active=call.l_active, perm_sigma=call.perm_sigma,
+              perm_z=call.perm_z)
+    world = 2 << e
+    back = np.zeros_like(whole)
+    for cosets, first, count in sharding.coset_partition(d.extended_k, k, world):
+        c = lambda a: _compact(a, cosets, e)
+        call.cosets, call.rows = cosets, (first, count)
+        call.fixed = [c(a) for a in pk["fixed"]]
+        call.l0, call.l_last, call.l_active = c(pk["l0"]), c(pk["l_last"]), c(pk["l_active"])
+        call.perm_sigma, call.perm_z = [c(a) for a in pk["perm_sigma"]], [c(a) for a in pk["perm_z"]]
+        call.advice, call.instance, call.lookups = coeff["advice"], coeff["instance"], coeff["lookups"]
+        part = d.evaluate_h(call.build(ffi.MEM_HOST, ffi.FORM_COEFF))
+        assert len(cosets) == 1 and part.shape[0] == count == n // 2
+        back[cosets[0]::1 << e][first:first + count] = part
+    assert np.array_equal(back, whole)
+    d.close()
+
+
 # ------------------------------------------------------------------------------------------------ lookup permutation
 def _lookup_pair(rng, n, usable, table_size, distinct_inputs):
     """table column: `table_size` distinct values padded with repeats of the first one (as halo2 tables are padded);

@@ -140,6 +140,28 @@ def test_partition_helpers():
             assert ((idx + rot * (1 << e)) % (1 << ek)) % (1 << e) == idx % (1 << e)
 
 
+def test_coset_partition():
+    """how ranks share the cosets of the extended domain: whole cosets up to 2^e ranks, row ranges of a coset beyond,
+    ranks past the largest power of two own nothing; the pieces tile the domain exactly once"""
+    for ek, k, world in ((22, 19, 1), (22, 19, 2), (22, 19, 8), (21, 19, 8), (21, 19, 3), (21, 19, 5), (20, 19, 8), (12, 10, 64)):
+        parts = sharding.coset_partition(ek, k, world)
+        assert len(parts) == world
+        e, n = ek - k, 1 << k
+        owners = [p for p in parts if p is not None]
+        assert len(owners) == min(1 << (world.bit_length() - 1), (1 << e) * max(1, n // 256))
+        assert all(p is None for p in parts[len(owners):])
+        seen = set()
+        for cosets, first, count in owners:
+            assert count == (1 << ek) // len(owners)
+            for q in range(first, first + count):             # compact row q of the cosets' layout
+                seen.add((q // len(cosets)) * (1 << e) + cosets[q % len(cosets)]) if ek <= 12 else None
+        if ek <= 12:
+            assert seen == set(range(1 << ek))
+    assert sharding.coset_partition(21, 19, 8)[5] == ([1], 1 << 18, 1 << 18)
+    assert sharding.coset_partition(22, 19, 2)[1] == ([1, 3, 5, 7], 0, 4 << 19)
+    assert sharding.coset_partition(21, 19, 3) == [([0, 2], 0, 2 << 19), ([1, 3], 0, 2 << 19), None]
+
+
 def test_shplonk_intermediate_sets_match_model():
     import halo2_model as hm
     from zkevm_circuits_amd import shplonk

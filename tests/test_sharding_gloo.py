@@ -40,31 +40,43 @@ def _worker(rank, world, port, n, ncols, q):
     mine = {c: co.best_multiexp(scal[c], bases) for c in sharding.columns_for_rank(ncols, rank, world)}
     allc = sharding.gather_commitments(mine, ncols, dist)
     # (3) evaluate_h split by coset: every rank evaluates its cosets (here: reads them out of a stand-in h that all
-    # ranks derive from the same seed), one all-gather, and the pieces are put back in extended order
+    # ranks derive from the same seed), one all-gather, and the pieces are put back in extended order.  Two shapes:
+    # four cosets (whole cosets per rank up to four ranks) and two cosets of 2^9 rows (ranks beyond two share a coset by
+    # row ranges); ranks past the largest power of two own nothing and still take part in the collective.
     import torch
-    k, ek = 4, 6
-    h_full = np.random.default_rng(7).integers(0, 2 ** 63, size=(1 << ek, 4), dtype=np.int64)
+    for k, ek in ((4, 6), (9, 10)):
+        h_full = np.random.default_rng(7).integers(0, 2 ** 63, size=(1 << ek, 4), dtype=np.int64)
 
-    def evaluate(cosets):
-        m = len(cosets)
-        out = np.zeros(((1 << k) * m, 4), dtype=np.int64)
-        for s_, j in enumerate(cosets):
-            out[s_::m] = h_full[j::1 << (ek - k)] if m else 0
-        return torch.from_numpy(out)
-    pieces = sharding.evaluate_h_by_cosets(ek, k, evaluate, dist)
-    h_back = np.zeros_like(h_full)
-    for cosets, rows in pieces:
-        for s_, j in enumerate(cosets):
-            h_back[j::1 << (ek - k)] = rows.numpy()[s_::len(cosets)]
-    assert np.array_equal(h_back, h_full)
-    assert sorted(j for cosets, _ in pieces for j in cosets) == list(range(1 << (ek - k)))
+        def evaluate(cosets, row_first, row_count):
+            m = len(cosets)
+            out = np.zeros(((1 << k) * m, 4), dtype=np.int64)
+            for s_, j in enumerate(cosets):
+                out[s_::m] = h_full[j::1 << (ek - k)]
+            return torch.from_numpy(out[row_first:row_first + row_count].copy())
+        pieces = sharding.evaluate_h_by_cosets(ek, k, evaluate, dist)
+        owners = sum(p is not None for p in sharding.coset_partition(ek, k, world))
+        assert len(pieces) == owners and all(rows.shape[0] == (1 << ek) // owners for _, _, rows in pieces)
+        h_back = np.zeros_like(h_full)
+        whole = sharding.assemble_cosets(pieces, k)
+        for cosets, rows in whole:
+            assert rows.shape[0] == (1 << k) * len(cosets)
+            for s_, j in enumerate(cosets):
+                h_back[j::1 << (ek - k)] = rows.numpy()[s_::len(cosets)]
+        assert np.array_equal(h_back, h_full)
+        assert sorted(j for cosets, _ in whole for j in cosets) == list(range(1 << (ek - k)))
     q.put((rank, co.g1_to_affine(full), np.stack([co.g1_to_affine(j) for j in allc])))
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_world_size_2_matches_single_process(co):
-    n, ncols, world = 200, 5, 2
+import pytest
+
+
+@pytest.mark.parametrize("world", [2, 3, 4])
+def test_world_matches_single_process(co, world):
+    """world 2: whole cosets per rank; world 3: the third rank owns no coset and the job neither fails nor hangs; world 4:
+    two ranks share each of the two cosets of the second shape by row ranges"""
+    n, ncols = 200, 5
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()

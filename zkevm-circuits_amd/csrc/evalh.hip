@@ -72,8 +72,9 @@ struct InterpArgs {
     uint32_t n_instr;
     uint32_t result_hdr;        // operand of the final value (slot / running value / zero)
     uint32_t lds_slots;
-    uint32_t log_size;          // extended_k
-    int32_t* spill;             // [slot - lds_slots][digit][size]
+    uint32_t log_size;          // log2 of the rows of every column (rotations wrap around at this size)
+    uint32_t row_first, rows;   // the rows evaluated: [row_first, row_first + rows); out and the spill buffer hold `rows` rows
+    int32_t* spill;             // [slot - lds_slots][digit][rows]
     fe* out;
 };
 
@@ -102,7 +103,7 @@ __device__ __forceinline__ fe ev_raw(const Opnd& o, uint32_t idx, uint32_t mask)
 // enter through from_fe_shl5 (value up to 32 p); the host tracks magnitudes and keeps every stored value below EV_LIMIT p.
 // Value slots: slot 0 is a register of the lane, slots 1 .. lds_slots-1 live in LDS, the rest in the spill buffer.
 __device__ __forceinline__ fw ev_value(const InterpArgs& a, const Opnd& o, const fe& raw, const int32_t* lds, const fw& acc,
-                                       const fw& reg0, uint32_t idx) {
+                                       const fw& reg0, uint32_t local) {
     const uint32_t kind = o.hdr >> 28, pl = o.hdr & 0x0fffffffu;
     switch (kind) {
         case L_ROW: return FrW::from_fe_shl5(raw);
@@ -114,9 +115,9 @@ __device__ __forceinline__ fw ev_value(const InterpArgs& a, const Opnd& o, const
 #pragma unroll
                 for (int d = 0; d < 9; d++) v.d[d] = lds[((pl - 1) * 9 + d) * EV_THREADS + threadIdx.x];
             } else {
-                const int32_t* base = a.spill + (((size_t)(pl - a.lds_slots) * 9) << a.log_size) + idx;
+                const int32_t* base = a.spill + (size_t)(pl - a.lds_slots) * 9 * a.rows + local;
 #pragma unroll
-                for (int d = 0; d < 9; d++) v.d[d] = base[(size_t)d << a.log_size];
+                for (int d = 0; d < 9; d++) v.d[d] = base[(size_t)d * a.rows];
             }
             return v;
         }
@@ -146,6 +147,7 @@ __device__ __forceinline__ void ev_stage(Staged& s, prog_ptr w, uint32_t idx, ui
     if (kc == L_ROW || kc == L_UNI) s.rc = ev_raw(s.c, idx, mask);
 }
 __device__ __forceinline__ void ev_execute(const InterpArgs& a, const Staged& s, int32_t* lds, fw& acc, fw& reg0, uint32_t idx) {
+    // idx: the lane's row inside the evaluated window (value slots are per lane; columns were read while staging)
     const uint32_t w0 = s.w0, dst = w0 >> DST_SHIFT;
     fw t;
     if (w0 & F_MUL2) {
@@ -191,9 +193,9 @@ __device__ __forceinline__ void ev_execute(const InterpArgs& a, const Staged& s,
 #pragma unroll
         for (int d = 0; d < 9; d++) lds[((dst - 1) * 9 + d) * EV_THREADS + threadIdx.x] = t.d[d];
     } else {
-        int32_t* base = a.spill + (((size_t)(dst - a.lds_slots) * 9) << a.log_size) + idx;
+        int32_t* base = a.spill + (size_t)(dst - a.lds_slots) * 9 * a.rows + idx;
 #pragma unroll
-        for (int d = 0; d < 9; d++) base[(size_t)d << a.log_size] = t.d[d];
+        for (int d = 0; d < 9; d++) base[(size_t)d * a.rows] = t.d[d];
     }
 }
 
@@ -201,23 +203,24 @@ __global__ void __launch_bounds__(EV_THREADS) evalh_interp_kernel(const uint32_t
     extern __shared__ __align__(16) unsigned char smem[];
     int32_t* lds = reinterpret_cast<int32_t*>(smem);
     const prog_ptr prog = (prog_ptr)prog_generic;
-    const uint32_t idx = blockIdx.x * EV_THREADS + threadIdx.x;
+    const uint32_t local = blockIdx.x * EV_THREADS + threadIdx.x;   // row inside the evaluated window
     const uint32_t mask = (1u << a.log_size) - 1;
-    if (idx > mask) return;   // domains smaller than one workgroup
+    if (local >= a.rows) return;   // windows that are no multiple of a workgroup
+    const uint32_t idx = a.row_first + local;                       // row of the columns
     fw acc = FrW::zero(), reg0 = FrW::zero();
     // instruction pc + 1 is decoded and its column / constant loads are issued right after instruction pc has computed
     Staged st;
     if (a.n_instr) ev_stage(st, prog, idx, mask);
     for (uint32_t pc = 0; pc < a.n_instr; pc++) {
-        ev_execute(a, st, lds, acc, reg0, idx);
+        ev_execute(a, st, lds, acc, reg0, local);
         if (pc + 1 < a.n_instr) ev_stage(st, prog + (size_t)(pc + 1) * INS_WORDS, idx, mask);
     }
     // back to the 2^256 domain, canonical
     Opnd ro;
     ro.hdr = a.result_hdr;
     ro.ptr = nullptr;
-    const fw r = ev_value(a, ro, Fr::zero(), lds, acc, reg0, idx);
-    store_fe(a.out + idx, FrW::to_fe(FrW::mul(r, FrW::r256())));
+    const fw r = ev_value(a, ro, Fr::zero(), lds, acc, reg0, local);
+    store_fe(a.out + local, FrW::to_fe(FrW::mul(r, FrW::r256())));
 }
 
 // x[idx] = zeta * extended_omega^idx: the point of extended row idx
@@ -1068,6 +1071,12 @@ extern "C" int zkhip_evaluate_h(zkhip_domain* dom, const zkhip_evalh_desc* desc,
     uint32_t log_rows = k;
     while ((1u << (log_rows - k)) < cl.num) log_rows++;
     const size_t size = (size_t)1 << log_rows;
+    // Rows evaluated: all `size` rows, or the window [row_first, row_first + row_count) of them (a rank that shares a
+    // coset with other ranks evaluates a contiguous part of its rows; the columns are still whole, so rotations need no
+    // exchange of neighbouring rows).  `out` then holds row_count rows.
+    const size_t row_first = desc->row_count ? desc->row_first : 0;
+    const size_t rows = desc->row_count ? desc->row_count : size;
+    ZK_CHECK(ctx, row_first + rows <= size, "evaluate_h: rows [%zu, %zu) of %zu", row_first, row_first + rows, size);
 
     // ---- the program of this shape: from the context's cache, or built now --------------------------------------
     std::shared_ptr<EvalhProgram> prog;
@@ -1190,7 +1199,7 @@ extern "C" int zkhip_evaluate_h(zkhip_domain* dom, const zkhip_evalh_desc* desc,
         (rc = grow(ctx, d_consts_v, ctx->evalh_buf_bytes[2], std::max<size_t>(32, prog->consts.size() * 8))))
         return rc;
     if (prog->n_slots > prog->lds_slots &&
-        (rc = grow(ctx, d_spill_v, ctx->evalh_buf_bytes[3], (size_t)(prog->n_slots - prog->lds_slots) * size * 36)))
+        (rc = grow(ctx, d_spill_v, ctx->evalh_buf_bytes[3], (size_t)(prog->n_slots - prog->lds_slots) * rows * 36)))
         return rc;
     fe* d_scal = (fe*)d_scal_v;
     fe* d_consts = (fe*)d_consts_v;
@@ -1240,7 +1249,7 @@ extern "C" int zkhip_evaluate_h(zkhip_domain* dom, const zkhip_evalh_desc* desc,
     fe* d_out;
     if (host) {
         void* p;
-        if ((rc = ar.alloc(size * 32, &p))) return rc;
+        if ((rc = ar.alloc(rows * 32, &p))) return rc;
         d_out = (fe*)p;
     } else {
         d_out = (fe*)out;
@@ -1252,6 +1261,8 @@ extern "C" int zkhip_evaluate_h(zkhip_domain* dom, const zkhip_evalh_desc* desc,
     a.lds_slots = prog->lds_slots;
     a.spill = prog->n_slots > prog->lds_slots ? (int32_t*)d_spill_v : nullptr;
     a.log_size = log_rows;
+    a.row_first = (uint32_t)row_first;
+    a.rows = (uint32_t)rows;
     a.out = d_out;
     const size_t lds_bytes = (size_t)(prog->lds_slots > 1 ? prog->lds_slots - 1 : 1) * EV_THREADS * 36;
     if (!ctx->evalh_attr_set) {
@@ -1261,11 +1272,11 @@ extern "C" int zkhip_evaluate_h(zkhip_domain* dom, const zkhip_evalh_desc* desc,
     }
     {
         TimedRegion tr(ctx, "evalh");
-        hipLaunchKernelGGL(evalh_interp_kernel, dim3((unsigned)((size + EV_THREADS - 1) / EV_THREADS)), dim3(EV_THREADS),
+        hipLaunchKernelGGL(evalh_interp_kernel, dim3((unsigned)((rows + EV_THREADS - 1) / EV_THREADS)), dim3(EV_THREADS),
                            lds_bytes, ctx->stream, (const uint32_t*)d_prog_v, a);
         ZK_HIP(ctx, hipGetLastError());
     }
-    if (host) ZK_HIP(ctx, hipMemcpyAsync(out, d_out, size * 32, hipMemcpyDeviceToHost, ctx->stream));
+    if (host) ZK_HIP(ctx, hipMemcpyAsync(out, d_out, rows * 32, hipMemcpyDeviceToHost, ctx->stream));
     // the scalars, the linked program and the spill buffer belong to the context and are rewritten by the next call
     ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return ZKHIP_OK;

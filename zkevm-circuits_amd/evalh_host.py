@@ -38,6 +38,7 @@ class EvalhCall:
         self.lookups = []        # [(product, permuted_input, permuted_table)]
         self.perm_sigma, self.perm_z = [], []
         self.cosets = None       # list of coset indices: evaluate only these, every extended vector in compact layout
+        self.rows = None         # (first, count): evaluate only this window of the rows (columns stay whole)
         self.graph = None        # with basis = BASIS_LAGRANGE: the graph evaluated over the 2^k rows of the circuit
         self.basis = ffi.BASIS_EXTENDED
 
@@ -93,6 +94,8 @@ class EvalhCall:
             cl = np.ascontiguousarray(np.asarray(self.cosets, dtype=np.uint32))
             b.keep.append(cl)
             d.num_cosets, d.cosets = len(cl), C.c_void_p(cl.ctypes.data)
+        if self.rows is not None:
+            d.row_first, d.row_count = self.rows
         self._keep = b
         return d
 

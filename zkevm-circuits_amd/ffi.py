@@ -83,7 +83,8 @@ class EvalhDesc(C.Structure):
                 ("perm_column_index", C.c_void_p), ("perm_sigma_cosets", C.POINTER(C.c_void_p)),
                 ("num_perm_sets", C.c_uint32), ("perm_product_cosets", C.POINTER(C.c_void_p)),
                 ("perm_chunk_len", C.c_uint32), ("blinding_factors", C.c_uint32),
-                ("num_cosets", C.c_uint32), ("cosets", C.c_void_p), ("basis", C.c_uint32)]
+                ("num_cosets", C.c_uint32), ("cosets", C.c_void_p), ("basis", C.c_uint32),
+                ("row_first", C.c_uint32), ("row_count", C.c_uint32)]
 
 
 MEM_HOST, MEM_DEVICE = 0, 1
@@ -144,6 +145,10 @@ class Context:
                              "(there is no CPU fallback)")
         self.h = h
         self.device = device
+        # bytes handed out by alloc() and not yet freed, and their high-water mark: what a rank keeps resident
+        self._sizes = {}
+        self.allocated_bytes = 0
+        self.peak_allocated_bytes = 0
 
     def close(self):
         if getattr(self, "h", None):
@@ -170,10 +175,17 @@ class Context:
     def alloc(self, nbytes: int) -> int:
         d = C.c_void_p()
         self._ck(self._l.zkhip_dev_alloc(self.h, C.c_size_t(nbytes), C.byref(d)))
+        self._sizes[d.value] = nbytes
+        self.allocated_bytes += nbytes
+        self.peak_allocated_bytes = max(self.peak_allocated_bytes, self.allocated_bytes)
         return d.value
 
     def free(self, dptr: int):
         self._ck(self._l.zkhip_dev_free(self.h, C.c_void_p(dptr)))
+        self.allocated_bytes -= self._sizes.pop(dptr, 0)
+
+    def reset_peak(self):
+        self.peak_allocated_bytes = self.allocated_bytes
 
     def upload(self, arr, dptr: int | None = None) -> int:
         arr = u64(arr)
@@ -481,6 +493,7 @@ class Domain:
         """`Evaluator::evaluate_h`.  Host descriptor -> numpy result; device descriptor -> writes out_dev."""
         if desc.mem == MEM_HOST:
             rows = self.n if desc.basis else (self.n * desc.num_cosets if desc.num_cosets else self.extended_len)
+            rows = desc.row_count or rows
             out = np.empty((rows, 4), dtype=np.uint64)
             self.ctx._ck(self._l.zkhip_evaluate_h(self.h, C.byref(desc), _p(out)))
             return out

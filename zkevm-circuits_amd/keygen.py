@@ -64,25 +64,36 @@ class ProvingKeyPolys:
         self.fixed_polys, self.fixed_cosets = [], []
         self.permutations, self.permutation_polys, self.permutation_cosets = [], [], []
         self.l0 = self.l_last = self.l_active_row = 0
+        self.cosets = None     # None: the "coset" vectors are whole extended vectors; a list: compact layout of these cosets
 
     def pointers(self):
         return (self.fixed_polys + self.fixed_cosets + self.permutations + self.permutation_polys + self.permutation_cosets
                 + [self.l0, self.l_last, self.l_active_row])
 
 
-def keygen_polys(ctx, dom, fixed_values, assembly: Assembly | None, blinding_factors: int) -> ProvingKeyPolys:
+def keygen_polys(ctx, dom, fixed_values, assembly: Assembly | None, blinding_factors: int, cosets=None) -> ProvingKeyPolys:
     """fixed_values: list of (n, 4) Montgomery arrays (Lagrange basis).  Returns device-resident key polynomials; the
-    caller frees `pointers()`."""
+    caller frees `pointers()`.  cosets: a rank of a multi-GPU prover that evaluates only these cosets of the extended
+    domain keeps the key's extended vectors (fixed_cosets, permutation_cosets, l0, l_last, l_active_row) in the compact
+    layout of those cosets -- n * len(cosets) rows, straight from the coefficients, never forming the whole vector."""
     n, en = dom.n, dom.extended_len
     pk = ProvingKeyPolys()
+    pk.cosets = list(cosets) if cosets is not None else None
+
+    def extend(d_poly):
+        if pk.cosets is None:
+            d_coset = ctx.alloc(en * 32)
+            dom.coeff_to_extended_dev(d_poly, d_coset)
+        else:
+            d_coset = ctx.alloc(n * len(pk.cosets) * 32)
+            dom.coeff_to_cosets_dev(d_poly, pk.cosets, d_coset)
+        return d_coset
 
     def to_coeff_and_coset(d_lagrange):
         d_poly = ctx.alloc(n * 32)
         ctx.poly_lincomb_dev([d_lagrange], [n], np.array([fr_to_mont_limbs(1)], dtype=np.uint64), n, d_poly)   # copy
         dom.lagrange_to_coeff_dev(d_poly)
-        d_coset = ctx.alloc(en * 32)
-        dom.coeff_to_extended_dev(d_poly, d_coset)
-        return d_poly, d_coset
+        return d_poly, extend(d_poly)
 
     # fixed columns: fixed_polys = lagrange_to_coeff(fixed_values), fixed_cosets = coeff_to_extended(fixed_polys)
     for col in fixed_values:
@@ -125,9 +136,7 @@ def keygen_polys(ctx, dom, fixed_values, assembly: Assembly | None, blinding_fac
     ctx.poly_lincomb_dev([d_one, d_ind[1], d_ind[2]], [1, n, n], np.array([one, minus_one, minus_one], dtype=np.uint64), n, d_act)
     outs = []
     for d in (d_ind[0], d_ind[1], d_act):
-        d_c = ctx.alloc(en * 32)
-        dom.coeff_to_extended_dev(d, d_c)
-        outs.append(d_c)
+        outs.append(extend(d))
     ctx.sync()
     for d in d_ind + [d_one, d_act]:
         ctx.free(d)

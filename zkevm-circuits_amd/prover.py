@@ -209,8 +209,11 @@ class ProvingKey:
         return self.polys.pointers() + self.fixed_values
 
 
-def keygen(ctx, dom, params: ParamsKZG, cs: ConstraintSystem, fixed, assembly) -> ProvingKey:
-    """`keygen_vk` + `keygen_pk` for assigned fixed columns (lists of n canonical integers) and copy constraints."""
+def keygen(ctx, dom, params: ParamsKZG, cs: ConstraintSystem, fixed, assembly, dist=None) -> ProvingKey:
+    """`keygen_vk` + `keygen_pk` for assigned fixed columns (lists of n canonical integers) and copy constraints.
+    dist: an initialised torch.distributed module with one rank per GPU; every rank then keeps the key's extended vectors
+    only on the cosets it evaluates in `create_proof(..., dist=dist)` (1 / world of them up to 2^e ranks), and such a key
+    proves only with the same process group."""
     n = dom.n
     if n < cs.minimum_rows():
         raise ValueError("not enough rows available")
@@ -221,7 +224,11 @@ def keygen(ctx, dom, params: ParamsKZG, cs: ConstraintSystem, fixed, assembly) -
     pk.ev = Evaluator(cs)
     evalh_host.prepare(dom, cs, pk.ev)       # the device program of evaluate_h, built once per key like `pk.ev`
     fixed_limbs = [fr_limbs(c) for c in fixed]
-    pk.polys = kg.keygen_polys(ctx, dom, fixed_limbs, assembly if cs.permutation_columns else None, cs.blinding_factors())
+    own = None
+    if dist is not None and dist.is_initialized() and dist.get_world_size() > 1:
+        part = sharding.coset_partition(dom.extended_k, dom.k, dist.get_world_size())[dist.get_rank()]
+        own = part[0] if part is not None else []
+    pk.polys = kg.keygen_polys(ctx, dom, fixed_limbs, assembly if cs.permutation_columns else None, cs.blinding_factors(), own)
     pk.fixed_values = [ctx.upload(a) for a in fixed_limbs]
     if pk.fixed_values:
         pk.fixed_commitments = [affine_ints(j) for j in params.commit_lagrange(pk.fixed_values)]
@@ -408,6 +415,8 @@ def create_proof(ctx, dom, params: ParamsKZG, pk: ProvingKey, advice, instance, 
             call.perm_z = [of_poly(p) for p in perm_z]
 
         if not sharded:
+            if pk.polys.cosets is not None:
+                raise ValueError("the proving key was generated for a multi-GPU partition (keygen(..., dist=...))")
             ext_block = alloc(en * max(total, 1))
             for s0 in range(0, total, BATCH):
                 dom.coeff_to_extended_dev(slot[s0], ext_block + s0 * en * 32, min(BATCH, total - s0))
@@ -417,8 +426,9 @@ def create_proof(ctx, dom, params: ParamsKZG, pk: ProvingKey, advice, instance, 
         else:
             import torch
 
-            def evaluate(cosets):
-                """this rank's cosets of the numerator, every column in the compact layout of those cosets"""
+            def evaluate(cosets, row_first, row_count):
+                """this rank's rows of the numerator: every column in the compact layout of its cosets, of which the rows
+                [row_first, row_first + row_count) are evaluated"""
                 if not cosets:
                     return torch.empty((0, 4), dtype=torch.int64, device="cuda")
                 rows = n * len(cosets)
@@ -429,19 +439,24 @@ def create_proof(ctx, dom, params: ParamsKZG, pk: ProvingKey, advice, instance, 
                     return d
 
                 def of_key(p):
+                    if pk.polys.cosets is not None:          # the key was generated for this partition: compact already
+                        if pk.polys.cosets != list(cosets):
+                            raise ValueError("the proving key holds other cosets than this rank evaluates")
+                        return p
                     d = alloc(rows)
                     dom.extended_to_cosets_dev(p, cosets, d)
                     return d
                 fill(of_poly, of_key)
                 call.cosets = cosets
-                out = torch.empty((rows, 4), dtype=torch.int64, device="cuda")
+                call.rows = (row_first, row_count) if row_count != rows else None
+                out = torch.empty((row_count, 4), dtype=torch.int64, device="cuda")
                 torch.cuda.synchronize()
                 dom.evaluate_h(call.build(ffi.MEM_DEVICE, ffi.FORM_EXTENDED), out.data_ptr())
                 ctx.sync()
                 return out
             pieces = sharding.evaluate_h_by_cosets(dom.extended_k, dom.k, evaluate, dist)
             torch.cuda.synchronize()
-            for cosets, rows in pieces:
+            for cosets, rows in sharding.assemble_cosets(pieces, dom.k):
                 dom.cosets_to_extended_dev(rows.data_ptr(), cosets, d_h)
             ctx.sync()
         mark("quotient_pieces")

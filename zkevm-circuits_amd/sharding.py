@@ -79,29 +79,85 @@ def msm_base_split(n: int, msm_range, fold, dist=None, device=None):
     return fold(parts)
 
 
+def coset_partition(extended_k: int, k: int, world: int):
+    """How `world` ranks share the 2^e cosets of the extended domain (e = extended_k - k), per rank
+    (cosets, row_first, row_count) or None for a rank that owns nothing:
+      * the owners are the first 2^floor(log2 world) ranks (whole cosets only split evenly over a power of two);
+      * up to 2^e owners: owner r holds the cosets r, r + owners, ... whole (row_first 0, all rows of its compact layout);
+      * more owners than cosets: owner r holds coset r mod 2^e and evaluates the rows [part * 2^k / s, (part + 1) * 2^k / s)
+        of it, part = r div 2^e, s = owners / 2^e.  The owner still holds the whole coset of every column (a rotation by r
+        rows of the circuit moves r rows inside the coset), so no neighbouring rows are exchanged.
+    Every owner's piece has 2^extended_k / owners rows."""
+    if world < 1:
+        raise ValueError("world size must be positive")
+    e = extended_k - k
+    m, n = 1 << e, 1 << k
+    owners = 1 << (world.bit_length() - 1)
+    owners = min(owners, m * max(1, n // 256))              # pieces of at least one workgroup of rows
+    out = []
+    for r in range(world):
+        if r >= owners:
+            out.append(None)
+        elif owners <= m:
+            cosets = list(range(r, m, owners))
+            out.append((cosets, 0, n * len(cosets)))
+        else:
+            s = owners // m
+            out.append(([r % m], (r // m) * (n // s), n // s))
+    return out
+
+
 def evaluate_h_by_cosets(extended_k: int, k: int, evaluate, dist=None):
-    """evaluate_h split by coset.  evaluate(cosets) -> torch tensor (2^k * len(cosets), 4) int64: the compact rows of
-    h on the listed cosets (compact row q * len(cosets) + s = extended row q * 2^e + cosets[s]), on the device the
-    process group communicates on.  Returns [(cosets of rank r, its rows)] for every rank that owns cosets, on every
-    rank: one all-gather of the pieces of h (2^extended_k x 32 bytes in total), the only exchange this phase needs.
-    With more ranks than cosets the surplus ranks own nothing (splitting a coset further by row ranges would need the
-    rotation halos this partition exists to avoid)."""
+    """evaluate_h split by coset (and, with more ranks than cosets, by row ranges inside a coset: `coset_partition`).
+    evaluate(cosets, row_first, row_count) -> torch tensor (row_count, 4) int64: the rows [row_first, row_first +
+    row_count) of h in the compact layout of the listed cosets (compact row q * len(cosets) + s = extended row
+    q * 2^e + cosets[s]), on the device the process group communicates on.  Returns, on every rank,
+    [(cosets, row_first, rows tensor)] for every owner: one all-gather of the pieces of h (2^extended_k x 32 bytes in
+    total), the only exchange this phase needs.  Ranks beyond the largest power of two own nothing and only take part in
+    the collective."""
     e = extended_k - k
     if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
         cosets = list(range(1 << e))
-        return [(cosets, evaluate(cosets))]
+        return [(cosets, 0, evaluate(cosets, 0, (1 << k) * len(cosets)))]
     import torch
     rank, world = dist.get_rank(), dist.get_world_size()
-    owners = min(world, 1 << e)
-    mine = cosets_for_rank(extended_k, k, rank, owners) if rank < owners else []
-    per = (1 << e) // owners
-    rows = (1 << k) * per
-    if mine:
-        piece = evaluate(mine)
-        assert tuple(piece.shape) == (rows, 4), (tuple(piece.shape), rows)
+    parts = coset_partition(extended_k, k, world)
+    rows = next(p[2] for p in parts if p is not None)
+    if any(p is not None and p[2] != rows for p in parts):
+        raise ValueError("coset partition with unequal pieces")      # same on every rank, before any collective
+    mine = parts[rank]
+    if mine is not None:
+        piece = evaluate(*mine)
+        if tuple(piece.shape) != (rows, 4):
+            raise ValueError(f"evaluate returned {tuple(piece.shape)}, expected {(rows, 4)}")
     else:
-        ref = evaluate([])            # an empty tensor on the right device, for the collective's shape
+        ref = evaluate([], 0, 0)          # an empty tensor on the right device, for the collective's shape
         piece = torch.zeros((rows, 4), dtype=torch.int64, device=ref.device)
     gathered = [torch.empty_like(piece) for _ in range(world)]
     dist.all_gather(gathered, piece.contiguous())
-    return [(cosets_for_rank(extended_k, k, r, owners), gathered[r]) for r in range(owners)]
+    return [(p[0], p[1], gathered[r]) for r, p in enumerate(parts) if p is not None]
+
+
+def assemble_cosets(pieces, k: int):
+    """[(cosets, row_first, rows)] of evaluate_h_by_cosets -> [(cosets, rows of all 2^k * len(cosets) compact rows)]:
+    the row ranges of a shared coset concatenated in order"""
+    import torch
+    n = 1 << k
+    by_cosets = {}
+    for cosets, first, rows in pieces:
+        by_cosets.setdefault(tuple(cosets), []).append((first, rows))
+    out = []
+    for cosets, parts in by_cosets.items():
+        parts.sort(key=lambda t: t[0])
+        if len(parts) == 1 and parts[0][1].shape[0] == n * len(cosets):
+            out.append((list(cosets), parts[0][1]))
+            continue
+        at = 0
+        for first, rows in parts:
+            if first != at:
+                raise ValueError("row ranges of a coset do not tile it")
+            at += rows.shape[0]
+        if at != n * len(cosets):
+            raise ValueError("row ranges of a coset do not cover it")
+        out.append((list(cosets), torch.cat([rows for _, rows in parts])))
+    return out
