@@ -52,6 +52,9 @@ int zkhip_set_stream(zkhip_ctx* ctx, void* hip_stream);
 int zkhip_sync(zkhip_ctx* ctx);
 int zkhip_dev_alloc(zkhip_ctx* ctx, size_t bytes, void** dptr);
 int zkhip_dev_free(zkhip_ctx* ctx, void* dptr);
+/* free and total device memory of the context's GPU: callers size their batches of resident cosets with it (no reference
+ * counterpart; the reference's runtime is given a fixed budget, benches/benchmark_list/main.rs:300-303). */
+int zkhip_mem_info(zkhip_ctx* ctx, size_t* free_bytes, size_t* total_bytes);
 int zkhip_upload(zkhip_ctx* ctx, void* dptr, const void* host, size_t bytes);
 int zkhip_download(zkhip_ctx* ctx, void* host, const void* dptr, size_t bytes);
 

@@ -114,6 +114,71 @@ def test_polynomial_raw_records():
         formats.read_polynomial_raw(g)
 
 
+def _points(rng, count):
+    """affine points as raw Montgomery limbs (multiples of the generator by the big-int model)"""
+    q = bn.FQ_MODULUS
+    pts = [bn.g1_mul(bn.G1_GENERATOR, rng.randrange(1, 1 << 40)) for _ in range(count)]
+    return np.array([[((c << 256) % q >> (64 * i)) & (2**64 - 1) for c in pt for i in range(4)] for pt in pts],
+                    dtype="<u8").reshape(count, 8)
+
+
+@pytest.mark.parametrize("layout", ["v3", "legacy"])
+def test_verifying_and_proving_key_raw_bytes(tmp_path, layout):
+    """`VerifyingKey::write` / `ProvingKey::write` in RawBytes (unpinned: restated layouts of the absent halo2 fork): byte
+    layout of the header, packed selector bits, round trip, the reader telling the two header layouts apart, and the
+    errors (truncation, trailing bytes, wrong column count, a coordinate that is no residue)"""
+    rng = random.Random(11)
+    k, ek = 4, 6
+    n, en = 1 << k, 1 << ek
+    sel = [np.array([rng.random() < 0.5 for _ in range(n)]) for _ in range(2)]
+    vk = formats.VerifyingKeyRaw(k, _points(rng, 3), _points(rng, 2), sel, True)
+    f = io.BytesIO()
+    formats.write_verifying_key_raw(f, vk, layout)
+    raw = f.getvalue()
+    head = 7 if layout == "v3" else 8
+    assert raw[:head] == (bytes([3, k, 1]) + struct.pack("<I", 3) if layout == "v3" else struct.pack(">II", k, 3))
+    assert len(raw) == head + 5 * 64 + 2 * (n // 8)
+    assert raw[head:head + 64] == vk.fixed_commitments[0].tobytes()
+    assert raw[-2] == sum(int(b) << i for i, b in enumerate(sel[1][:8]))          # least significant bit first
+    back = formats.read_verifying_key_raw(io.BytesIO(raw), 2, 2)
+    assert back.k == k and np.array_equal(back.fixed_commitments, vk.fixed_commitments)
+    assert np.array_equal(back.permutation_commitments, vk.permutation_commitments)
+    assert all(np.array_equal(a, b) for a, b in zip(back.selectors, sel)) and back.compress_selectors
+    with pytest.raises(formats.FormatError):
+        formats.read_verifying_key_raw(io.BytesIO(raw[:-1]), 2, 2)
+    with pytest.raises(formats.FormatError):
+        formats.read_verifying_key_raw(io.BytesIO(raw), 9, 2)                    # more permutation columns than stored
+    with pytest.raises(formats.FormatError):
+        formats.read_verifying_key_raw(io.BytesIO(b"\x07" + raw[1:]), 2, 2)      # unknown version byte
+    bad = bytearray(raw)
+    bad[head:head + 32] = b"\xff" * 32                                            # x coordinate beyond the modulus
+    with pytest.raises(formats.FormatError):
+        formats.read_verifying_key_raw(io.BytesIO(bytes(bad)), 2, 2)
+
+    poly = lambda length: _mont_rows([rng.randrange(P) for _ in range(length)])
+    pk = formats.ProvingKeyRaw(vk, l0=poly(en), l_last=poly(en), l_active_row=poly(en),
+                               fixed_values=[poly(n) for _ in range(3)], fixed_polys=[poly(n) for _ in range(3)],
+                               fixed_cosets=[poly(en) for _ in range(3)], permutations=[poly(n) for _ in range(2)],
+                               permutation_polys=[poly(n) for _ in range(2)], permutation_cosets=[poly(en) for _ in range(2)])
+    pk.check(ek)
+    path = str(tmp_path / "k4.pk")
+    formats.write_proving_key_raw(path, pk, layout)
+    size = len(raw) + 3 * (4 + en * 32) + 4 * 6 + 3 * 2 * (4 + n * 32) + 3 * (4 + en * 32) + 2 * 2 * (4 + n * 32) + 2 * (4 + en * 32)
+    assert (tmp_path / "k4.pk").stat().st_size == size
+    got = formats.read_proving_key_raw(path, 2, 2)
+    got.check(ek)
+    for name in formats.ProvingKeyRaw.SINGLE:
+        assert np.array_equal(getattr(got, name), getattr(pk, name))
+    for name in formats.ProvingKeyRaw.SLICES:
+        assert all(np.array_equal(a, b) for a, b in zip(getattr(got, name), getattr(pk, name)))
+    with pytest.raises(formats.FormatError):
+        got.check(ek + 1)
+    with open(path, "ab") as g:
+        g.write(b"\x00")
+    with pytest.raises(formats.FormatError):
+        formats.read_proving_key_raw(path, 2, 2)
+
+
 def _scrape(lines, tag):
     """What scripts/report_system_data/report_bench.py:57-75 does with an End line: collapse runs of equal characters,
     keep what follows the first dot."""

@@ -66,6 +66,48 @@ def test_prover_reproduces_the_golden_proof(ctx, setup):
     assert _prove(ctx, setup, advice, instance, seed=gold["rng_seed"]).hex() == gold["proof"]
 
 
+def test_proving_key_file_round_trip(ctx, setup, tmp_path):
+    """the key written as `ProvingKey::write(RawBytes)` and read back (both header layouts) proves to the same bytes, and
+    its file has the size the layout predicts"""
+    import os
+    k, cs, dom, params, pk, vk, advice, instance = setup
+    proof = _prove(ctx, setup, advice, instance)
+    F, Pc, n, en = cs.num_fixed_columns, len(cs.permutation_columns), dom.n, dom.extended_len
+    for layout, head in (("v3", 7), ("legacy", 8)):
+        path = str(tmp_path / f"k{k}_{layout}.pk")
+        prover.save_proving_key(ctx, dom, pk, path, layout)
+        assert os.path.getsize(path) == (head + (F + Pc) * 64 + 3 * (4 + en * 32) + 6 * 4
+                                         + (F + Pc) * (2 * (4 + n * 32) + 4 + en * 32))
+        pk2 = prover.load_proving_key(ctx, dom, cs, path)
+        assert pk2.fixed_commitments == pk.fixed_commitments and pk2.transcript_repr == pk.transcript_repr
+        got = prover.create_proof(ctx, dom, params, pk2, advice, instance, prover.FieldRng(1), prover.Blake2bWrite())
+        assert got == proof
+        for p in pk2.pointers():
+            ctx.free(p)
+    with pytest.raises(ValueError):
+        other = zk.Domain(ctx, cs.degree(), k + 1)
+        try:
+            prover.load_proving_key(ctx, other, cs, path)
+        finally:
+            other.close()
+
+
+def test_bounded_footprint_gives_the_same_proof(ctx, setup):
+    """the quotient numerator evaluated coset group by coset group (what a GPU with less free memory than all extended
+    cosets need does) gives the same bytes as all cosets at once; the OS-entropy RNG gives a verifying proof"""
+    k, cs, dom, params, pk, vk, advice, instance = setup
+    proof = _prove(ctx, setup, advice, instance)
+    for groups in (2, 4):
+        got = prover.create_proof(ctx, dom, params, pk, advice, instance, prover.FieldRng(1), prover.Blake2bWrite(),
+                                  coset_groups=groups)
+        assert got == proof, groups
+    with pytest.raises(ValueError):
+        prover.create_proof(ctx, dom, params, pk, advice, instance, prover.FieldRng(1), prover.Blake2bWrite(), coset_groups=3)
+    fresh = prover.create_proof(ctx, dom, params, pk, advice, instance, prover.OsFieldRng(), prover.Blake2bWrite())
+    assert fresh != proof
+    vm.verify_proof(cs, k, vk, instance, fresh, TAU)
+
+
 def test_verifier_rejects_what_it_must(ctx, setup):
     k, cs, dom, params, pk, vk, advice, instance = setup
     proof = _prove(ctx, setup, advice, instance)

@@ -174,6 +174,12 @@ int zkhip_dev_free(zkhip_ctx* ctx, void* dptr) {
     ZK_HIP(ctx, hipFree(dptr));
     return ZKHIP_OK;
 }
+int zkhip_mem_info(zkhip_ctx* ctx, size_t* free_bytes, size_t* total_bytes) {
+    if (!ctx || !free_bytes || !total_bytes) return ZKHIP_ERR_INVALID;
+    ZK_HIP(ctx, hipSetDevice(ctx->device));
+    ZK_HIP(ctx, hipMemGetInfo(free_bytes, total_bytes));
+    return ZKHIP_OK;
+}
 int zkhip_upload(zkhip_ctx* ctx, void* dptr, const void* host, size_t bytes) {
     if (!ctx || (!dptr && bytes) || (!host && bytes)) return ZKHIP_ERR_INVALID;
     ZK_HIP(ctx, hipMemcpyAsync(dptr, host, bytes, hipMemcpyHostToDevice, ctx->stream));

@@ -539,6 +539,7 @@ int zkhip_permutation_product_dev(zkhip_domain* dom, const uint64_t* const* d_va
     const fe** d_ptrs = (const fe**)(d_totals + nblocks + 1);
     ZK_HIP(ctx, hipMemcpyAsync(d_ptrs, d_values, num_cols * sizeof(void*), hipMemcpyHostToDevice, ctx->stream));
     ZK_HIP(ctx, hipMemcpyAsync(d_ptrs + num_cols, d_sigmas, num_cols * sizeof(void*), hipMemcpyHostToDevice, ctx->stream));
+    ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));   // the tables are the caller's pageable host memory, free to die on return
     PermArgs a;
     a.values = d_ptrs;
     a.sigmas = d_ptrs + num_cols;

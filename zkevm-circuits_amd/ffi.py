@@ -16,7 +16,7 @@ _LIB = None
 
 EXPORTS = [
     "zkhip_create", "zkhip_destroy", "zkhip_last_error", "zkhip_version", "zkhip_set_stream", "zkhip_sync",
-    "zkhip_dev_alloc", "zkhip_dev_free", "zkhip_upload", "zkhip_download",
+    "zkhip_dev_alloc", "zkhip_dev_free", "zkhip_mem_info", "zkhip_upload", "zkhip_download",
     "zkhip_field_binop", "zkhip_field_batch_invert", "zkhip_g1_add_affine", "zkhip_g1_multiples", "zkhip_probe_mad_rate",
     "zkhip_register_bases", "zkhip_release_bases", "zkhip_msm", "zkhip_msm_batch_dev", "zkhip_msm_range_dev",
     "zkhip_g1_sum_jacobian", "zkhip_g1_to_affine", "zkhip_g1_fft",
@@ -183,6 +183,12 @@ class Context:
     def free(self, dptr: int):
         self._ck(self._l.zkhip_dev_free(self.h, C.c_void_p(dptr)))
         self.allocated_bytes -= self._sizes.pop(dptr, 0)
+
+    def mem_info(self):
+        """(free, total) bytes of device memory"""
+        free, total = C.c_size_t(), C.c_size_t()
+        self._ck(self._l.zkhip_mem_info(self.h, C.byref(free), C.byref(total)))
+        return free.value, total.value
 
     def reset_peak(self):
         self.peak_allocated_bytes = self.allocated_bytes

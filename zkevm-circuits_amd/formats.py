@@ -23,6 +23,7 @@ import numpy as np
 
 from .plonk import FR_MODULUS
 
+FQ_MODULUS = 0x30644E72E131A029B85045B68181585D97816A916871CA8D3C208C16D87CFD47
 _R_INV = pow(1 << 256, -1, FR_MODULUS)
 G1_RAW = 64     # x | y, four u64 limbs each
 G2_RAW = 128    # x.c0 | x.c1 | y.c0 | y.c1
@@ -122,8 +123,8 @@ def read_polynomial_raw(f, max_len: int = 1 << 30) -> np.ndarray:
     return a
 
 
-def _all_below_modulus(a: np.ndarray) -> bool:
-    p = [(FR_MODULUS >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for i in range(4)]
+def _all_below_modulus(a: np.ndarray, modulus: int = FR_MODULUS) -> bool:
+    p = [(modulus >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for i in range(4)]
     lt = np.zeros(a.shape[0], dtype=bool)
     eq = np.ones(a.shape[0], dtype=bool)
     for i in (3, 2, 1, 0):
@@ -131,6 +132,161 @@ def _all_below_modulus(a: np.ndarray) -> bool:
         lt |= eq & (limb < np.uint64(p[i]))
         eq &= limb == np.uint64(p[i])
     return bool(lt.all())
+
+
+# ---- VerifyingKey / ProvingKey, SerdeFormat::RawBytes -----------------------------------------------------------------
+# The key files the reference's harness caches next to the parameters (benches/benchmark_list/main.rs:448-461 write them,
+# :463-501 read them back; prover/src/util.rs:48-57 for the verifying key alone).  The byte layouts belong to the halo2 fork,
+# whose source is absent: both layouts that releases of halo2_proofs 0.3.0 have used are implemented, the reader tells them
+# apart by their first byte, and both are *unpinned* (no key file written by the reference exists to check them against):
+#   "v3"     version byte 0x03, k as one byte, compress_selectors as one byte, number of fixed commitments u32 LE
+#   "legacy" k u32 BE, number of fixed commitments u32 BE
+# then, in both: the fixed commitments, the permutation commitments (their number comes from the constraint system, not
+# from the file), and every selector's 2^k assignment bits packed eight to a byte, least significant bit first (none
+# when selectors were not compressed into fixed columns).  As upstream, the constraint system itself is not stored: the
+# reader is told how many permutation columns and selectors the circuit's `configure` produces.
+# A proving key is its verifying key followed by l0, l_last, l_active_row (extended domain), fixed_values (Lagrange),
+# fixed_polys (coefficients), fixed_cosets (extended), and the permutation argument's permutations, polys, cosets; the
+# three single polynomials as polynomial records, the six lists as u32 BE count + records.
+VK_VERSION = 0x03
+
+
+class VerifyingKeyRaw:
+    def __init__(self, k, fixed_commitments, permutation_commitments, selectors=(), compress_selectors=True):
+        self.k = int(k)
+        self.fixed_commitments = np.asarray(fixed_commitments, dtype="<u8").reshape(-1, 8)
+        self.permutation_commitments = np.asarray(permutation_commitments, dtype="<u8").reshape(-1, 8)
+        self.selectors = [np.asarray(sel, dtype=bool) for sel in selectors]
+        self.compress_selectors = bool(compress_selectors)
+        for sel in self.selectors:
+            if sel.shape != (1 << self.k,):
+                raise FormatError("verifying key: a selector holds one bit per row")
+        if self.selectors and not self.compress_selectors:
+            raise FormatError("verifying key: selectors are stored only when they were compressed")
+
+
+def write_verifying_key_raw(f, vk: VerifyingKeyRaw, layout: str = "v3") -> None:
+    if layout == "v3":
+        if vk.k > 255:
+            raise FormatError("verifying key: k does not fit one byte")
+        f.write(bytes([VK_VERSION, vk.k, 1 if vk.compress_selectors else 0]))
+        f.write(struct.pack("<I", len(vk.fixed_commitments)))
+    elif layout == "legacy":
+        f.write(struct.pack(">I", vk.k))
+        f.write(struct.pack(">I", len(vk.fixed_commitments)))
+    else:
+        raise FormatError(f"verifying key: unknown layout {layout!r}")
+    f.write(np.ascontiguousarray(vk.fixed_commitments, dtype="<u8").tobytes())
+    f.write(np.ascontiguousarray(vk.permutation_commitments, dtype="<u8").tobytes())
+    for sel in vk.selectors:
+        f.write(np.packbits(sel, bitorder="little").tobytes())
+
+
+def _read_exact(f, n: int, what: str) -> bytes:
+    b = f.read(n)
+    if len(b) != n:
+        raise FormatError(f"{what}: truncated")
+    return b
+
+
+def _read_points(f, count: int, what: str) -> np.ndarray:
+    pts = np.frombuffer(_read_exact(f, count * G1_RAW, what), dtype="<u8").reshape(count, 8)
+    for half in (pts[:, :4], pts[:, 4:]):
+        if count and not _all_below_modulus(half, FQ_MODULUS):
+            raise FormatError(f"{what}: coordinate not below the base-field modulus")
+    return pts
+
+
+def read_verifying_key_raw(f, num_permutation_columns: int, num_selectors: int = 0, max_k: int = 28) -> VerifyingKeyRaw:
+    """num_permutation_columns / num_selectors: what the circuit's constraint system has (upstream re-runs `configure`)."""
+    first = _read_exact(f, 1, "verifying key")
+    if first[0] == VK_VERSION:
+        k, compress = _read_exact(f, 2, "verifying key")
+        if compress > 1:
+            raise FormatError("verifying key: compress_selectors is not a boolean")
+        (nfixed,) = struct.unpack("<I", _read_exact(f, 4, "verifying key"))
+    elif first[0] == 0:
+        (k,) = struct.unpack(">I", first + _read_exact(f, 3, "verifying key"))
+        (nfixed,) = struct.unpack(">I", _read_exact(f, 4, "verifying key"))
+        compress = 1
+    else:
+        raise FormatError(f"verifying key: unknown version byte {first[0]:#x}")
+    if k > max_k:
+        raise FormatError(f"verifying key: k = {k} is beyond {max_k}")
+    if nfixed > 1 << 20:
+        raise FormatError("verifying key: implausible number of fixed commitments")
+    fixed = _read_points(f, nfixed, "verifying key")
+    perm = _read_points(f, num_permutation_columns, "verifying key")
+    selectors = []
+    if compress:
+        nbytes = ((1 << k) + 7) // 8
+        for _ in range(num_selectors):
+            bits = np.unpackbits(np.frombuffer(_read_exact(f, nbytes, "verifying key"), dtype=np.uint8), bitorder="little")
+            selectors.append(bits[: 1 << k].astype(bool))
+    return VerifyingKeyRaw(k, fixed, perm, selectors, bool(compress))
+
+
+def write_polynomial_slice_raw(f, polys) -> None:
+    f.write(struct.pack(">I", len(polys)))
+    for poly in polys:
+        write_polynomial_raw(f, poly)
+
+
+def read_polynomial_slice_raw(f, max_polys: int = 1 << 16, max_len: int = 1 << 30):
+    (count,) = struct.unpack(">I", _read_exact(f, 4, "polynomial slice"))
+    if count > max_polys:
+        raise FormatError(f"polynomial slice: {count} polynomials is beyond {max_polys}")
+    return [read_polynomial_raw(f, max_len) for _ in range(count)]
+
+
+class ProvingKeyRaw:
+    """Host arrays ((len, 4) uint64 Montgomery limbs) of everything `ProvingKey::write` stores."""
+    SINGLE = ("l0", "l_last", "l_active_row")
+    SLICES = ("fixed_values", "fixed_polys", "fixed_cosets", "permutations", "permutation_polys", "permutation_cosets")
+
+    def __init__(self, vk: VerifyingKeyRaw, **polys):
+        self.vk = vk
+        for name in self.SINGLE:
+            setattr(self, name, np.asarray(polys[name], dtype="<u8").reshape(-1, 4))
+        for name in self.SLICES:
+            setattr(self, name, [np.asarray(a, dtype="<u8").reshape(-1, 4) for a in polys[name]])
+
+    def check(self, extended_k: int) -> None:
+        n, en = 1 << self.vk.k, 1 << extended_k
+        want = {"l0": en, "l_last": en, "l_active_row": en, "fixed_values": n, "fixed_polys": n, "fixed_cosets": en,
+                "permutations": n, "permutation_polys": n, "permutation_cosets": en}
+        for name in self.SINGLE:
+            if len(getattr(self, name)) != want[name]:
+                raise FormatError(f"proving key: {name} has {len(getattr(self, name))} elements, the domain needs {want[name]}")
+        for name in self.SLICES:
+            for a in getattr(self, name):
+                if len(a) != want[name]:
+                    raise FormatError(f"proving key: a polynomial of {name} has {len(a)} elements, the domain needs {want[name]}")
+        if not (len(self.fixed_values) == len(self.fixed_polys) == len(self.fixed_cosets) == len(self.vk.fixed_commitments)):
+            raise FormatError("proving key: fixed column lists differ in length")
+        if not (len(self.permutations) == len(self.permutation_polys) == len(self.permutation_cosets)
+                == len(self.vk.permutation_commitments)):
+            raise FormatError("proving key: permutation lists differ in length")
+
+
+def write_proving_key_raw(path: str, pk: ProvingKeyRaw, layout: str = "v3") -> None:
+    with open(path, "wb") as f:
+        write_verifying_key_raw(f, pk.vk, layout)
+        for name in ProvingKeyRaw.SINGLE:
+            write_polynomial_raw(f, getattr(pk, name))
+        for name in ProvingKeyRaw.SLICES:
+            write_polynomial_slice_raw(f, getattr(pk, name))
+
+
+def read_proving_key_raw(path: str, num_permutation_columns: int, num_selectors: int = 0) -> ProvingKeyRaw:
+    with open(path, "rb") as f:
+        vk = read_verifying_key_raw(f, num_permutation_columns, num_selectors)
+        polys = {name: read_polynomial_raw(f) for name in ProvingKeyRaw.SINGLE}
+        for name in ProvingKeyRaw.SLICES:
+            polys[name] = read_polynomial_slice_raw(f)
+        if f.read(1):
+            raise FormatError("proving key: trailing bytes")
+    return ProvingKeyRaw(vk, **polys)
 
 
 # ---- instances and the proof JSON -------------------------------------------------------------------------------------

@@ -128,6 +128,28 @@ class FieldRng:
         return a
 
 
+class OsFieldRng:
+    """The prover's RNG for real proofs: `Fr::random(OsRng)` as the reference draws it
+    (/root/reference/zkevm-circuits/benches/benchmark_list/main.rs:277): 64 bytes of operating-system entropy reduced mod r
+    per element (`from_uniform_bytes`), so every blinding value is uniform to within 2^-258.  `FieldRng` is for
+    reproducible tests and benchmarks only: its generator is not cryptographic and its `limbs` are not uniform below r."""
+
+    def fr(self) -> int:
+        import secrets
+        return int.from_bytes(secrets.token_bytes(64), "little") % P
+
+    def limbs(self, n: int) -> np.ndarray:
+        import secrets
+        raw = np.frombuffer(secrets.token_bytes(64 * n), dtype=np.uint8).reshape(n, 64)
+        r = evalh_host.R256
+        # wide reduction of every 64-byte draw, then Montgomery form
+        out = np.empty((n, 4), dtype=np.uint64)
+        for i in range(n):
+            v = int.from_bytes(raw[i].tobytes(), "little") % P * r % P
+            out[i] = [(v >> (64 * j)) & 0xFFFFFFFFFFFFFFFF for j in range(4)]
+        return out
+
+
 def collect_queries(cs: ConstraintSystem):
     """(advice_queries, fixed_queries, instance_queries) as [(column, rotation)], each in order of first appearance."""
     out = {"advice": [], "fixed": [], "instance": []}
@@ -234,16 +256,79 @@ def keygen(ctx, dom, params: ParamsKZG, cs: ConstraintSystem, fixed, assembly, d
         pk.fixed_commitments = [affine_ints(j) for j in params.commit_lagrange(pk.fixed_values)]
     if pk.polys.permutations:
         pk.permutation_commitments = [affine_ints(j) for j in params.commit_lagrange(pk.polys.permutations)]
+    pk.transcript_repr = _vk_digest(dom.k, pk.fixed_commitments, pk.permutation_commitments)
+    return pk
+
+
+def _point_limbs(xy) -> np.ndarray:
+    """(x, y) canonical integers (None: identity) -> 8 Montgomery limbs, the RawBytes form of a G1Affine"""
+    if xy is None:
+        return np.zeros(8, dtype=np.uint64)
+    r = 1 << 256
+    words = []
+    for c in xy:
+        m = c * r % FQ_MODULUS
+        words += [(m >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for i in range(4)]
+    return np.array(words, dtype=np.uint64)
+
+
+def _vk_digest(k: int, fixed_commitments, permutation_commitments) -> int:
     h = hashlib.blake2b(digest_size=64, person=b"Halo2-Verify-Key")
-    h.update(dom.k.to_bytes(4, "little"))
-    for c in pk.fixed_commitments + pk.permutation_commitments:
+    h.update(k.to_bytes(4, "little"))
+    for c in fixed_commitments + permutation_commitments:
         h.update(compress_point(c))
-    pk.transcript_repr = int.from_bytes(h.digest(), "little") % P
+    return int.from_bytes(h.digest(), "little") % P
+
+
+def save_proving_key(ctx, dom, pk: ProvingKey, path: str, layout: str = "v3") -> None:
+    """`ProvingKey::write(_, SerdeFormat::RawBytes)` (/root/reference/zkevm-circuits/benches/benchmark_list/main.rs:456-461):
+    downloads the key's polynomials and writes them behind the verifying key (`formats.write_proving_key_raw`)."""
+    from . import formats
+    if pk.polys.cosets is not None:
+        raise ValueError("a key generated for a multi-GPU partition holds only its rank's cosets")
+    n, en = dom.n, dom.extended_len
+    get = lambda ptrs, rows: [ctx.download(p, (rows, 4)) for p in ptrs]
+    vk = formats.VerifyingKeyRaw(dom.k, [_point_limbs(c) for c in pk.fixed_commitments] or np.zeros((0, 8), np.uint64),
+                                 [_point_limbs(c) for c in pk.permutation_commitments] or np.zeros((0, 8), np.uint64))
+    raw = formats.ProvingKeyRaw(
+        vk, l0=ctx.download(pk.polys.l0, (en, 4)), l_last=ctx.download(pk.polys.l_last, (en, 4)),
+        l_active_row=ctx.download(pk.polys.l_active_row, (en, 4)), fixed_values=get(pk.fixed_values, n),
+        fixed_polys=get(pk.polys.fixed_polys, n), fixed_cosets=get(pk.polys.fixed_cosets, en),
+        permutations=get(pk.polys.permutations, n), permutation_polys=get(pk.polys.permutation_polys, n),
+        permutation_cosets=get(pk.polys.permutation_cosets, en))
+    formats.write_proving_key_raw(path, raw, layout)
+
+
+def load_proving_key(ctx, dom, cs: ConstraintSystem, path: str) -> ProvingKey:
+    """`ProvingKey::read::<_, Circuit>(_, SerdeFormat::RawBytes)` (/root/reference/zkevm-circuits/benches/benchmark_list/main.rs:
+    486-501): as upstream, the constraint system comes from the circuit (`cs`), the file supplies commitments and
+    polynomials, which are uploaded as they are.  The result proves like a key from `keygen`."""
+    from . import formats
+    raw = formats.read_proving_key_raw(path, len(cs.permutation_columns))
+    if raw.vk.k != dom.k:
+        raise ValueError(f"the key is for k = {raw.vk.k}, the domain has k = {dom.k}")
+    raw.check(dom.extended_k)
+    if len(raw.fixed_values) != cs.num_fixed_columns:
+        raise ValueError("the key's fixed columns do not match the constraint system")
+    pk = ProvingKey()
+    pk.cs = cs
+    pk.ev = Evaluator(cs)
+    evalh_host.prepare(dom, cs, pk.ev)
+    up = lambda arrs: [ctx.upload(a) for a in arrs]
+    pk.polys = kg.ProvingKeyPolys()
+    pk.polys.l0, pk.polys.l_last, pk.polys.l_active_row = (ctx.upload(a) for a in (raw.l0, raw.l_last, raw.l_active_row))
+    pk.fixed_values = up(raw.fixed_values)
+    pk.polys.fixed_polys, pk.polys.fixed_cosets = up(raw.fixed_polys), up(raw.fixed_cosets)
+    pk.polys.permutations, pk.polys.permutation_polys = up(raw.permutations), up(raw.permutation_polys)
+    pk.polys.permutation_cosets = up(raw.permutation_cosets)
+    pk.fixed_commitments = [affine_ints(c) for c in raw.vk.fixed_commitments]
+    pk.permutation_commitments = [affine_ints(c) for c in raw.vk.permutation_commitments]
+    pk.transcript_repr = _vk_digest(dom.k, pk.fixed_commitments, pk.permutation_commitments)
     return pk
 
 
 def create_proof(ctx, dom, params: ParamsKZG, pk: ProvingKey, advice, instance, rng: FieldRng, transcript: Blake2bWrite,
-                 timings: dict | None = None, dist=None):
+                 timings: dict | None = None, dist=None, coset_groups: int | None = None):
     """One circuit.  advice: per column the values of the usable rows (a list of canonical integers, or a
     (usable rows, 4) uint64 array of Montgomery limbs; the remaining rows are blinding), or a callable
     (phase, challenges so far) -> such a list, called once per phase of `cs.phases()` as upstream re-runs witness
@@ -253,7 +338,10 @@ def create_proof(ctx, dom, params: ParamsKZG, pk: ProvingKey, advice, instance, 
     dist: an initialised torch.distributed module with one rank per GPU: every rank calls with the same arguments, the
     commitments are computed column-sharded and the quotient numerator coset-sharded (zkevm_circuits_amd/sharding.py), the
     rest is replicated; every rank returns the same bytes as a single-rank call.  A rank that raises (a lookup input
-    outside its table, say) does so on every rank alike, since all ranks hold the same witness."""
+    outside its table, say) does so on every rank alike, since all ranks hold the same witness.
+    coset_groups (single rank): evaluate the quotient numerator in that many passes over disjoint coset groups, which
+    bounds the resident extended data to 1 / coset_groups of the whole; None picks the smallest count that fits the free
+    device memory (1 on a whole MI355X at the SuperCircuit's width).  The proof bytes do not depend on it."""
     cs = pk.cs
     n, en = dom.n, dom.extended_len
     bf = cs.blinding_factors()
@@ -417,12 +505,54 @@ def create_proof(ctx, dom, params: ParamsKZG, pk: ProvingKey, advice, instance, 
         if not sharded:
             if pk.polys.cosets is not None:
                 raise ValueError("the proving key was generated for a multi-GPU partition (keygen(..., dist=...))")
+            # Footprint of the quotient phase: every extended coset at once is total * 2^extended_k * 32 bytes plus the
+            # transform scratch of a batch (83 GB + 34 GB at the SuperCircuit's width).  When that does not fit the free
+            # memory -- a smaller GPU or a partition of this one -- the numerator is evaluated coset group by coset group
+            # (what the ranks of the multi-GPU split do side by side), which holds 1 / groups of the cosets at a time.
+            free_bytes = ctx.mem_info()[0]
+            m = en // n
+            if coset_groups is None:
+                coset_groups = 1
+                while coset_groups < m and (en // coset_groups) * 32 * (total + 3 * BATCH) > 0.85 * free_bytes:
+                    coset_groups *= 2
+            if coset_groups < 1 or coset_groups > m or coset_groups & (coset_groups - 1):
+                raise ValueError("coset_groups must be a power of two between 1 and the number of cosets")
+            BATCH = max(1, min(BATCH, int(0.1 * free_bytes) // (3 * en * 32)))
+        if not sharded and coset_groups == 1:
             ext_block = alloc(en * max(total, 1))
             for s0 in range(0, total, BATCH):
                 dom.coeff_to_extended_dev(slot[s0], ext_block + s0 * en * 32, min(BATCH, total - s0))
             fill(lambda p: ext_block + (p - block) // (n * 32) * en * 32, lambda p: p)
             mark("quotient_evaluate_h")
             dom.evaluate_h(call.build(ffi.MEM_DEVICE, ffi.FORM_EXTENDED), d_h)
+        elif not sharded:
+            mark("quotient_evaluate_h")
+            for g in range(coset_groups):
+                cosets = list(range(g, m, coset_groups))
+                rows = n * len(cosets)
+                group = []
+
+                def of_poly(p):
+                    d = ctx.alloc(rows * 32)
+                    group.append(d)
+                    dom.coeff_to_cosets_dev(p, cosets, d)
+                    return d
+
+                def of_key(p):
+                    d = ctx.alloc(rows * 32)
+                    group.append(d)
+                    dom.extended_to_cosets_dev(p, cosets, d)
+                    return d
+                fill(of_poly, of_key)
+                call.cosets = cosets
+                d_piece = ctx.alloc(rows * 32)
+                group.append(d_piece)
+                dom.evaluate_h(call.build(ffi.MEM_DEVICE, ffi.FORM_EXTENDED), d_piece)
+                dom.cosets_to_extended_dev(d_piece, cosets, d_h)
+                ctx.sync()
+                for d in group:
+                    ctx.free(d)
+            call.cosets = None
         else:
             import torch
 
