@@ -6,7 +6,8 @@ sys.path.insert(0, ROOT)
 import zkhip_pkg
 zk = zkhip_pkg.load()
 ctx = zk.Context(0)
-k, j, batch = 19, 5, int(sys.argv[1]) if len(sys.argv) > 1 else 64
+k, batch = 19, int(sys.argv[1]) if len(sys.argv) > 1 else 64
+j = int(sys.argv[2]) if len(sys.argv) > 2 else 5
 dom = zk.Domain(ctx, j, k)
 n, en = 1 << k, dom.extended_len
 gen = torch.Generator(device="cuda"); gen.manual_seed(1)

@@ -20,6 +20,7 @@
 //     while storing.  That product also pulls the value back into (-p/100, 1.01 p), so adding p gives a non-negative
 //     residue below 2^256 that is stored as is; only the last pass canonicalises.
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include "common.h"
 #include "ntt.h"
@@ -139,6 +140,13 @@ constexpr int TK_E = 1 << TK_LOGE;
 constexpr int TK_THREADS = (1 << TILE_LOG) / TK_E;
 constexpr int TK_MAX_ROUNDS = 4;
 constexpr uint32_t NTT_BOUNDARY_TABLE_MAX_LOG = 22;   // 128 MiB
+
+// Largest pass boundary (log2 of its twiddle count) that gets a single-lookup table; larger ones compute
+// w^e = lo[e mod 2^h] * hi[e >> h].  ZKHIP_NTT_BOUNDARY_TABLE_MAX_LOG overrides it (measurements).
+static uint32_t boundary_table_max_log() {
+    const char* e = getenv("ZKHIP_NTT_BOUNDARY_TABLE_MAX_LOG");
+    return e && *e ? (uint32_t)atoi(e) : NTT_BOUNDARY_TABLE_MAX_LOG;
+}
 
 struct NttTileArgs {
     const fe* in;
@@ -456,7 +464,7 @@ int ntt_plan_create(zkhip_ctx* ctx, uint32_t log_n, const uint64_t omega[4], Ntt
         for (uint32_t p = 0; p + 1 < npass; p++) {
             bits += plan->radix[p + 1];
             plan->d_bt.push_back(nullptr);
-            if (bits > NTT_BOUNDARY_TABLE_MAX_LOG) continue;
+            if (bits > boundary_table_max_log()) continue;
             const size_t cnt = (size_t)1 << bits;
             std::vector<uint64_t> bt(cnt * 4);
             uint64_t step[4];
