@@ -55,6 +55,13 @@ int zkhip_dev_free(zkhip_ctx* ctx, void* dptr);
 /* free and total device memory of the context's GPU: callers size their batches of resident cosets with it (no reference
  * counterpart; the reference's runtime is given a fixed budget, benches/benchmark_list/main.rs:300-303). */
 int zkhip_mem_info(zkhip_ctx* ctx, size_t* free_bytes, size_t* total_bytes);
+/* Page-locked host memory for the buffers a caller hands over (witness columns): the device reads it by DMA at the
+ * link's rate, and zkhip_upload_async from it returns at once (the copy is ordered on the context's stream before the
+ * calls that follow; the memory must stay untouched until they have run or zkhip_sync returns).  From ordinary host
+ * memory zkhip_upload_async behaves like zkhip_upload without the final synchronisation. */
+int zkhip_host_alloc(zkhip_ctx* ctx, size_t bytes, void** hptr);
+int zkhip_host_free(zkhip_ctx* ctx, void* hptr);
+int zkhip_upload_async(zkhip_ctx* ctx, void* dptr, const void* host, size_t bytes);
 int zkhip_upload(zkhip_ctx* ctx, void* dptr, const void* host, size_t bytes);
 int zkhip_download(zkhip_ctx* ctx, void* host, const void* dptr, size_t bytes);
 
@@ -262,6 +269,12 @@ int zkhip_eval_polynomials_dev(zkhip_ctx* ctx, const uint64_t* const* d_coeffs, 
  * when an input value is missing from the table (upstream: Error::ConstraintSystemFailure).  Synchronises. */
 int zkhip_lookup_permute_dev(zkhip_domain* dom, const uint64_t* d_compressed_input, const uint64_t* d_compressed_table,
                              uint32_t usable_rows, uint64_t* d_permuted_input, uint64_t* d_permuted_table);
+/* The same for `count` lookups in one sequence of launches (all lookups of a proof: no challenge is squeezed between them,
+ * so `create_proof` can permute them together).  Every argument of zkhip_lookup_permute_dev becomes a HOST array of
+ * `count` device pointers; the error names the first lookup whose input is not contained in its table. */
+int zkhip_lookup_permute_batch_dev(zkhip_domain* dom, uint32_t count, const uint64_t* const* d_compressed_inputs,
+                                   const uint64_t* const* d_compressed_tables, uint32_t usable_rows,
+                                   uint64_t* const* d_permuted_inputs, uint64_t* const* d_permuted_tables);
 /* `arithmetic::best_fft` on G1 points (host pointers, n = 2^log_n affine points in and out): out[i] = scale * sum_j
  * omega^(i j) in[j].  `poly::kzg::commitment::ParamsKZG::setup` / `g_to_lagrange` obtain `g_lagrange` from `g` this way with
  * omega = omega_n^-1 and scale = n^-1 (parameters are built at zkevm-circuits/benches/benchmark_list/main.rs:184).

@@ -1044,6 +1044,51 @@ def test_lookup_permute_full_size_feeds_the_grand_product(ctx):
     d.close()
 
 
+@pytest.mark.parametrize("exact", [False, True])
+def test_lookup_permute_batch_of_mixed_columns(ctx, exact, monkeypatch):
+    """five lookups permuted in one call, each stressing another side of the radix sort: table indices below 2^10 (two
+    sort passes), full-width values, values whose varying bits straddle two key windows so that different values agree on
+    the whole 48-bit window (the batch then takes the exact re-sort), a column of one repeated value, and 62-bit values;
+    each against the model of upstream's loop.  exact: the re-sort on all 256 bits forced for the whole batch."""
+    import halo2_model as hm
+    if exact:
+        monkeypatch.setenv("ZKHIP_LOOKUP_EXACT_SORT", "1")
+    k, blinding = 11, 5
+    n = 1 << k
+    usable = n - (blinding + 1)
+    rng = np.random.default_rng(31 + exact)
+    cases = []
+    small_table = [i % 1000 for i in range(n)]
+    cases.append(([int(v) for v in rng.integers(0, 1000, size=n)], small_table))
+    wide = [int.from_bytes(rng.bytes(32), "little") % P for _ in range(300)]
+    cases.append(([wide[int(i)] for i in rng.integers(0, 300, size=n)], [wide[i % 300] for i in range(n)]))
+    # 2^200 + i and i: the window ends at bit 200, where every small i looks alike
+    split = [(1 << 200) + i for i in range(200)] + list(range(1, 200))
+    cases.append(([split[int(i)] for i in rng.integers(0, len(split), size=n)], [split[i % len(split)] for i in range(n)]))
+    cases.append(([7] * n, [7] * n))
+    cases.append(_lookup_pair(rng, n, usable, 500, 40))
+    d = zk.Domain(ctx, 3, k)
+    d_in = [ctx.upload(fr_arr(a)) for a, _ in cases]
+    d_tb = [ctx.upload(fr_arr(t)) for _, t in cases]
+    d_pa = [ctx.alloc(n * 32) for _ in cases]
+    d_ps = [ctx.alloc(n * 32) for _ in cases]
+    d.lookup_permute_batch_dev(d_in, d_tb, usable, d_pa, d_ps)
+    for (a, t), pa, ps in zip(cases, d_pa, d_ps):
+        exp_a, exp_s = hm.permute_expression_pair(a, t, usable)
+        assert fr_ints(ctx.download(pa, (n, 4))[:usable]) == exp_a
+        assert fr_ints(ctx.download(ps, (n, 4))[:usable]) == exp_s
+    # the error names the lookup whose input left its table
+    bad = list(cases[3][0])
+    bad[5] = 8
+    ctx.upload(fr_arr(bad), d_in[3])
+    with pytest.raises(ffi.ZkhipError, match="lookup 3"):
+        d.lookup_permute_batch_dev(d_in, d_tb, usable, d_pa, d_ps)
+    d.lookup_permute_batch_dev([], [], usable, [], [])
+    for p_ in d_in + d_tb + d_pa + d_ps:
+        ctx.free(p_)
+    d.close()
+
+
 def test_lookup_permute_golden(ctx):
     for c in golden("lookup_permute.json")["cases"]:
         n, usable = 1 << c["k"], c["usable_rows"]

@@ -180,6 +180,23 @@ int zkhip_mem_info(zkhip_ctx* ctx, size_t* free_bytes, size_t* total_bytes) {
     ZK_HIP(ctx, hipMemGetInfo(free_bytes, total_bytes));
     return ZKHIP_OK;
 }
+int zkhip_host_alloc(zkhip_ctx* ctx, size_t bytes, void** hptr) {
+    if (!ctx || !hptr) return ZKHIP_ERR_INVALID;
+    ZK_HIP(ctx, hipSetDevice(ctx->device));
+    ZK_HIP(ctx, hipHostMalloc(hptr, bytes ? bytes : 1, hipHostMallocDefault));
+    return ZKHIP_OK;
+}
+int zkhip_host_free(zkhip_ctx* ctx, void* hptr) {
+    if (!ctx) return ZKHIP_ERR_INVALID;
+    ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ZK_HIP(ctx, hipHostFree(hptr));
+    return ZKHIP_OK;
+}
+int zkhip_upload_async(zkhip_ctx* ctx, void* dptr, const void* host, size_t bytes) {
+    if (!ctx || (!dptr && bytes) || (!host && bytes)) return ZKHIP_ERR_INVALID;
+    ZK_HIP(ctx, hipMemcpyAsync(dptr, host, bytes, hipMemcpyHostToDevice, ctx->stream));
+    return ZKHIP_OK;
+}
 int zkhip_upload(zkhip_ctx* ctx, void* dptr, const void* host, size_t bytes) {
     if (!ctx || (!dptr && bytes) || (!host && bytes)) return ZKHIP_ERR_INVALID;
     ZK_HIP(ctx, hipMemcpyAsync(dptr, host, bytes, hipMemcpyHostToDevice, ctx->stream));

@@ -17,6 +17,7 @@ _LIB = None
 EXPORTS = [
     "zkhip_create", "zkhip_destroy", "zkhip_last_error", "zkhip_version", "zkhip_set_stream", "zkhip_sync",
     "zkhip_dev_alloc", "zkhip_dev_free", "zkhip_mem_info", "zkhip_upload", "zkhip_download",
+    "zkhip_host_alloc", "zkhip_host_free", "zkhip_upload_async",
     "zkhip_field_binop", "zkhip_field_batch_invert", "zkhip_g1_add_affine", "zkhip_g1_multiples", "zkhip_probe_mad_rate",
     "zkhip_register_bases", "zkhip_release_bases", "zkhip_msm", "zkhip_msm_batch_dev", "zkhip_msm_range_dev",
     "zkhip_g1_sum_jacobian", "zkhip_g1_to_affine", "zkhip_g1_fft",
@@ -30,7 +31,7 @@ EXPORTS = [
     "zkhip_evaluate_h", "zkhip_evaluate_h_last_stats", "zkhip_evaluate_h_cache_stats", "zkhip_evaluate_h_prepare",
     "zkhip_coeff_to_cosets_dev", "zkhip_extended_to_cosets_dev", "zkhip_cosets_to_extended_dev",
     "zkhip_batch_invert_dev", "zkhip_prefix_product_dev", "zkhip_prefix_product_noalloc_dev", "zkhip_permutation_product_dev", "zkhip_lookup_product_dev",
-    "zkhip_eval_polynomial_dev", "zkhip_eval_polynomials_dev", "zkhip_poly_lincomb_dev", "zkhip_kate_division_dev", "zkhip_lookup_permute_dev", "zkhip_permutation_sigma_dev",
+    "zkhip_eval_polynomial_dev", "zkhip_eval_polynomials_dev", "zkhip_poly_lincomb_dev", "zkhip_kate_division_dev", "zkhip_lookup_permute_dev", "zkhip_lookup_permute_batch_dev", "zkhip_permutation_sigma_dev",
     "zkhip_timing_enable", "zkhip_timing_reset", "zkhip_timing_get",
 ]
 
@@ -147,11 +148,15 @@ class Context:
         self.device = device
         # bytes handed out by alloc() and not yet freed, and their high-water mark: what a rank keeps resident
         self._sizes = {}
+        self._pinned = {}                 # address -> bytes of the page-locked host buffers handed out by host_zeros
         self.allocated_bytes = 0
         self.peak_allocated_bytes = 0
 
     def close(self):
         if getattr(self, "h", None):
+            for addr in list(getattr(self, "_pinned", {})):
+                self._l.zkhip_host_free(self.h, C.c_void_p(addr))
+            self._pinned = {}
             self._l.zkhip_destroy(self.h)
             self.h = None
 
@@ -197,8 +202,37 @@ class Context:
         arr = u64(arr)
         if dptr is None:
             dptr = self.alloc(arr.nbytes)
-        self._ck(self._l.zkhip_upload(self.h, C.c_void_p(dptr), _p(arr), C.c_size_t(arr.nbytes)))
+        if self.is_pinned(arr):
+            # page-locked source: a DMA ordered on the context's stream, no wait (the buffer outlives the context's work)
+            self._ck(self._l.zkhip_upload_async(self.h, C.c_void_p(dptr), _p(arr), C.c_size_t(arr.nbytes)))
+        else:
+            self._ck(self._l.zkhip_upload(self.h, C.c_void_p(dptr), _p(arr), C.c_size_t(arr.nbytes)))
         return dptr
+
+    def host_zeros(self, shape) -> np.ndarray:
+        """a zeroed uint64 array in page-locked host memory (freed with the context): witness columns built in such
+        arrays reach the device by DMA at the link's rate, without the staging copy ordinary memory needs"""
+        nbytes = int(np.prod(shape)) * 8
+        h = C.c_void_p()
+        self._ck(self._l.zkhip_host_alloc(self.h, C.c_size_t(max(nbytes, 8)), C.byref(h)))
+        self._pinned[h.value] = max(nbytes, 8)
+        buf = (C.c_uint8 * max(nbytes, 8)).from_address(h.value)
+        a = np.frombuffer(buf, dtype=np.uint64, count=nbytes // 8).reshape(shape)
+        a[...] = 0
+        return a
+
+    def host_free(self, arr: np.ndarray):
+        addr = arr.ctypes.data
+        if addr in self._pinned:
+            self._ck(self._l.zkhip_host_free(self.h, C.c_void_p(addr)))
+            del self._pinned[addr]
+
+    def is_pinned(self, arr: np.ndarray) -> bool:
+        addr = arr.ctypes.data
+        for base, size in self._pinned.items():
+            if base <= addr and addr + arr.nbytes <= base + size:
+                return True
+        return False
 
     def download(self, dptr: int, shape) -> np.ndarray:
         out = np.empty(shape, dtype=np.uint64)
@@ -482,6 +516,14 @@ class Domain:
     def lookup_permute_dev(self, d_input: int, d_table: int, usable_rows: int, d_permuted_input: int, d_permuted_table: int):
         self.ctx._ck(self._l.zkhip_lookup_permute_dev(self.h, C.c_void_p(d_input), C.c_void_p(d_table), C.c_uint32(usable_rows),
                                                       C.c_void_p(d_permuted_input), C.c_void_p(d_permuted_table)))
+
+    def lookup_permute_batch_dev(self, d_inputs, d_tables, usable_rows: int, d_permuted_inputs, d_permuted_tables):
+        """lookup_permute_dev for all lookups of a proof in one sequence of launches (lists of device pointers)"""
+        count = len(d_inputs)
+        assert len(d_tables) == len(d_permuted_inputs) == len(d_permuted_tables) == count
+        arr = lambda ptrs: (C.c_void_p * max(count, 1))(*[C.c_void_p(int(p)) for p in ptrs])
+        self.ctx._ck(self._l.zkhip_lookup_permute_batch_dev(self.h, C.c_uint32(count), arr(d_inputs), arr(d_tables),
+                                                            C.c_uint32(usable_rows), arr(d_permuted_inputs), arr(d_permuted_tables)))
 
     def lookup_product_dev(self, d_input: int, d_table: int, d_permuted_input: int, d_permuted_table: int, beta, gamma,
                            d_z: int):

@@ -429,11 +429,15 @@ def create_proof(ctx, dom, params: ParamsKZG, pk: ProvingKey, advice, instance, 
             for exprs, d_out in ((lk.input_expressions, d_in), (lk.table_expressions, d_tb)):
                 call = evalh_host.lookup_compress_call(cs, exprs, pk.fixed_values, adv, inst, ch_limbs, limb(theta))
                 dom.evaluate_h(call.build(ffi.MEM_DEVICE, ffi.FORM_EXTENDED), d_out)
-            dom.lookup_permute_dev(d_in, d_tb, usable, d_pa, d_ps)
+            lookups.append([d_in, d_tb, d_pa, d_ps, 0])
+        # the permuted columns of all lookups in one sequence of launches; blinding rows and blinds in upstream's order
+        if lookups:
+            dom.lookup_permute_batch_dev([lk[0] for lk in lookups], [lk[1] for lk in lookups], usable,
+                                         [lk[2] for lk in lookups], [lk[3] for lk in lookups])
+        for _, _, d_pa, d_ps, _ in lookups:
             blind_rows(d_pa, usable)
             blind_rows(d_ps, usable)
             rng.fr(), rng.fr()
-            lookups.append([d_in, d_tb, d_pa, d_ps, 0])
         # no challenge is squeezed between the lookups, so their commitments go out as one pipelined batch, written in
         # upstream's order (a' then s' of each lookup)
         if lookups:

@@ -104,7 +104,7 @@ def satisfied_cs(units, degree9=False, extra_gates=0):
     return cs
 
 
-def satisfied_witness(cs, n, seed, units, active_rows=500, as_arrays=False):
+def satisfied_witness(cs, n, seed, units, active_rows=500, as_arrays=False, zeros=None):
     """(advice, instance, fixed, copy-constraint assembly) for `satisfied_cs(units, ..)` on n rows: `active_rows` rows per
     unit carry b = a^2, c = a b and the running sum s, tied to the public inputs and to each other by copy constraints.
     as_arrays: advice columns as (usable, 4) Montgomery limb arrays (zero below the active rows) instead of lists."""
@@ -141,7 +141,7 @@ def satisfied_witness(cs, n, seed, units, active_rows=500, as_arrays=False):
         from .prover import fr_limbs
         arrays = []
         for col in advice:
-            arr = np.zeros((usable, 4), dtype=np.uint64)
+            arr = zeros((usable, 4)) if zeros else np.zeros((usable, 4), dtype=np.uint64)
             arr[:m + 1] = fr_limbs(col[:m + 1])
             assert not any(col[m + 1:])
             arrays.append(arr)
@@ -209,10 +209,12 @@ def standin_cs(units=52, lanes=8, wide_lookups=8, lookup_width=10, extra_gates=0
     return cs
 
 
-def standin_witness(cs, n, seed, active_rows=3000):
+def standin_witness(cs, n, seed, active_rows=3000, zeros=None):
     """(advice callable for `prover.create_proof`, instance, fixed, assembly) satisfying `standin_cs`.  Advice columns are
     (usable, 4) Montgomery limb arrays, zero below the active rows; the callable fills the second-phase columns from the
-    challenges it is given."""
+    challenges it is given.  zeros: allocator of zeroed uint64 arrays for the columns (`Context.host_zeros` puts the
+    witness into page-locked memory, which the device reads by DMA)."""
+    zeros = zeros or (lambda shape: np.zeros(shape, dtype=np.uint64))
     from .keygen import Assembly
     from .prover import fr_limbs
     from .plonk import FR_MODULUS as P
@@ -227,12 +229,12 @@ def standin_witness(cs, n, seed, active_rows=3000):
     shim = ConstraintSystem()
     shim.blinding_factors = lambda: base_cs_bf
     shim.permutation_columns = base_cs.permutation_columns
-    advice, instance, fixed, _ = satisfied_witness(shim, n, seed, units, active_rows=m, as_arrays=True)
+    advice, instance, fixed, _ = satisfied_witness(shim, n, seed, units, active_rows=m, as_arrays=True, zeros=zeros)
     rng = np.random.default_rng(seed + 1)
     act = m + 205                                         # rows that may be non-zero
 
     def arr(vals):
-        a = np.zeros((usable, 4), dtype=np.uint64)
+        a = zeros((usable, 4))
         a[:len(vals)] = fr_limbs(vals)
         return a
 
@@ -254,7 +256,7 @@ def standin_witness(cs, n, seed, active_rows=3000):
             advice.append(arr([p * (j + 1) for p in pick]))
     xs = [[int(v) for v in fr_from_limbs_rows(advice[c][:m])] for c in info["x"][:3]]
     a0 = [int(v) for v in fr_from_limbs_rows(advice[0][:m])]
-    zero = np.zeros((usable, 4), dtype=np.uint64)
+    zero = zeros((usable, 4))
     fixed = [list(c) for c in fixed]
     fixed.append([1 if first <= i < last else 0 for i in range(n)])        # q_k
     fixed.append([1] * m + [0] * (n - m))                                   # q_w
