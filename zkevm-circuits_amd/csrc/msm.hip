@@ -794,8 +794,13 @@ static const uint32_t FORCE_L = env_u32("ZKHIP_SLOT_L", 0);
 // Buffers of one in-flight MSM.  A workspace is bound to a stream; several workspaces let the latency-bound tail of
 // one MSM (merge, reduce, host fold) overlap the accumulate phase of the next.
 struct MsmWorkspace {
-    hipStream_t stream = nullptr;
+    // stream: recode / count / plan / scatter.  acc_stream / tail_stream: the accumulate kernel and merge + reduce when
+    // the pipelined batch runs them on streams of their own (null: everything on `stream`).
+    hipStream_t stream = nullptr, acc_stream = nullptr, tail_stream = nullptr;
     hipEvent_t ev_info = nullptr;      // the plan has reached h_info
+    hipEvent_t ev_sorted = nullptr, ev_acc = nullptr, ev_done = nullptr;   // hand-offs between the three streams
+    hipStream_t acc() const { return acc_stream ? acc_stream : stream; }
+    hipStream_t tail() const { return tail_stream ? tail_stream : stream; }
     unsigned char* base = nullptr;
     size_t bytes = 0;
     uint32_t* h_info = nullptr;        // pinned copy of info[0..3]
@@ -841,6 +846,8 @@ static int ws_prepare(zkhip_ctx* ctx, MsmWorkspace& ws, const MsmTables& tb, siz
     if (off > ws.bytes) {
         if (ws.base) {
             ZK_HIP(ctx, hipStreamSynchronize(ws.stream));
+            ZK_HIP(ctx, hipStreamSynchronize(ws.acc()));
+            ZK_HIP(ctx, hipStreamSynchronize(ws.tail()));
             ZK_HIP(ctx, hipFree(ws.base));
             ws.base = nullptr;
             ws.bytes = 0;
@@ -849,7 +856,12 @@ static int ws_prepare(zkhip_ctx* ctx, MsmWorkspace& ws, const MsmTables& tb, siz
         ws.bytes = off;
     }
     if (!ws.h_info) ZK_HIP(ctx, hipHostMalloc((void**)&ws.h_info, 64));
-    if (!ws.ev_info) ZK_HIP(ctx, hipEventCreateWithFlags(&ws.ev_info, hipEventDisableTiming));
+    if (!ws.ev_info) {
+        ZK_HIP(ctx, hipEventCreateWithFlags(&ws.ev_info, hipEventDisableTiming));
+        ZK_HIP(ctx, hipEventCreateWithFlags(&ws.ev_sorted, hipEventDisableTiming));
+        ZK_HIP(ctx, hipEventCreateWithFlags(&ws.ev_acc, hipEventDisableTiming));
+        ZK_HIP(ctx, hipEventCreateWithFlags(&ws.ev_done, hipEventDisableTiming));
+    }
     ws.acc_blocks = (uint32_t)((T1_max + 255) / 256);
     if (!ws.h_sums) ZK_HIP(ctx, hipHostMalloc((void**)&ws.h_sums, REDUCE_OUT * sizeof(g1_xyzz)));
     unsigned char* p = ws.base;
@@ -926,23 +938,27 @@ static int msm_phase1(zkhip_ctx* ctx, MsmWorkspace& ws, const MsmTables& tb, siz
                            parts, ws.entries);
     }
     ZK_HIP(ctx, hipGetLastError());
+    if (ws.acc() != ws.stream) ZK_HIP(ctx, hipEventRecord(ws.ev_sorted, ws.stream));
     return ZKHIP_OK;
 }
 
 // accumulate: launched for the largest slot count the plan may choose; lanes beyond the planned slots leave at once
 static int msm_accumulate(zkhip_ctx* ctx, MsmWorkspace& ws, const MsmTables& tb) {
     const uint32_t B = 1u << (tb.c - 1);
-    hipLaunchKernelGGL(accumulate_kernel, dim3(ws.acc_blocks), dim3(256), 0, ws.stream, ws.entries, ws.start, ws.cnt, ws.offA,
+    if (ws.acc() != ws.stream) ZK_HIP(ctx, hipStreamWaitEvent(ws.acc(), ws.ev_sorted, 0));
+    hipLaunchKernelGGL(accumulate_kernel, dim3(ws.acc_blocks), dim3(256), 0, ws.acc(), ws.entries, ws.start, ws.cnt, ws.offA,
                        ws.cntA, B, tb.d_tables, tb.n, ws.first, ws.itemsA);
     ZK_HIP(ctx, hipGetLastError());
+    if (ws.tail() != ws.acc()) ZK_HIP(ctx, hipEventRecord(ws.ev_acc, ws.acc()));
     return ZKHIP_OK;
 }
 
 // phase 2: waits for the plan (the accumulate kernel is already queued), then merge and reduce; asynchronous readback
 // of the leftover sums
 static int msm_phase2(zkhip_ctx* ctx, MsmWorkspace& ws, const MsmTables& tb, bool timed) {
-    hipStream_t st = ws.stream;
+    hipStream_t st = ws.tail();
     ZK_HIP(ctx, hipEventSynchronize(ws.ev_info));
+    if (ws.tail() != ws.acc()) ZK_HIP(ctx, hipStreamWaitEvent(st, ws.ev_acc, 0));
     const uint32_t total_slots = ws.h_info[INFO_SLOTS], max_cnt = ws.h_info[INFO_MAXCNT], L = ws.h_info[INFO_L];
     const uint32_t B = 1u << (tb.c - 1);
     ws.nonzero = total_slots != 0;
@@ -950,7 +966,10 @@ static int msm_phase2(zkhip_ctx* ctx, MsmWorkspace& ws, const MsmTables& tb, boo
     if (debug)
         fprintf(stderr, "[zkhip] msm n=%zu: slots=%u max_cnt=%u L=%u entries=%u heavy=%u\n", ws.n, total_slots, max_cnt, L,
                 ws.h_info[INFO_ENTRIES], ws.h_info[INFO_HEAVY]);
-    if (!ws.nonzero) return ZKHIP_OK;   // every scalar is zero
+    if (!ws.nonzero) {                  // every scalar is zero
+        ZK_HIP(ctx, hipEventRecord(ws.ev_done, st));
+        return ZKHIP_OK;
+    }
     // all items live in one array: itemsA (the slot sums) followed by itemsB (the outputs of the pre-levels, appended
     // level after level); bucket views index it from itemsA
     g1_xyzz* items = ws.itemsA;
@@ -998,6 +1017,7 @@ static int msm_phase2(zkhip_ctx* ctx, MsmWorkspace& ws, const MsmTables& tb, boo
         ZK_HIP(ctx, hipGetLastError());
     }
     ZK_HIP(ctx, hipMemcpyAsync(ws.h_sums, ws.out2, REDUCE_OUT * sizeof(g1_xyzz), hipMemcpyDeviceToHost, st));
+    ZK_HIP(ctx, hipEventRecord(ws.ev_done, st));
     return ZKHIP_OK;
 }
 
@@ -1006,7 +1026,7 @@ static int msm_phase2(zkhip_ctx* ctx, MsmWorkspace& ws, const MsmTables& tb, boo
 // (bucket b = 64 h + l weighs b + 1 = 64 h + l + 1), by Horner: 14 doublings and 15 additions, after the two halves of
 // level 2 have been added up (D_8 = total of the upper half).
 static int msm_phase3(zkhip_ctx* ctx, MsmWorkspace& ws, uint64_t out_jacobian[12]) {
-    ZK_HIP(ctx, hipStreamSynchronize(ws.stream));
+    ZK_HIP(ctx, hipEventSynchronize(ws.ev_done));   // this MSM's sums have arrived (the stream may hold later MSMs' work)
     memset(out_jacobian, 0, 96);
     if (!ws.nonzero) return ZKHIP_OK;
     uint64_t pt[2][15][12];
@@ -1074,14 +1094,28 @@ static int msm_pipeline(zkhip_ctx* ctx, MsmState& stt, const MsmTables& tb, cons
         ZK_HIP(ctx, hipEventCreateWithFlags(&stt.ev_in, hipEventDisableTiming));
         for (int i = 0; i < MSM_PIPE; i++) ZK_HIP(ctx, hipEventCreateWithFlags(&stt.ev_out[i], hipEventDisableTiming));
     }
+    // Three streams by role, shared by the workspaces: [0] recode / count / plan / scatter, [1] accumulate, [2] merge +
+    // reduce.  The accumulate kernels run back to back on their own stream at the lowest priority; the short kernels
+    // before and after them go to high-priority streams, so that the dispatcher hands them the workgroup slots that
+    // accumulate frees (at equal priority they starve next to it: 24 us of histogram take 560 us and delay the next
+    // accumulate, which waits for them).
     MsmWorkspace* pipe[MSM_PIPE];
+    if (!stt.batch_streams[0]) {
+        int least = 0, greatest = 0;
+        ZK_HIP(ctx, hipDeviceGetStreamPriorityRange(&least, &greatest));
+        static const bool flat = getenv("ZKHIP_MSM_FLAT_PRIORITY") != nullptr;   // measurements: all streams alike
+        const int prio[MSM_PIPE] = {greatest, flat ? greatest : least, greatest};
+        for (int i = 0; i < MSM_PIPE; i++)
+            ZK_HIP(ctx, hipStreamCreateWithPriority(&stt.batch_streams[i], hipStreamNonBlocking, prio[i]));
+    }
     for (int i = 0; i < MSM_PIPE; i++) {
-        if (!stt.batch_streams[i]) ZK_HIP(ctx, hipStreamCreateWithFlags(&stt.batch_streams[i], hipStreamNonBlocking));
-        stt.ws[i].stream = stt.batch_streams[i];
+        stt.ws[i].stream = stt.batch_streams[0];
+        stt.ws[i].acc_stream = stt.batch_streams[1];
+        stt.ws[i].tail_stream = stt.batch_streams[2];
         pipe[i] = &stt.ws[i];
     }
     ZK_HIP(ctx, hipEventRecord(stt.ev_in, ctx->stream));
-    for (int i = 0; i < MSM_PIPE; i++) ZK_HIP(ctx, hipStreamWaitEvent(pipe[i]->stream, stt.ev_in, 0));
+    for (int i = 0; i < MSM_PIPE; i++) ZK_HIP(ctx, hipStreamWaitEvent(stt.batch_streams[i], stt.ev_in, 0));
     // software pipeline: phase1(j + 2), phase2(j + 1), phase3(j)
     int rc;
     for (size_t j = 0; j < batch + 2; j++) {
@@ -1092,7 +1126,7 @@ static int msm_pipeline(zkhip_ctx* ctx, MsmState& stt, const MsmTables& tb, cons
                 rc = msm_phase1(ctx, ws, tb, items[j].first, items[j].d_scalars, items[j].n);
             }
             if (!rc) {
-                TimedRegion tr(ctx, timed ? "msm_accumulate" : nullptr, ws.stream);
+                TimedRegion tr(ctx, timed ? "msm_accumulate" : nullptr, ws.acc());
                 rc = msm_accumulate(ctx, ws, tb);
             }
             if (rc) return rc;
@@ -1107,7 +1141,7 @@ static int msm_pipeline(zkhip_ctx* ctx, MsmState& stt, const MsmTables& tb, cons
         }
     }
     for (int i = 0; i < MSM_PIPE; i++) {
-        ZK_HIP(ctx, hipEventRecord(stt.ev_out[i], pipe[i]->stream));
+        ZK_HIP(ctx, hipEventRecord(stt.ev_out[i], stt.batch_streams[i]));
         ZK_HIP(ctx, hipStreamWaitEvent(ctx->stream, stt.ev_out[i], 0));
     }
     return ZKHIP_OK;
@@ -1121,6 +1155,7 @@ int msm_run(zkhip_ctx* ctx, MsmState& stt, const MsmTables& tb, size_t first, co
     if (rc) return rc;
     MsmWorkspace& ws = stt.ws[0];
     ws.stream = ctx->stream;
+    ws.acc_stream = ws.tail_stream = nullptr;      // a lone MSM has nothing to overlap with: one stream
     {
         TimedRegion tr(ctx, "msm_sort");
         rc = msm_phase1(ctx, ws, tb, first, d_scalars, n);
@@ -1158,6 +1193,9 @@ void msm_drop_ctx(zkhip_ctx* ctx) {
         if (w.h_info) (void)hipHostFree(w.h_info);
         if (w.h_sums) (void)hipHostFree(w.h_sums);
         if (w.ev_info) (void)hipEventDestroy(w.ev_info);
+        if (w.ev_sorted) (void)hipEventDestroy(w.ev_sorted);
+        if (w.ev_acc) (void)hipEventDestroy(w.ev_acc);
+        if (w.ev_done) (void)hipEventDestroy(w.ev_done);
         if (st.batch_streams[i]) (void)hipStreamDestroy(st.batch_streams[i]);
         if (st.ev_out[i]) (void)hipEventDestroy(st.ev_out[i]);
     }
