@@ -62,6 +62,15 @@ int zkhip_mem_info(zkhip_ctx* ctx, size_t* free_bytes, size_t* total_bytes);
 int zkhip_host_alloc(zkhip_ctx* ctx, size_t bytes, void** hptr);
 int zkhip_host_free(zkhip_ctx* ctx, void* hptr);
 int zkhip_upload_async(zkhip_ctx* ctx, void* dptr, const void* host, size_t bytes);
+/* Copies that run BESIDE the context's work, on a transfer stream of the context's own: the witness columns of the next
+ * commitments arrive while the current ones are computed (the reference's prover holds the witness in host memory and
+ * commits column after column, benches/benchmark_list/main.rs:277-285).  zkhip_upload_overlapped returns at once; the
+ * first copy after a fence is ordered behind the work the context holds at that moment, the following ones behind each
+ * other only.  Calls made after zkhip_upload_fence see every copy issued before it; calls made before it must not touch
+ * the targets.  zkhip_sync implies a fence.  The host memory should be page-locked (zkhip_host_alloc) and stays
+ * untouched until a fence has been followed by zkhip_sync or by a call that returns results. */
+int zkhip_upload_overlapped(zkhip_ctx* ctx, void* dptr, const void* host, size_t bytes);
+int zkhip_upload_fence(zkhip_ctx* ctx);
 int zkhip_upload(zkhip_ctx* ctx, void* dptr, const void* host, size_t bytes);
 int zkhip_download(zkhip_ctx* ctx, void* host, const void* dptr, size_t bytes);
 

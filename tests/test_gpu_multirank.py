@@ -187,9 +187,16 @@ def _prover_worker(rank, world, port, q):
                 peak_whole = ctx.peak_allocated_bytes - base
                 vk = {"fixed_commitments": pk.fixed_commitments, "permutation_commitments": pk.permutation_commitments,
                       "transcript_repr": pk.transcript_repr}
-                vm.verify_proof(cs, k, vk, instance, sharded, pc.TAU)
                 same_vk = pk.fixed_commitments == pk_s.fixed_commitments and pk.transcript_repr == pk_s.transcript_repr
-                results.append((sharded == whole and same_vk, peak_sharded, peak_whole, dom.extended_k - k))
+                # the first 32-byte item of the proof that differs, if any (tells the phase that went wrong)
+                differ = [i for i in range(0, max(len(whole), len(sharded)), 32) if whole[i:i + 32] != sharded[i:i + 32]]
+                note = f"k={k}: first differing proof item {differ[0] // 32} of {len(whole) // 32}" if differ else ""
+                try:
+                    vm.verify_proof(cs, k, vk, instance, whole, pc.TAU)
+                    vm.verify_proof(cs, k, vk, instance, sharded, pc.TAU)
+                except vm.VerifyError as err:
+                    note += f"; verifier: {err}"
+                results.append((not differ and same_vk and not note, peak_sharded, peak_whole, dom.extended_k - k, note))
                 for p in pk.pointers():
                     ctx.free(p)
             dist.barrier()
@@ -199,6 +206,10 @@ def _prover_worker(rank, world, port, q):
             q.put(results)
         dist.barrier()
         ctx.close()
+    except Exception:
+        import traceback
+        q.put(f"rank {rank} failed:\n{traceback.format_exc()}")     # the test fails at once instead of waiting
+        raise
     finally:
         dist.destroy_process_group()
 
@@ -219,10 +230,13 @@ def test_ranks_create_the_same_proof_as_one(world):
         results = q.get(timeout=300)
     finally:
         for p in procs:
-            p.join(timeout=120)
+            p.join(timeout=60)
+            if p.is_alive():
+                p.kill()
+    assert not isinstance(results, str), results
     assert all(p.exitcode == 0 for p in procs)
-    assert [r[0] for r in results] == [True, True]
-    for ok, peak_sharded, peak_whole, e in results:
+    assert [r[0] for r in results] == [True, True], [r[4] for r in results]
+    for ok, peak_sharded, peak_whole, e, _ in results:
         share = max(1.0 / world, 1.0 / (1 << e))          # the part of the extended domain one rank holds
         # the 2^k-sized polynomials (coefficient and Lagrange forms) stay whole on every rank: they come on top of the
         # rank's share of the extended vectors, and weigh most where the extended domain is only 2n

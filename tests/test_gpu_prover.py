@@ -217,6 +217,17 @@ def test_wide_circuit_proof_verifies(ctx, co, k, units, degree9):
           "transcript_repr": pk.transcript_repr}
     proof = prover.create_proof(ctx, dom, params, pk, advice, instance, prover.FieldRng(k), prover.Blake2bWrite())
     vm.verify_proof(cs, k, vk, instance, proof, TAU)
+    # the witness handed over as Montgomery limbs in page-locked memory: the columns reach the device on the transfer
+    # stream, group after group beside the commitments of the group before (80 columns = three groups at 16 units), and
+    # the proof has the same bytes
+    pinned = []
+    for col in advice:
+        a = ctx.host_zeros((len(col), 4))
+        a[:] = prover.fr_limbs(col)
+        pinned.append(a)
+    assert prover.create_proof(ctx, dom, params, pk, pinned, instance, prover.FieldRng(k), prover.Blake2bWrite()) == proof
+    for a in pinned:
+        ctx.host_free(a)
     # one wrong cell in the last unit: d != a(-1) + b on one row
     advice = [list(col) for col in advice]
     advice[5 * (units - 1) + 4][9] += 1

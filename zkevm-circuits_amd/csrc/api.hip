@@ -145,6 +145,12 @@ void zkhip_destroy(zkhip_ctx* ctx) {
         }
     for (NttPlan* p : ctx->plans) delete p;
     if (ctx->scratch) (void)hipFree(ctx->scratch);
+    if (ctx->upload_stream) {
+        (void)hipStreamSynchronize(ctx->upload_stream);
+        (void)hipStreamDestroy(ctx->upload_stream);
+        (void)hipEventDestroy(ctx->ev_upload_base);
+        (void)hipEventDestroy(ctx->ev_upload_done);
+    }
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
 }
@@ -153,12 +159,16 @@ const char* zkhip_last_error(const zkhip_ctx* ctx) { return ctx ? ctx->last_erro
 
 int zkhip_set_stream(zkhip_ctx* ctx, void* hip_stream) {
     if (!ctx) return ZKHIP_ERR_INVALID;
+    int rc = zkhip_upload_fence(ctx);
+    if (rc) return rc;
     ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
     ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
     return ZKHIP_OK;
 }
 int zkhip_sync(zkhip_ctx* ctx) {
     if (!ctx) return ZKHIP_ERR_INVALID;
+    int rc = zkhip_upload_fence(ctx);     // overlapped copies still open count as the context's work
+    if (rc) return rc;
     ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return ZKHIP_OK;
 }
@@ -170,6 +180,7 @@ int zkhip_dev_alloc(zkhip_ctx* ctx, size_t bytes, void** dptr) {
 }
 int zkhip_dev_free(zkhip_ctx* ctx, void* dptr) {
     if (!ctx) return ZKHIP_ERR_INVALID;
+    if (ctx->upload_stream) ZK_HIP(ctx, hipStreamSynchronize(ctx->upload_stream));
     ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
     ZK_HIP(ctx, hipFree(dptr));
     return ZKHIP_OK;
@@ -188,6 +199,7 @@ int zkhip_host_alloc(zkhip_ctx* ctx, size_t bytes, void** hptr) {
 }
 int zkhip_host_free(zkhip_ctx* ctx, void* hptr) {
     if (!ctx) return ZKHIP_ERR_INVALID;
+    if (ctx->upload_stream) ZK_HIP(ctx, hipStreamSynchronize(ctx->upload_stream));   // a copy may still read the buffer
     ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
     ZK_HIP(ctx, hipHostFree(hptr));
     return ZKHIP_OK;
@@ -195,6 +207,31 @@ int zkhip_host_free(zkhip_ctx* ctx, void* hptr) {
 int zkhip_upload_async(zkhip_ctx* ctx, void* dptr, const void* host, size_t bytes) {
     if (!ctx || (!dptr && bytes) || (!host && bytes)) return ZKHIP_ERR_INVALID;
     ZK_HIP(ctx, hipMemcpyAsync(dptr, host, bytes, hipMemcpyHostToDevice, ctx->stream));
+    return ZKHIP_OK;
+}
+int zkhip_upload_overlapped(zkhip_ctx* ctx, void* dptr, const void* host, size_t bytes) {
+    if (!ctx || (!dptr && bytes) || (!host && bytes)) return ZKHIP_ERR_INVALID;
+    if (!ctx->upload_stream) {
+        ZK_HIP(ctx, hipSetDevice(ctx->device));
+        ZK_HIP(ctx, hipStreamCreateWithFlags(&ctx->upload_stream, hipStreamNonBlocking));
+        ZK_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_upload_base, hipEventDisableTiming));
+        ZK_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_upload_done, hipEventDisableTiming));
+    }
+    if (!ctx->upload_open) {
+        // the first copy after a fence: behind everything the compute stream holds now, which may still read the target
+        ZK_HIP(ctx, hipEventRecord(ctx->ev_upload_base, ctx->stream));
+        ZK_HIP(ctx, hipStreamWaitEvent(ctx->upload_stream, ctx->ev_upload_base, 0));
+        ctx->upload_open = true;
+    }
+    ZK_HIP(ctx, hipMemcpyAsync(dptr, host, bytes, hipMemcpyHostToDevice, ctx->upload_stream));
+    return ZKHIP_OK;
+}
+int zkhip_upload_fence(zkhip_ctx* ctx) {
+    if (!ctx) return ZKHIP_ERR_INVALID;
+    if (!ctx->upload_open) return ZKHIP_OK;
+    ZK_HIP(ctx, hipEventRecord(ctx->ev_upload_done, ctx->upload_stream));
+    ZK_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_upload_done, 0));
+    ctx->upload_open = false;
     return ZKHIP_OK;
 }
 int zkhip_upload(zkhip_ctx* ctx, void* dptr, const void* host, size_t bytes) {

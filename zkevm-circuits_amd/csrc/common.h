@@ -47,6 +47,10 @@ struct zkhip_ctx {
     size_t evalh_buf_bytes[4] = {0, 0, 0, 0};
     std::vector<uint32_t> evalh_linked;
     bool evalh_attr_set = false;
+    // transfer stream of zkhip_upload_overlapped: copies run beside the compute stream until zkhip_upload_fence joins them
+    hipStream_t upload_stream = nullptr;
+    hipEvent_t ev_upload_base = nullptr, ev_upload_done = nullptr;
+    bool upload_open = false;             // copies were issued since the last fence
 };
 
 namespace zkhip {

@@ -397,10 +397,10 @@ struct Builder {
         v_out = v;
         return flags;
     }
-    void emit(uint32_t flags, uint32_t dst, uint32_t a, uint32_t b = W_ZERO, uint32_t c = W_ZERO) {
+    void emit(uint32_t flags, uint32_t dst, uint32_t a, uint32_t b = W_ZERO, uint32_t c = W_ZERO, uint32_t d = W_ZERO) {
         double v;
-        flags = track(flags, dst, a, b, c, W_ZERO, v);
-        const uint32_t ins[IW] = {flags, dst, a, b, c, W_ZERO};
+        flags = track(flags, dst, a, b, c, d, v);
+        const uint32_t ins[IW] = {flags, dst, a, b, c, d};
         words.insert(words.end(), ins, ins + IW);
         // renormalise the value through a multiplication by one
         if (v > EV_LIMIT) emit(F_MUL, dst, dst == DST_ACC_V ? W_ACC : slot(dst), scalar(SC_ONE));
@@ -514,8 +514,90 @@ struct Builder {
     uint32_t sub(uint32_t a, uint32_t c) { const uint32_t d = fresh(); emit(F_SUB, d, a, W_ZERO, c); return slot(d); }
     uint32_t mul_add(uint32_t a, uint32_t b, uint32_t c) { const uint32_t d = fresh(); emit(F_MUL | F_ADD, d, a, b, c); return slot(d); }
     uint32_t mul_sub(uint32_t a, uint32_t b, uint32_t c) { const uint32_t d = fresh(); emit(F_MUL | F_SUB, d, a, b, c); return slot(d); }
-    // values[idx] = values[idx] * y + term
-    void fold(uint32_t term) { emit(F_MUL | F_ADD, DST_ACC_V, W_ACC, scalar(SC_Y), term); }
+
+    // ---- the terms of h --------------------------------------------------------------------------------------
+    // Upstream folds the N terms of the quotient numerator (gate polynomials, permutation and lookup identities) one
+    // after the other, values[idx] = values[idx] * y + term_i, so that h = sum_i y^(N-1-i) term_i.  Nearly every term is
+    // itself a product F * e with a factor shared by many terms: a selector (times a condition) in front of the
+    // constraints of a gate, l_0 / l_last / l_active in front of the argument identities.  With the powers of y as
+    // scalars of the call,
+    //     h = sum over factors F of  F * (sum of y^(N-1-i) e_i over the terms i with that factor)  +  the other terms,
+    // which is one product per term plus one per factor where the chain needs two per term.  Products are issued in
+    // pairs that share a reduction (a b + c d).  The field arithmetic is exact, so the value is the same.
+    bool grouping = false;
+    uint32_t n_terms = 0, sc_y0 = 0;
+    struct PairSum {               // a sum of products under construction: pairs go out as they complete
+        uint32_t sum = W_ZERO, px = 0, py = 0;
+        bool has_sum = false, has_pend = false;
+    };
+    std::map<uint32_t, PairSum> open_groups;   // by factor operand
+    PairSum total;
+    static bool in_memory(uint32_t o) { const uint32_t k = o >> 28; return k == K_COL || k == K_CONST || k == K_SCALAR; }
+    void pair_push(PairSum& A, uint32_t x, uint32_t y) {
+        if (!A.has_pend) {
+            A.px = x;
+            A.py = y;
+            A.has_pend = true;
+            return;
+        }
+        // a b + c d: a must be a value slot (the interpreter stages three memory operands)
+        uint32_t a = A.px, b2 = A.py, c = x, d = y;
+        if (in_memory(a)) std::swap(a, b2);
+        if (in_memory(a)) {
+            std::swap(a, c);
+            std::swap(b2, d);
+            if (in_memory(a)) std::swap(a, b2);
+        }
+        if (in_memory(a)) {
+            const uint32_t v = fresh();
+            emit(0, v, a);
+            a = slot(v);
+        }
+        const uint32_t t = fresh();
+        emit(F_MUL | F_ADD | F_MUL2, t, a, b2, c, d);
+        A.sum = A.has_sum ? add(A.sum, slot(t)) : slot(t);
+        A.has_sum = true;
+        A.has_pend = false;
+    }
+    uint32_t pair_close(PairSum& A) {
+        if (A.has_pend) {
+            A.sum = A.has_sum ? mul_add(A.px, A.py, A.sum) : mul(A.px, A.py);
+            A.has_sum = true;
+            A.has_pend = false;
+        }
+        return A.has_sum ? A.sum : W_ZERO;
+    }
+    // term_i = term
+    void fold(uint32_t term) {
+        if (!grouping) {
+            emit(F_MUL | F_ADD, DST_ACC_V, W_ACC, scalar(SC_Y), term);   // values[idx] = values[idx] * y + term
+            return;
+        }
+        pair_push(total, term, scalar(sc_y0 + n_terms++));
+    }
+    // term_i = e * factor
+    void fold_times(uint32_t e, uint32_t factor) {
+        if (!grouping) {
+            fold(mul(e, factor));
+            return;
+        }
+        pair_push(open_groups[factor], e, scalar(sc_y0 + n_terms++));
+    }
+    // no further term carries this factor
+    void close_group(uint32_t factor) {
+        auto it = open_groups.find(factor);
+        if (it == open_groups.end()) return;
+        const uint32_t s = pair_close(it->second);
+        open_groups.erase(it);
+        if (s != W_ZERO) pair_push(total, s, factor);
+    }
+    // the operand that holds h once every term is in
+    uint32_t finish_terms() {
+        if (!grouping) return W_ACC;
+        while (!open_groups.empty()) close_group(open_groups.begin()->first);
+        if (n_terms == 1 && total.has_pend && !total.has_sum) return total.px;   // a lone term: y^0 = 1
+        return pair_close(total);
+    }
 };
 
 // Lowers one GraphEvaluator into the builder.  `is_gates`: the root Horner accumulates into the running value.

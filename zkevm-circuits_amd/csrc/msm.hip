@@ -1095,18 +1095,25 @@ static int msm_pipeline(zkhip_ctx* ctx, MsmState& stt, const MsmTables& tb, cons
         for (int i = 0; i < MSM_PIPE; i++) ZK_HIP(ctx, hipEventCreateWithFlags(&stt.ev_out[i], hipEventDisableTiming));
     }
     // Three streams by role, shared by the workspaces: [0] recode / count / plan / scatter, [1] accumulate, [2] merge +
-    // reduce.  The accumulate kernels run back to back on their own stream at the lowest priority; the short kernels
-    // before and after them go to high-priority streams, so that the dispatcher hands them the workgroup slots that
-    // accumulate frees (at equal priority they starve next to it: 24 us of histogram take 560 us and delay the next
-    // accumulate, which waits for them).
+    // reduce.  The accumulate kernels run back to back on their own stream; the short kernels before and after them
+    // have streams of their own, so that they queue behind each other and not behind an accumulate (24 us of histogram
+    // take 560 us next to one, and delay the next accumulate, which waits for them).
+    // Stream priorities (accumulate lowest, the others highest) gain another 2 % in a batch that starts on an idle
+    // device, but a priority stream that waits on an event of the context's normal-priority stream while that stream
+    // still has hundreds of milliseconds of work queued was seen never to wake up: they stay off unless
+    // ZKHIP_MSM_STREAM_PRIORITY is set (measurements only).
     MsmWorkspace* pipe[MSM_PIPE];
     if (!stt.batch_streams[0]) {
+        static const bool with_priority = getenv("ZKHIP_MSM_STREAM_PRIORITY") != nullptr;
         int least = 0, greatest = 0;
         ZK_HIP(ctx, hipDeviceGetStreamPriorityRange(&least, &greatest));
-        static const bool flat = getenv("ZKHIP_MSM_FLAT_PRIORITY") != nullptr;   // measurements: all streams alike
-        const int prio[MSM_PIPE] = {greatest, flat ? greatest : least, greatest};
-        for (int i = 0; i < MSM_PIPE; i++)
-            ZK_HIP(ctx, hipStreamCreateWithPriority(&stt.batch_streams[i], hipStreamNonBlocking, prio[i]));
+        const int prio[MSM_PIPE] = {greatest, least, greatest};
+        for (int i = 0; i < MSM_PIPE; i++) {
+            if (with_priority)
+                ZK_HIP(ctx, hipStreamCreateWithPriority(&stt.batch_streams[i], hipStreamNonBlocking, prio[i]));
+            else
+                ZK_HIP(ctx, hipStreamCreateWithFlags(&stt.batch_streams[i], hipStreamNonBlocking));
+        }
     }
     for (int i = 0; i < MSM_PIPE; i++) {
         stt.ws[i].stream = stt.batch_streams[0];

@@ -17,7 +17,7 @@ _LIB = None
 EXPORTS = [
     "zkhip_create", "zkhip_destroy", "zkhip_last_error", "zkhip_version", "zkhip_set_stream", "zkhip_sync",
     "zkhip_dev_alloc", "zkhip_dev_free", "zkhip_mem_info", "zkhip_upload", "zkhip_download",
-    "zkhip_host_alloc", "zkhip_host_free", "zkhip_upload_async",
+    "zkhip_host_alloc", "zkhip_host_free", "zkhip_upload_async", "zkhip_upload_overlapped", "zkhip_upload_fence",
     "zkhip_field_binop", "zkhip_field_batch_invert", "zkhip_g1_add_affine", "zkhip_g1_multiples", "zkhip_probe_mad_rate",
     "zkhip_register_bases", "zkhip_release_bases", "zkhip_msm", "zkhip_msm_batch_dev", "zkhip_msm_range_dev",
     "zkhip_g1_sum_jacobian", "zkhip_g1_to_affine", "zkhip_g1_fft",
@@ -208,6 +208,17 @@ class Context:
         else:
             self._ck(self._l.zkhip_upload(self.h, C.c_void_p(dptr), _p(arr), C.c_size_t(arr.nbytes)))
         return dptr
+
+    def upload_overlapped(self, arr: np.ndarray, dptr: int):
+        """a copy from page-locked memory on the context's transfer stream: it runs beside the calls that follow, which
+        must not touch the target before `upload_fence`"""
+        if arr.dtype != np.uint64 or not arr.flags.c_contiguous or not self.is_pinned(arr):
+            raise ValueError("upload_overlapped takes a contiguous uint64 array in page-locked memory (host_zeros)")
+        self._ck(self._l.zkhip_upload_overlapped(self.h, C.c_void_p(dptr), _p(arr), C.c_size_t(arr.nbytes)))
+
+    def upload_fence(self):
+        """the calls that follow see every overlapped copy issued so far"""
+        self._ck(self._l.zkhip_upload_fence(self.h))
 
     def host_zeros(self, shape) -> np.ndarray:
         """a zeroed uint64 array in page-locked host memory (freed with the context): witness columns built in such

@@ -395,27 +395,56 @@ def create_proof(ctx, dom, params: ParamsKZG, pk: ProvingKey, advice, instance, 
         for col, d in zip(instance, inst):
             for v in col:
                 transcript.common_scalar(v)
-            ctx.upload(fr_limbs(list(col) + [0] * (n - len(col))), d)
+            padded = np.zeros((n, 4), dtype=np.uint64)           # the rows beyond the instance values are zero
+            if len(col):
+                padded[:len(col)] = fr_limbs(col)
+            ctx.upload(padded, d)
         # per phase: the phase's columns are assigned (from the challenges of the phases before), blinded, committed
         # and written, then the phase's challenges are squeezed
         challenges = [0] * cs.num_challenges
         for phase, columns, phase_challenges in cs.phases():
             assigned = advice(phase, list(challenges)) if callable(advice) else advice
-            for c in columns:                                   # the unusable rows of every column are blinding
-                col, d = assigned[c], adv[c]
+            for c in columns:
+                col = assigned[c]
                 if len(col) != usable or (isinstance(col, np.ndarray) and (col.dtype != np.uint64 or col.shape != (usable, 4))):
                     raise ValueError("an advice column holds the usable rows (integers, or (usable rows, 4) uint64 limbs)")
-                blinding = fr_limbs([rng.fr() for _ in range(n - usable)])
-                if isinstance(col, np.ndarray):
-                    ctx.upload(col, d)
-                    ctx.upload(blinding, d + usable * 32)
-                else:
-                    ctx.upload(np.concatenate([fr_limbs(col), blinding]), d)
+            points = []
+            if columns and all(isinstance(assigned[c], np.ndarray) and assigned[c].flags.c_contiguous
+                               and ctx.is_pinned(assigned[c]) for c in columns):
+                # page-locked columns: the copies of one group of columns run on the transfer stream while the group
+                # before it is committed, so that the link and the multiplier work side by side
+                GROUP = 32
+                stage = ctx.host_zeros((len(columns), n - usable, 4))      # the blinding rows of every column
+                try:
+                    pending = None
+                    for g0 in range(0, len(columns), GROUP):
+                        group = columns[g0:g0 + GROUP]
+                        for i, c in enumerate(group, g0):
+                            stage[i] = fr_limbs([rng.fr() for _ in range(n - usable)])
+                            ctx.upload_overlapped(assigned[c], adv[c])
+                            ctx.upload_overlapped(stage[i], adv[c] + usable * 32)
+                        if pending is not None:
+                            points.extend(params.commit_lagrange(pending, dist))
+                        ctx.upload_fence()
+                        pending = [adv[c] for c in group]
+                    points.extend(params.commit_lagrange(pending, dist))
+                finally:
+                    ctx.host_free(stage)
+            else:
+                for c in columns:                               # the unusable rows of every column are blinding
+                    col, d = assigned[c], adv[c]
+                    blinding = fr_limbs([rng.fr() for _ in range(n - usable)])
+                    if isinstance(col, np.ndarray):
+                        ctx.upload(col, d)
+                        ctx.upload(blinding, d + usable * 32)
+                    else:
+                        ctx.upload(np.concatenate([fr_limbs(col), blinding]), d)
+                if columns:
+                    points.extend(params.commit_lagrange([adv[c] for c in columns], dist))
             for _ in columns:
                 rng.fr()                                        # one Blind per column: drawn, unused by KZG
-            if columns:
-                for jac in params.commit_lagrange([adv[c] for c in columns], dist):
-                    transcript.write_point(jac)
+            for jac in points:
+                transcript.write_point(jac)
             for c in phase_challenges:
                 challenges[c] = transcript.squeeze_challenge()
         ch_limbs = fr_limbs(challenges) if challenges else np.zeros((0, 4), dtype=np.uint64)
@@ -589,8 +618,9 @@ def create_proof(ctx, dom, params: ParamsKZG, pk: ProvingKey, advice, instance, 
                 ctx.sync()
                 return out
             pieces = sharding.evaluate_h_by_cosets(dom.extended_k, dom.k, evaluate, dist)
-            torch.cuda.synchronize()
-            for cosets, rows in sharding.assemble_cosets(pieces, dom.k):
+            assembled = sharding.assemble_cosets(pieces, dom.k)    # row ranges of a coset are joined on torch's stream
+            torch.cuda.synchronize()                               # ... which the context's stream does not follow
+            for cosets, rows in assembled:
                 dom.cosets_to_extended_dev(rows.data_ptr(), cosets, d_h)
             ctx.sync()
         mark("quotient_pieces")
