@@ -364,6 +364,62 @@ def test_evaluate_h_program_is_built_once_per_shape(ctx, co):
     d.close()
 
 
+def _factored_terms_cs(lookups):
+    """Gate polynomials that take every path of the term grouping in the program builder: shared factors on the left and
+    on the right, a factor whose terms are interleaved with terms of another factor and with terms that have none, a
+    square, a product that two polynomials share (read twice, so it stays a term of its own), bare columns and sums as
+    polynomials, a selector times a condition in front of several constraints, a lone product at the end."""
+    from zkevm_circuits_amd.plonk import (ANY_ADVICE, ANY_FIXED, ANY_INSTANCE, Advice, Challenge, Constant, ConstraintSystem,
+                                         Fixed, Instance, Lookup, Product, Scaled, Sub, Sum)
+    cs = ConstraintSystem(num_fixed_columns=3, num_advice_columns=6, num_instance_columns=1, num_challenges=1)
+    a, b, c, d, e, f = (Advice(i) for i in range(6))
+    q0, q1, q2 = Fixed(0), Fixed(1), Fixed(2)
+    cond = Sub(Constant(1), Advice(5, 1))
+    shared = Product(a, Advice(1, -1))
+    cs.gates = [
+        [Product(q0, Sub(Product(a, b), c)), Sum(a, Advice(2, 1)), Product(Sub(d, e), q0), Product(q1, Sum(e, f))],
+        [Product(c, c), Product(q0, Scaled(Advice(3, -1), 12345)), shared, Product(q1, Sub(b, Challenge(0)))],
+        [Product(Product(q2, cond), Sub(a, b)), Product(Product(q2, cond), Sub(c, d)), d,
+         Product(Product(q2, cond), Product(e, Advice(0, 2)))],
+        [shared, Product(Sub(f, Constant(7)), q1), Product(q0, Instance(0)), Product(q0, Sum(a, Constant(3)))],
+        [Product(Sum(a, b), Sum(c, d))],
+    ]
+    for i in range(lookups):
+        cs.lookups.append(Lookup([Product(q0, Advice(i)), Sum(b, Advice(i + 1, 1))], [Fixed(1), Advice(4)]))
+    cs.permutation_columns = [(ANY_ADVICE, 0), (ANY_ADVICE, 2), (ANY_FIXED, 1), (ANY_INSTANCE, 0)]
+    return cs
+
+
+@pytest.mark.parametrize("lookups", [0, 2])
+def test_evaluate_h_factored_terms_vs_oracle(ctx, co, lookups):
+    """h = sum over factors of F * (weighted sum of the co-factors) + the chain of the other terms: the same values as
+    upstream's term-by-term chain, which the oracle evaluates"""
+    cs = _factored_terms_cs(lookups)
+    for k in (6, 9):
+        d, od = zk.Domain(ctx, cs.degree(), k), co.Domain(cs.degree(), k, threads=8)
+        call, coeff, ext = _random_call(cs, np.random.default_rng(40 + k + lookups), d.n, d.extended_len, od)
+        call.advice, call.instance, call.lookups = ext["advice"], ext["instance"], ext["lookups"]
+        desc = call.build(ffi.MEM_HOST, ffi.FORM_EXTENDED)
+        exp = od.evaluate_h(desc)
+        assert np.array_equal(d.evaluate_h(desc), exp)
+        # a window of rows of two cosets in compact layout runs the same program
+        e = d.extended_k - k
+        if e >= 1:
+            cosets = [0, (1 << e) - 1]
+            call.cosets = cosets
+            compact = lambda a: np.ascontiguousarray(np.stack([a[j::1 << e] for j in cosets], axis=1).reshape(-1, 4))
+            call.fixed = [compact(x) for x in call.fixed]
+            call.advice = [compact(x) for x in ext["advice"]]
+            call.instance = [compact(x) for x in ext["instance"]]
+            call.lookups = [tuple(compact(x) for x in t) for t in ext["lookups"]]
+            call.perm_sigma = [compact(x) for x in call.perm_sigma]
+            call.perm_z = [compact(x) for x in call.perm_z]
+            call.l0, call.l_last, call.l_active = compact(call.l0), compact(call.l_last), compact(call.l_active)
+            got = d.evaluate_h(call.build(ffi.MEM_HOST, ffi.FORM_EXTENDED))
+            assert np.array_equal(got, compact(exp))
+        d.close()
+
+
 def _additive_cs(degree, rotations, width):
     """Gates that are long sums of columns and sums of sums times sums: exercises the magnitude bookkeeping of the
     interpreter's lazy arithmetic (sums of many 32 p column values) and extended domains of 2^1 .. 2^4 times n."""

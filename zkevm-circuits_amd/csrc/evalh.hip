@@ -26,6 +26,8 @@
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
+#include <map>
 #include <memory>
 #include "domain.h"
 #include "wide.cuh"
@@ -522,17 +524,44 @@ struct Builder {
     // constraints of a gate, l_0 / l_last / l_active in front of the argument identities.  With the powers of y as
     // scalars of the call,
     //     h = sum over factors F of  F * (sum of y^(N-1-i) e_i over the terms i with that factor)  +  the other terms,
-    // which is one product per term plus one per factor where the chain needs two per term.  Products are issued in
-    // pairs that share a reduction (a b + c d).  The field arithmetic is exact, so the value is the same.
+    // which is one product per term plus one per factor where the chain needs two per term; the products of a group go
+    // out in pairs that share a reduction (a b + c d).  Terms without a shared factor keep the chain among themselves,
+    // H = H * y^gap + term, which the peephole pass fuses with the term's own last product as before; H joins the sum
+    // with the weight of its last term.  The field arithmetic is exact, so the value is the same.
+    // The running-value register holds H while the gates are lowered, afterwards (or when no gate term is outside a
+    // group) the partial sum of the one group that is open: a value in the register costs no slot.
     bool grouping = false;
+    std::vector<std::pair<const char*, size_t>> marks;   // section boundaries (instruction index), for the debug print
+    void mark(const char* name) { marks.push_back({name, words.size() / IW}); }
     uint32_t n_terms = 0, sc_y0 = 0;
+    static constexpr uint32_t GAP_TAG = 1u << 24;      // scalar operands y^gap until finish_terms knows where they live
+    std::vector<uint32_t> gaps;                        // exponents of the y^gap scalars, in order of first use
     struct PairSum {               // a sum of products under construction: pairs go out as they complete
         uint32_t sum = W_ZERO, px = 0, py = 0;
-        bool has_sum = false, has_pend = false;
+        bool has_sum = false, has_pend = false, in_acc = false;
     };
     std::map<uint32_t, PairSum> open_groups;   // by factor operand
     PairSum total;
+    bool chain_reserved = false;   // the gates graph is being lowered and has terms outside groups: H is still growing
+    bool chain_started = false, acc_taken = false, has_stash = false;
+    uint32_t chain_last = 0, stash = 0;
     static bool in_memory(uint32_t o) { const uint32_t k = o >> 28; return k == K_COL || k == K_CONST || k == K_SCALAR; }
+    uint32_t to_slot(uint32_t w) {
+        const uint32_t v = fresh();
+        emit(0, v, w);
+        return slot(v);
+    }
+    // t = x y + px py as one instruction (a must be a value slot or the register: three memory operands are staged)
+    void emit_pair(uint32_t dst, uint32_t a, uint32_t b2, uint32_t c, uint32_t d) {
+        if (in_memory(a)) std::swap(a, b2);
+        if (in_memory(a)) {
+            std::swap(a, c);
+            std::swap(b2, d);
+            if (in_memory(a)) std::swap(a, b2);
+        }
+        if (in_memory(a)) a = to_slot(a);
+        emit(F_MUL | F_ADD | F_MUL2, dst, a, b2, c, d);
+    }
     void pair_push(PairSum& A, uint32_t x, uint32_t y) {
         if (!A.has_pend) {
             A.px = x;
@@ -540,63 +569,136 @@ struct Builder {
             A.has_pend = true;
             return;
         }
-        // a b + c d: a must be a value slot (the interpreter stages three memory operands)
-        uint32_t a = A.px, b2 = A.py, c = x, d = y;
-        if (in_memory(a)) std::swap(a, b2);
-        if (in_memory(a)) {
-            std::swap(a, c);
-            std::swap(b2, d);
-            if (in_memory(a)) std::swap(a, b2);
-        }
-        if (in_memory(a)) {
-            const uint32_t v = fresh();
-            emit(0, v, a);
-            a = slot(v);
-        }
-        const uint32_t t = fresh();
-        emit(F_MUL | F_ADD | F_MUL2, t, a, b2, c, d);
-        A.sum = A.has_sum ? add(A.sum, slot(t)) : slot(t);
-        A.has_sum = true;
         A.has_pend = false;
+        if (A.in_acc && !A.has_sum) {
+            emit_pair(DST_ACC_V, A.px, A.py, x, y);
+        } else {
+            const uint32_t t = fresh();
+            emit_pair(t, A.px, A.py, x, y);
+            if (A.in_acc) emit(F_ADD, DST_ACC_V, W_ACC, W_ZERO, slot(t));
+            else A.sum = A.has_sum ? add(A.sum, slot(t)) : slot(t);
+        }
+        if (A.in_acc) A.sum = W_ACC;
+        A.has_sum = true;
     }
     uint32_t pair_close(PairSum& A) {
         if (A.has_pend) {
-            A.sum = A.has_sum ? mul_add(A.px, A.py, A.sum) : mul(A.px, A.py);
-            A.has_sum = true;
             A.has_pend = false;
+            if (A.in_acc) {
+                if (A.has_sum) emit(F_MUL | F_ADD, DST_ACC_V, A.px, A.py, W_ACC);
+                else emit(F_MUL, DST_ACC_V, A.px, A.py);
+                A.sum = W_ACC;
+            } else {
+                A.sum = A.has_sum ? mul_add(A.px, A.py, A.sum) : mul(A.px, A.py);
+            }
+            A.has_sum = true;
         }
         return A.has_sum ? A.sum : W_ZERO;
     }
-    // term_i = term
-    void fold(uint32_t term) {
+    // total += x * y with x in the register, which is about to be reused: nothing may stay pending on it
+    void total_add_acc_times(uint32_t y) {
+        if (total.has_pend) {
+            pair_push(total, W_ACC, y);
+        } else {
+            total.sum = total.has_sum ? mul_add(W_ACC, y, total.sum) : mul(W_ACC, y);
+            total.has_sum = true;
+        }
+    }
+    // The terms are numbered in upstream's order; they may be issued in any order (terms outside groups: ascending).
+    uint32_t reserve_terms(uint32_t k) {
+        const uint32_t first = n_terms;
+        n_terms += k;
+        return first;
+    }
+    uint32_t gap_scalar(uint32_t g) {
+        if (g == 1) return scalar(SC_Y);
+        for (size_t q = 0; q < gaps.size(); q++)
+            if (gaps[q] == g) return scalar(GAP_TAG + (uint32_t)q);
+        gaps.push_back(g);
+        return scalar(GAP_TAG + (uint32_t)gaps.size() - 1);
+    }
+    // term i = term (chain form: the next term of the chain, i is not looked at)
+    void fold_at(uint32_t i, uint32_t term) {
         if (!grouping) {
             emit(F_MUL | F_ADD, DST_ACC_V, W_ACC, scalar(SC_Y), term);   // values[idx] = values[idx] * y + term
             return;
         }
-        pair_push(total, term, scalar(sc_y0 + n_terms++));
-    }
-    // term_i = e * factor
-    void fold_times(uint32_t e, uint32_t factor) {
-        if (!grouping) {
-            fold(mul(e, factor));
+        if (acc_taken) {                      // the register serves a group: this term joins the sum on its own
+            pair_push(total, term, scalar(sc_y0 + i));
             return;
         }
-        pair_push(open_groups[factor], e, scalar(sc_y0 + n_terms++));
+        if (!chain_started) emit(0, DST_ACC_V, term);
+        else emit(F_MUL | F_ADD, DST_ACC_V, W_ACC, gap_scalar(i - chain_last), term);
+        chain_started = true;
+        chain_last = i;
     }
+    // H joins the sum; the register is free again
+    void end_chain() {
+        if (!chain_started) return;
+        total_add_acc_times(scalar(sc_y0 + chain_last));
+        chain_started = false;
+    }
+    // term i = e * factor
+    void fold_times_at(uint32_t i, uint32_t e, uint32_t factor) {
+        if (!grouping) {
+            fold_at(i, mul(e, factor));
+            return;
+        }
+        auto it = open_groups.find(factor);
+        if (it == open_groups.end()) {
+            it = open_groups.emplace(factor, PairSum()).first;
+            if (!acc_taken) {
+                // the register goes to this group's partial sum.  While the gates are lowered H steps aside into a slot
+                // (it rests while the members of the group are issued back to back); afterwards H is complete
+                if (chain_started && chain_reserved) {
+                    stash = to_slot(W_ACC);
+                    has_stash = true;
+                } else {
+                    end_chain();
+                }
+                it->second.in_acc = true;
+                acc_taken = true;
+            }
+        }
+        pair_push(it->second, e, scalar(sc_y0 + i));
+    }
+    void fold(uint32_t term) { fold_at(reserve_terms(1), term); }
     // no further term carries this factor
     void close_group(uint32_t factor) {
         auto it = open_groups.find(factor);
         if (it == open_groups.end()) return;
         const uint32_t s = pair_close(it->second);
+        const bool in_acc = it->second.in_acc;
         open_groups.erase(it);
-        if (s != W_ZERO) pair_push(total, s, factor);
+        if (in_acc) {
+            acc_taken = false;
+            if (s != W_ZERO) total_add_acc_times(factor);
+            if (has_stash) {
+                emit(0, DST_ACC_V, stash);
+                has_stash = false;
+            }
+        } else if (s != W_ZERO) {
+            pair_push(total, s, factor);
+        }
     }
     // the operand that holds h once every term is in
     uint32_t finish_terms() {
         if (!grouping) return W_ACC;
         while (!open_groups.empty()) close_group(open_groups.begin()->first);
-        if (n_terms == 1 && total.has_pend && !total.has_sum) return total.px;   // a lone term: y^0 = 1
-        return pair_close(total);
+        uint32_t result;
+        if (chain_started && !total.has_sum && !total.has_pend && chain_last + 1 == n_terms) {
+            result = W_ACC;                   // nothing but the chain, its last term weighs y^0
+        } else {
+            end_chain();
+            result = pair_close(total);
+        }
+        // the y^gap scalars follow the n_terms weights
+        for (size_t q = 0; q + IW <= words.size(); q += IW)
+            for (size_t k = 2; k < IW; k++) {
+                uint32_t& w = words[q + k];
+                if ((w >> 28) == K_SCALAR && (w & 0x0fffffffu) >= GAP_TAG) w = scalar(sc_y0 + n_terms + ((w & 0x0fffffffu) - GAP_TAG));
+            }
+        return result;
     }
 };
 
@@ -684,9 +786,38 @@ struct Lowering {
                 }
                 done[t] = 1;
                 st.pop_back();
+            } else if (terms_root && t == root) {
+                // the root of the gates graph, previous_value * y^k + sum parts_j y^(k-1-j): every part is a term of h
+                if (st.back().stage == 0) {
+                    plan_root_terms(c);
+                    st.back().stage = 1;
+                }
+                bool pushed = false;
+                while (st.back().stage - 1 < root_order.size()) {
+                    const uint32_t j = root_order[st.back().stage - 1];
+                    const RootPart& rp = root_parts[j];
+                    if (rp.group < 0) {
+                        if (dep(c.parts[j])) { pushed = true; break; }
+                        uint32_t pw;
+                        if (!operand(c.parts[j], pw)) return false;
+                        b.fold_at(root_term0 + j, pw);
+                    } else {
+                        if (dep(rp.factor) || dep(rp.other)) { pushed = true; break; }
+                        uint32_t fw, ew;
+                        if (!operand(rp.factor, fw) || !operand(rp.other, ew)) return false;
+                        b.fold_times_at(root_term0 + j, ew, fw);
+                        if (--group_left[rp.group] == 0) b.close_group(fw);
+                    }
+                    st.back().stage++;
+                }
+                if (!err.empty()) return false;
+                if (pushed) continue;
+                val[t] = W_ZERO;        // the value lives in the builder's terms
+                done[t] = 1;
+                st.pop_back();
             } else {
                 // Horner: stage 0 = start / factor dependencies, then one part at a time
-                const bool to_acc = is_gates && t == root;
+                const bool to_acc = is_gates && t == root && !b.grouping;
                 if (st.back().stage == 0) {
                     if (dep(c.start) || dep(c.factor)) { if (!err.empty()) return false; continue; }
                     uint32_t s;
@@ -715,6 +846,89 @@ struct Lowering {
         return true;
     }
 
+    // ---- terms of the root Horner ------------------------------------------------------------------------
+    // A part that is a product nobody else reads, F * e, joins the group of its factor F when another part shares that
+    // factor; the factor with the most parts is served first (ties: the lower key), so that `q * cond` in front of the
+    // constraints of a gate wins over a column that happens to occur twice.
+    struct RootPart {
+        int32_t group = -1;
+        VS factor{0, 0, 0}, other{0, 0, 0};
+    };
+    bool terms_root = false;
+    std::vector<RootPart> root_parts;
+    std::vector<uint32_t> group_left;
+    std::vector<uint32_t> root_order;   // the parts in the order they are issued: the members of a group back to back, so
+                                        // that one partial sum is live at a time
+    uint32_t root_term0 = 0;
+    static uint64_t vs_key(const VS& v) { return ((uint64_t)v.kind << 56) ^ ((uint64_t)v.a << 24) ^ (uint64_t)v.b; }
+    void plan_root_terms(const Calc& c) {
+        const size_t np = c.parts.size();
+        root_parts.assign(np, RootPart());
+        // how often every calculation is read
+        std::vector<uint32_t> uses(calcs.size(), 0);
+        auto use = [&](const VS& v) { if (v.kind == 1 && v.a < calcs.size()) uses[v.a]++; };
+        for (const Calc& k : calcs) {
+            if (k.op == 6) {
+                use(k.start);
+                use(k.factor);
+                for (const VS& v : k.parts) use(v);
+            } else {
+                use(k.src[0]);
+                if (k.op <= 2) use(k.src[1]);
+            }
+        }
+        struct Cand { size_t part; VS f[2]; };
+        std::vector<Cand> cand;
+        for (size_t j = 0; j < np; j++) {
+            const VS& v = c.parts[j];
+            if (v.kind != 1 || v.a >= calcs.size() || uses[v.a] != 1) continue;
+            const Calc& m = calcs[v.a];
+            if (m.op != 2 || vs_key(m.src[0]) == vs_key(m.src[1])) continue;
+            cand.push_back({j, {m.src[0], m.src[1]}});
+        }
+        std::vector<uint8_t> taken(cand.size(), 0);
+        for (;;) {
+            std::map<uint64_t, uint32_t> count;
+            for (size_t q = 0; q < cand.size(); q++)
+                if (!taken[q]) { count[vs_key(cand[q].f[0])]++; count[vs_key(cand[q].f[1])]++; }
+            uint64_t best = 0;
+            uint32_t best_n = 1;
+            for (const auto& kv : count)
+                if (kv.second > best_n) { best = kv.first; best_n = kv.second; }
+            if (best_n < 2) break;
+            const int32_t gid = (int32_t)group_left.size();
+            group_left.push_back(0);
+            for (size_t q = 0; q < cand.size(); q++) {
+                if (taken[q]) continue;
+                const int side = vs_key(cand[q].f[0]) == best ? 0 : (vs_key(cand[q].f[1]) == best ? 1 : -1);
+                if (side < 0) continue;
+                RootPart& rp = root_parts[cand[q].part];
+                rp.group = gid;
+                rp.factor = cand[q].f[side];
+                rp.other = cand[q].f[1 - side];
+                group_left[gid]++;
+                taken[q] = 1;
+            }
+        }
+        root_term0 = b.reserve_terms((uint32_t)np);
+        for (size_t j = 0; j < np; j++)
+            if (root_parts[j].group < 0) b.chain_reserved = true;   // the register carries the chain of those parts
+        std::vector<std::vector<uint32_t>> members(group_left.size());
+        for (size_t j = 0; j < np; j++)
+            if (root_parts[j].group >= 0) members[root_parts[j].group].push_back((uint32_t)j);
+        std::vector<uint8_t> issued(group_left.size(), 0);
+        root_order.clear();
+        for (size_t j = 0; j < np; j++) {
+            const int32_t gi = root_parts[j].group;
+            if (gi < 0) {
+                root_order.push_back((uint32_t)j);
+            } else if (!issued[gi]) {
+                issued[gi] = 1;
+                root_order.insert(root_order.end(), members[gi].begin(), members[gi].end());
+            }
+        }
+    }
+
     // returns the operand word of the graph's value (W_ACC for a gates graph rooted in a Horner)
     bool run(uint32_t& result) {
         if (!parse_graph(g, calcs, err)) return false;
@@ -724,6 +938,7 @@ struct Lowering {
         val.assign(calcs.size(), 0);
         done.assign(calcs.size(), 0);
         root = (uint32_t)calcs.size() - 1;
+        terms_root = is_gates && b.grouping && calcs[root].op == 6 && calcs[root].start.kind == 10 && calcs[root].factor.kind == 9;
         if (!schedule(root)) return false;
         result = val[root];
         return true;
@@ -845,6 +1060,8 @@ struct EvalhProgram {
     std::vector<uint64_t> consts;    // merged constant table, already in the 2^261 Montgomery domain
     std::vector<int32_t> rots;
     uint32_t result = W_ACC, lds_slots = 1, n_slots = 1, n_cols = 0;
+    uint32_t n_terms = 0, sc_y0 = 0;     // scalars sc_y0 + i hold y^(n_terms - 1 - i): the weight of term i of h
+    std::vector<uint32_t> gaps;          // followed by y^gaps[q]
     uint64_t stats[4] = {0, 0, 0, 0};
 };
 
@@ -906,21 +1123,42 @@ static int build_program(zkhip_ctx* ctx, const zkhip_evalh_desc* desc, bool lagr
     const uint32_t c_l0 = L.c_l0, c_last = L.c_l0 + 1, c_active = L.c_l0 + 2;
     Builder b;
     const uint32_t ONE = Builder::scalar(SC_ONE), BETA = Builder::scalar(SC_BETA), GAMMA = Builder::scalar(SC_GAMMA);
+    // scalars after the challenges: beta * delta^c per permutation column, then the powers of y (filled in per call)
+    const uint32_t sc_perm0 = SC_CHALLENGE0 + desc->num_challenges;
+    // ZKHIP_EVALH_CHAIN: the terms as upstream's chain h = h * y + term (measurements and differential tests)
+    static const bool chain = getenv("ZKHIP_EVALH_CHAIN") != nullptr;
+    b.grouping = !chain;
+    b.sc_y0 = sc_perm0 + (desc->num_perm_sets ? desc->num_perm_columns : 0);
     // ---- 1. custom gates -----------------------------------------------------------------------------
     if (desc->custom_gates) {
         const zkhip_graph* g = desc->custom_gates;
         Lowering lw(b, g, desc, true);
         uint32_t res;
         if (!lw.run(res)) return set_error(ctx, ZKHIP_ERR_INVALID, "evaluate_h: %s", lw.err.c_str());
-        if (res != W_ACC) b.emit(0, DST_ACC_V, res);   // a gates graph whose value is not the running Horner
+        if (b.grouping) {
+            if (!lw.terms_root) b.fold(res);           // the value of the graph is the first term
+            b.chain_reserved = false;                  // the groups that follow may use the register
+        } else if (res != W_ACC) {
+            b.emit(0, DST_ACC_V, res);                 // a gates graph whose value is not the running Horner
+        }
     }
 
     // ---- 2. permutation argument ---------------------------------------------------------------------
-    // scalars after the challenges: beta * delta^c per permutation column (filled in per call)
-    const uint32_t sc_perm0 = SC_CHALLENGE0 + desc->num_challenges;
+    b.mark("gates");
+    // ---- 2. + 3. permutation and lookup arguments ---------------------------------------------------------
+    // Every identity is (expression) * l_0, l_last or l_active.  The terms get their numbers in upstream's order
+    // (permutation argument, then lookup after lookup); they are issued factor by factor, so that one partial sum is
+    // live at a time (a lookup's a' - s' is then formed twice, a subtraction).
+    struct Term {
+        uint32_t idx;
+        std::function<int(uint32_t&)> make;    // emits the expression, returns its operand
+    };
+    std::vector<Term> by_factor[3];            // 0: l_0, 1: l_last, 2: l_active
+    const uint32_t l_cols[3] = {c_l0, c_last, c_active};
+    auto term = [&](int f, std::function<int(uint32_t&)> make) { by_factor[f].push_back({b.reserve_terms(1), std::move(make)}); };
+    std::vector<uint32_t> pcol(desc->num_perm_sets ? desc->num_perm_columns : 0);
     if (desc->num_perm_sets) {
         const uint32_t c_x = L.c_x, c_z0 = L.c_z0, c_sigma0 = L.c_sigma0;
-        std::vector<uint32_t> pcol(desc->num_perm_columns);
         for (uint32_t c = 0; c < desc->num_perm_columns; c++) {
             const uint32_t kind = desc->perm_column_kind[c], ci = desc->perm_column_index[c];
             if (kind == 2) { ZK_CHECK(ctx, ci < desc->num_fixed, "evaluate_h: permutation fixed column out of range"); pcol[c] = ci; }
@@ -931,58 +1169,99 @@ static int build_program(zkhip_ctx* ctx, const zkhip_evalh_desc* desc, bool lagr
         const int32_t last_rot = -((int32_t)desc->blinding_factors + 1);
         const uint32_t nsets = desc->num_perm_sets;
         // l_0(X) * (1 - z_0(X))
-        b.fold(b.mul(b.sub(ONE, b.col(c_z0, 0)), b.col(c_l0, 0)));
+        term(0, [&b, ONE, c_z0](uint32_t& e) { e = b.sub(ONE, b.col(c_z0, 0)); return (int)ZKHIP_OK; });
         // l_last(X) * (z_l(X)^2 - z_l(X))
-        {
+        term(1, [&b, c_z0, nsets](uint32_t& e) {
             const uint32_t zl = b.col(c_z0 + nsets - 1, 0);
-            b.fold(b.mul(b.mul_sub(zl, zl, zl), b.col(c_last, 0)));
-        }
+            e = b.mul_sub(zl, zl, zl);
+            return (int)ZKHIP_OK;
+        });
         // l_0(X) * (z_i(X) - z_{i-1}(omega^last X))
         for (uint32_t s = 1; s < nsets; s++)
-            b.fold(b.mul(b.sub(b.col(c_z0 + s, 0), b.col(c_z0 + s - 1, last_rot)), b.col(c_l0, 0)));
+            term(0, [&b, c_z0, s, last_rot](uint32_t& e) {
+                e = b.sub(b.col(c_z0 + s, 0), b.col(c_z0 + s - 1, last_rot));
+                return (int)ZKHIP_OK;
+            });
         // l_active(X) * (z_i(omega X) prod (p + beta s_j + gamma) - z_i(X) prod (p + delta^j beta X + gamma));
         // current_delta of column c on row idx = beta * zeta * extended_omega^idx * delta^c = (beta * delta^c) * X[idx]
-        for (uint32_t s = 0; s < nsets; s++) {
-            const uint32_t c0 = s * desc->perm_chunk_len, c1 = std::min(c0 + desc->perm_chunk_len, desc->num_perm_columns);
-            uint32_t left = b.col(c_z0 + s, 1), right = b.col(c_z0 + s, 0);
-            for (uint32_t c = c0; c < c1; c++) {
-                const uint32_t val = b.col(pcol[c], 0);
-                left = b.mul(left, b.add(b.mul_add(BETA, b.col(c_sigma0 + c, 0), val), GAMMA));
-                right = b.mul(right, b.add(b.mul_add(b.col(c_x, 0), Builder::scalar(sc_perm0 + c), val), GAMMA));
-            }
-            b.fold(b.mul(b.sub(left, right), b.col(c_active, 0)));
-        }
+        for (uint32_t s = 0; s < nsets; s++)
+            term(2, [&b, &pcol, desc, s, c_z0, c_x, c_sigma0, sc_perm0, BETA, GAMMA](uint32_t& e) {
+                const uint32_t c0 = s * desc->perm_chunk_len, c1 = std::min(c0 + desc->perm_chunk_len, desc->num_perm_columns);
+                uint32_t left = b.col(c_z0 + s, 1), right = b.col(c_z0 + s, 0);
+                for (uint32_t c = c0; c < c1; c++) {
+                    const uint32_t val = b.col(pcol[c], 0);
+                    left = b.mul(left, b.add(b.mul_add(BETA, b.col(c_sigma0 + c, 0), val), GAMMA));
+                    right = b.mul(right, b.add(b.mul_add(b.col(c_x, 0), Builder::scalar(sc_perm0 + c), val), GAMMA));
+                }
+                e = b.sub(left, right);
+                return (int)ZKHIP_OK;
+            });
     }
-
-    // ---- 3. lookup arguments -------------------------------------------------------------------------
     for (uint32_t i = 0; i < desc->num_lookups; i++) {
         const zkhip_graph* g = &desc->lookups[i].graph;
         const uint32_t c_z = L.c_lk0 + 3 * i, c_a = c_z + 1, c_s = c_z + 2;
-        Lowering lw(b, g, desc, false);
-        uint32_t table_value;
-        if (!lw.run(table_value)) return set_error(ctx, ZKHIP_ERR_INVALID, "evaluate_h: %s", lw.err.c_str());
-        const uint32_t Z = b.col(c_z, 0), A = b.col(c_a, 0), S = b.col(c_s, 0);
-        const uint32_t a_minus_s = b.sub(A, S);
         // l_0(X) * (1 - z(X))
-        b.fold(b.mul(b.sub(ONE, Z), b.col(c_l0, 0)));
+        term(0, [&b, ONE, c_z](uint32_t& e) { e = b.sub(ONE, b.col(c_z, 0)); return (int)ZKHIP_OK; });
         // l_last(X) * (z(X)^2 - z(X))
-        b.fold(b.mul(b.mul_sub(Z, Z, Z), b.col(c_last, 0)));
+        term(1, [&b, c_z](uint32_t& e) {
+            const uint32_t Z = b.col(c_z, 0);
+            e = b.mul_sub(Z, Z, Z);
+            return (int)ZKHIP_OK;
+        });
         // l_active(X) * (z(omega X) (a'(X) + beta) (s'(X) + gamma) - z(X) * table_value)
-        {
-            const uint32_t left = b.mul(b.mul(b.col(c_z, 1), b.add(A, BETA)), b.add(S, GAMMA));
-            const uint32_t diff = b.sub(left, b.mul(Z, table_value));
-            b.fold(b.mul(diff, b.col(c_active, 0)));
-        }
+        term(2, [&b, ctx, g, desc, c_z, c_a, c_s, BETA, GAMMA](uint32_t& e) {
+            Lowering lw(b, g, desc, false);
+            uint32_t table_value;
+            if (!lw.run(table_value)) return set_error(ctx, ZKHIP_ERR_INVALID, "evaluate_h: %s", lw.err.c_str());
+            const uint32_t left = b.mul(b.mul(b.col(c_z, 1), b.add(b.col(c_a, 0), BETA)), b.add(b.col(c_s, 0), GAMMA));
+            e = b.sub(left, b.mul(b.col(c_z, 0), table_value));
+            return (int)ZKHIP_OK;
+        });
         // l_0(X) * (a'(X) - s'(X))
-        b.fold(b.mul(a_minus_s, b.col(c_l0, 0)));
+        term(0, [&b, c_a, c_s](uint32_t& e) { e = b.sub(b.col(c_a, 0), b.col(c_s, 0)); return (int)ZKHIP_OK; });
         // l_active(X) * (a'(X) - s'(X)) * (a'(X) - a'(omega^-1 X))
-        b.fold(b.mul(b.mul(a_minus_s, b.sub(A, b.col(c_a, -1))), b.col(c_active, 0)));
+        term(2, [&b, c_a, c_s](uint32_t& e) {
+            const uint32_t A = b.col(c_a, 0);
+            e = b.mul(b.sub(A, b.col(c_s, 0)), b.sub(A, b.col(c_a, -1)));
+            return (int)ZKHIP_OK;
+        });
+    }
+    if (b.grouping) {
+        for (int f = 0; f < 3; f++) {
+            for (const Term& t : by_factor[f]) {
+                uint32_t e;
+                const int rc = t.make(e);
+                if (rc) return rc;
+                b.fold_times_at(t.idx, e, b.col(l_cols[f], 0));
+            }
+            if (!by_factor[f].empty()) b.close_group(b.col(l_cols[f], 0));
+            b.mark(f == 0 ? "l_0 terms" : f == 1 ? "l_last terms" : "l_active terms");
+        }
+    } else {
+        // the chain takes its terms in upstream's order
+        std::vector<std::pair<uint32_t, int>> seq;
+        std::vector<const Term*> where;
+        for (int f = 0; f < 3; f++)
+            for (const Term& t : by_factor[f]) {
+                seq.push_back({t.idx, f});
+                where.push_back(&t);
+            }
+        std::vector<size_t> ord(seq.size());
+        for (size_t q = 0; q < ord.size(); q++) ord[q] = q;
+        std::sort(ord.begin(), ord.end(), [&](size_t x, size_t y) { return seq[x].first < seq[y].first; });
+        for (size_t q : ord) {
+            uint32_t e;
+            const int rc = where[q]->make(e);
+            if (rc) return rc;
+            b.fold_times_at(seq[q].first, e, b.col(l_cols[seq[q].second], 0));
+        }
     }
     ZK_CHECK(ctx, L.total < (1u << 16) && b.rots.size() < (1u << 12), "evaluate_h: too many columns or rotations");
     ZK_CHECK(ctx, b.n_virtual < (1u << 28), "evaluate_h: program too large");
 
     // ---- peephole fusion, slots -----------------------------------------------------------------------
-    uint32_t result = W_ACC, lds_slots = 1, n_slots = 1;
+    uint32_t result = b.finish_terms(), lds_slots = 1, n_slots = 1;
+    ZK_CHECK(ctx, b.n_virtual < (1u << 28), "evaluate_h: program too large");
     Builder::FuseStats fuse;
     if (do_fuse) ZK_CHECK(ctx, b.fuse_products(result, fuse), "evaluate_h: internal error, a fused value left its bound");
     assign_slots(b.words, result, b.n_virtual, lds_budget, lds_slots, n_slots);
@@ -998,6 +1277,22 @@ static int build_program(zkhip_ctx* ctx, const zkhip_evalh_desc* desc, bool lagr
             if ((w[q] >> 28) == K_SLOT && (w[q] & 0x0fffffffu) >= lds_slots) nspill++;
         }
         if (w[1] != DST_ACC_V && w[1] >= lds_slots) nspill++;
+    }
+    if (getenv("ZKHIP_DEBUG") && ni > 100) {
+        // spill accesses per section (the marks are instruction indices before the peephole pass: approximate)
+        size_t from = 0;
+        for (const auto& m : b.marks) {
+            size_t acc = 0;
+            const size_t to = std::min(ni, m.second);
+            for (size_t pc = from; pc < to; pc++) {
+                const uint32_t* w = &b.words[pc * IW];
+                for (size_t q = 2; q < IW; q++)
+                    if ((w[q] >> 28) == K_SLOT && (w[q] & 0x0fffffffu) >= lds_slots) acc++;
+                if (w[1] != DST_ACC_V && w[1] >= lds_slots) acc++;
+            }
+            fprintf(stderr, "[zkhip]   %s: instructions [%zu, %zu), %zu spill accesses\n", m.first, from, to, acc);
+            from = to;
+        }
     }
     if (getenv("ZKHIP_DEBUG"))
         fprintf(stderr, "[zkhip] evaluate_h program: %zu instructions (%zu products, %zu of them second products sharing a "
@@ -1018,6 +1313,9 @@ static int build_program(zkhip_ctx* ctx, const zkhip_evalh_desc* desc, bool lagr
     out.lds_slots = lds_slots;
     out.n_slots = n_slots;
     out.n_cols = L.total;
+    out.n_terms = b.grouping ? b.n_terms : 0;
+    out.sc_y0 = b.sc_y0;
+    out.gaps = b.gaps;
     out.stats[0] = ni;
     out.stats[1] = nmul;
     out.stats[2] = ncol;
@@ -1176,7 +1474,7 @@ extern "C" int zkhip_evaluate_h(zkhip_domain* dom, const zkhip_evalh_desc* desc,
     auto resolve = [&](const uint64_t* p, bool ext_in, const fe** outp) -> int {
         ZK_CHECK(ctx, p != nullptr, "evaluate_h: null polynomial pointer");
         if (ext_in) {
-            if (!host) { *outp = (const fe*)p; return ZKHIP_OK; }
+            if (!host) { *outp = (const fe*)p; return (int)ZKHIP_OK; }
             fe* d;
             int r = ar.upload((const fe*)p, size, &d);
             if (r) return r;
@@ -1265,6 +1563,21 @@ extern "C" int zkhip_evaluate_h(zkhip_domain* dom, const zkhip_evalh_desc* desc,
     memcpy(&scal[4 * SC_ONE], HFR.r, 32);
     if (desc->num_challenges) memcpy(&scal[4 * SC_CHALLENGE0], desc->challenges, (size_t)desc->num_challenges * 32);
     scal.insert(scal.end(), extra_scalars.begin(), extra_scalars.end());
+    if (prog->n_terms) {
+        ZK_CHECK(ctx, scal.size() == (size_t)prog->sc_y0 * 4, "evaluate_h: internal error, scalar table mismatch");
+        scal.resize(((size_t)prog->sc_y0 + prog->n_terms) * 4);
+        uint64_t cur[4], y[4];
+        memcpy(cur, HFR.r, 32);
+        memcpy(y, desc->y, 32);
+        for (uint32_t i = prog->n_terms; i-- > 0;) {      // term i weighs y^(n_terms - 1 - i)
+            memcpy(&scal[((size_t)prog->sc_y0 + i) * 4], cur, 32);
+            h_mul(HFR, cur, cur, y);
+        }
+        for (uint32_t g : prog->gaps) {
+            h_pow(HFR, cur, y, g);
+            scal.insert(scal.end(), cur, cur + 4);
+        }
+    }
     {
         uint64_t k32[4];
         memcpy(k32, FrParams::TWO5, 32);
