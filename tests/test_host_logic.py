@@ -269,3 +269,13 @@ def _queries(e):
     out = set()
     plonk._walk_queries(e, out)
     return out
+
+
+def test_rng_batched_draws_equal_single_draws():
+    """`FieldRng.fr_many` (what the prover uses for the blinding rows) continues the stream exactly like repeated `fr`"""
+    from zkevm_circuits_amd import prover
+    a, b = prover.FieldRng(11), prover.FieldRng(11)
+    seq = [a.fr() for _ in range(40)]
+    assert b.fr_many(7) + [b.fr()] + b.fr_many(32) == seq
+    assert a.fr() == b.fr()
+    assert len(prover.OsFieldRng().fr_many(5)) == 5 and all(0 <= v < prover.P for v in prover.OsFieldRng().fr_many(5))

@@ -1050,12 +1050,19 @@ static int msm_phase3(zkhip_ctx* ctx, MsmWorkspace& ws, uint64_t out_jacobian[12
     return ZKHIP_OK;
 }
 
-constexpr int MSM_PIPE = 3;
+// Workspaces of a pipelined batch: MSM j is sorted and accumulated while MSM j - 1 is merged and reduced and the sums of
+// MSM j - 1 - MSM_TAIL_LAG .. are joined on the host, so that MSM_TAIL_LAG + 1 merge + reduce tails are in flight, each
+// on its workspace's own stream.  A tail is a chain of dependent point additions (0.2 - 0.5 ms whatever the size): for
+// sparse witness columns, whose other phases take tens of microseconds, the tails in flight set the rate of the batch.
+constexpr int MSM_TAIL_LAG = 3;
+constexpr int MSM_PIPE = 2 + MSM_TAIL_LAG;
 struct MsmState {
     std::map<uint32_t, MsmTables> tables;
     MsmWorkspace ws[MSM_PIPE];
-    hipEvent_t ev_in = nullptr, ev_out[MSM_PIPE] = {nullptr, nullptr, nullptr};
-    hipStream_t batch_streams[MSM_PIPE] = {nullptr, nullptr, nullptr};
+    // streams: [0] recode / count / plan / scatter, [1] accumulate, [2 + i] merge + reduce of workspace i
+    static constexpr int N_STREAMS = 2 + MSM_PIPE;
+    hipEvent_t ev_in = nullptr, ev_out[N_STREAMS] = {};
+    hipStream_t batch_streams[N_STREAMS] = {};
 };
 // Per-context MSM state.  The map is shared by all contexts of the process (one per device), so lookups are
 // serialised; a context itself is not re-entrant, so the state found is then used without the lock.  std::map never
@@ -1092,12 +1099,13 @@ static int msm_pipeline(zkhip_ctx* ctx, MsmState& stt, const MsmTables& tb, cons
     const size_t batch = items.size();
     if (!stt.ev_in) {
         ZK_HIP(ctx, hipEventCreateWithFlags(&stt.ev_in, hipEventDisableTiming));
-        for (int i = 0; i < MSM_PIPE; i++) ZK_HIP(ctx, hipEventCreateWithFlags(&stt.ev_out[i], hipEventDisableTiming));
+        for (int i = 0; i < MsmState::N_STREAMS; i++) ZK_HIP(ctx, hipEventCreateWithFlags(&stt.ev_out[i], hipEventDisableTiming));
     }
-    // Three streams by role, shared by the workspaces: [0] recode / count / plan / scatter, [1] accumulate, [2] merge +
-    // reduce.  The accumulate kernels run back to back on their own stream; the short kernels before and after them
-    // have streams of their own, so that they queue behind each other and not behind an accumulate (24 us of histogram
-    // take 560 us next to one, and delay the next accumulate, which waits for them).
+    // Streams by role, shared by the workspaces: [0] recode / count / plan / scatter, [1] accumulate.  The accumulate
+    // kernels run back to back on their own stream; the short kernels before them have a stream of their own, so that
+    // they queue behind each other and not behind an accumulate (24 us of histogram take 560 us next to one, and delay
+    // the next accumulate, which waits for them).  Merge + reduce run on a stream per workspace: the tails of
+    // consecutive MSMs are latency chains and overlap.
     // Stream priorities (accumulate lowest, the others highest) gain another 2 % in a batch that starts on an idle
     // device, but a priority stream that waits on an event of the context's normal-priority stream while that stream
     // still has hundreds of milliseconds of work queued was seen never to wake up: they stay off unless
@@ -1107,10 +1115,9 @@ static int msm_pipeline(zkhip_ctx* ctx, MsmState& stt, const MsmTables& tb, cons
         static const bool with_priority = getenv("ZKHIP_MSM_STREAM_PRIORITY") != nullptr;
         int least = 0, greatest = 0;
         ZK_HIP(ctx, hipDeviceGetStreamPriorityRange(&least, &greatest));
-        const int prio[MSM_PIPE] = {greatest, least, greatest};
-        for (int i = 0; i < MSM_PIPE; i++) {
+        for (int i = 0; i < MsmState::N_STREAMS; i++) {
             if (with_priority)
-                ZK_HIP(ctx, hipStreamCreateWithPriority(&stt.batch_streams[i], hipStreamNonBlocking, prio[i]));
+                ZK_HIP(ctx, hipStreamCreateWithPriority(&stt.batch_streams[i], hipStreamNonBlocking, i == 1 ? least : greatest));
             else
                 ZK_HIP(ctx, hipStreamCreateWithFlags(&stt.batch_streams[i], hipStreamNonBlocking));
         }
@@ -1118,14 +1125,15 @@ static int msm_pipeline(zkhip_ctx* ctx, MsmState& stt, const MsmTables& tb, cons
     for (int i = 0; i < MSM_PIPE; i++) {
         stt.ws[i].stream = stt.batch_streams[0];
         stt.ws[i].acc_stream = stt.batch_streams[1];
-        stt.ws[i].tail_stream = stt.batch_streams[2];
+        stt.ws[i].tail_stream = stt.batch_streams[2 + i];
         pipe[i] = &stt.ws[i];
     }
     ZK_HIP(ctx, hipEventRecord(stt.ev_in, ctx->stream));
-    for (int i = 0; i < MSM_PIPE; i++) ZK_HIP(ctx, hipStreamWaitEvent(stt.batch_streams[i], stt.ev_in, 0));
-    // software pipeline: phase1(j + 2), phase2(j + 1), phase3(j)
+    for (int i = 0; i < MsmState::N_STREAMS; i++) ZK_HIP(ctx, hipStreamWaitEvent(stt.batch_streams[i], stt.ev_in, 0));
+    // software pipeline: phase1(j), phase2(j - 1), phase3(j - 1 - MSM_TAIL_LAG)
     int rc;
-    for (size_t j = 0; j < batch + 2; j++) {
+    const size_t lag3 = 1 + MSM_TAIL_LAG;
+    for (size_t j = 0; j < batch + lag3; j++) {
         if (j < batch) {
             MsmWorkspace& ws = *pipe[j % MSM_PIPE];
             {
@@ -1142,12 +1150,12 @@ static int msm_pipeline(zkhip_ctx* ctx, MsmState& stt, const MsmTables& tb, cons
             rc = msm_phase2(ctx, *pipe[(j - 1) % MSM_PIPE], tb, timed);
             if (rc) return rc;
         }
-        if (j >= 2 && j - 2 < batch) {
-            rc = msm_phase3(ctx, *pipe[(j - 2) % MSM_PIPE], out + 12 * (j - 2));
+        if (j >= lag3 && j - lag3 < batch) {
+            rc = msm_phase3(ctx, *pipe[(j - lag3) % MSM_PIPE], out + 12 * (j - lag3));
             if (rc) return rc;
         }
     }
-    for (int i = 0; i < MSM_PIPE; i++) {
+    for (int i = 0; i < MsmState::N_STREAMS; i++) {
         ZK_HIP(ctx, hipEventRecord(stt.ev_out[i], stt.batch_streams[i]));
         ZK_HIP(ctx, hipStreamWaitEvent(ctx->stream, stt.ev_out[i], 0));
     }
@@ -1203,6 +1211,8 @@ void msm_drop_ctx(zkhip_ctx* ctx) {
         if (w.ev_sorted) (void)hipEventDestroy(w.ev_sorted);
         if (w.ev_acc) (void)hipEventDestroy(w.ev_acc);
         if (w.ev_done) (void)hipEventDestroy(w.ev_done);
+    }
+    for (int i = 0; i < MsmState::N_STREAMS; i++) {
         if (st.batch_streams[i]) (void)hipStreamDestroy(st.batch_streams[i]);
         if (st.ev_out[i]) (void)hipEventDestroy(st.ev_out[i]);
     }

@@ -120,6 +120,11 @@ class FieldRng:
     def fr(self) -> int:
         return int.from_bytes(self.g.bytes(64), "little") % P
 
+    def fr_many(self, count: int) -> list:
+        """the next `count` draws of `fr` (the generator hands out the same bytes in one call as in `count` calls)"""
+        raw = self.g.bytes(64 * count)
+        return [int.from_bytes(raw[64 * i:64 * i + 64], "little") % P for i in range(count)]
+
     def limbs(self, n: int) -> np.ndarray:
         """n field elements at once as (n, 4) Montgomery limbs: residues uniform below 2^252 (< r), which is as good a
         stand-in for a polynomial with random coefficients and keeps 2^k draws out of the interpreter"""
@@ -137,6 +142,11 @@ class OsFieldRng:
     def fr(self) -> int:
         import secrets
         return int.from_bytes(secrets.token_bytes(64), "little") % P
+
+    def fr_many(self, count: int) -> list:
+        import secrets
+        raw = secrets.token_bytes(64 * count)
+        return [int.from_bytes(raw[64 * i:64 * i + 64], "little") % P for i in range(count)]
 
     def limbs(self, n: int) -> np.ndarray:
         import secrets
@@ -376,8 +386,13 @@ def create_proof(ctx, dom, params: ParamsKZG, pk: ProvingKey, advice, instance, 
             timings[clock[1]] = timings.get(clock[1], 0.0) + now - clock[0]
         clock[0], clock[1] = now, phase
 
+    def draws(count):
+        """the next `count` values of the RNG, in the order single draws would come"""
+        many = getattr(rng, "fr_many", None)
+        return many(count) if many else [rng.fr() for _ in range(count)]
+
     def blind_rows(d_col, first_row):
-        ctx.upload(fr_limbs([rng.fr() for _ in range(n - first_row)]), d_col + first_row * 32)
+        ctx.upload(fr_limbs(draws(n - first_row)), d_col + first_row * 32)
 
     try:
         # ---- instances and advice ---------------------------------------------------------------------------
@@ -420,7 +435,7 @@ def create_proof(ctx, dom, params: ParamsKZG, pk: ProvingKey, advice, instance, 
                     for g0 in range(0, len(columns), GROUP):
                         group = columns[g0:g0 + GROUP]
                         for i, c in enumerate(group, g0):
-                            stage[i] = fr_limbs([rng.fr() for _ in range(n - usable)])
+                            stage[i] = fr_limbs(draws(n - usable))
                             ctx.upload_overlapped(assigned[c], adv[c])
                             ctx.upload_overlapped(stage[i], adv[c] + usable * 32)
                         if pending is not None:
@@ -433,7 +448,7 @@ def create_proof(ctx, dom, params: ParamsKZG, pk: ProvingKey, advice, instance, 
             else:
                 for c in columns:                               # the unusable rows of every column are blinding
                     col, d = assigned[c], adv[c]
-                    blinding = fr_limbs([rng.fr() for _ in range(n - usable)])
+                    blinding = fr_limbs(draws(n - usable))
                     if isinstance(col, np.ndarray):
                         ctx.upload(col, d)
                         ctx.upload(blinding, d + usable * 32)
@@ -441,8 +456,7 @@ def create_proof(ctx, dom, params: ParamsKZG, pk: ProvingKey, advice, instance, 
                         ctx.upload(np.concatenate([fr_limbs(col), blinding]), d)
                 if columns:
                     points.extend(params.commit_lagrange([adv[c] for c in columns], dist))
-            for _ in columns:
-                rng.fr()                                        # one Blind per column: drawn, unused by KZG
+            draws(len(columns))                                 # one Blind per column: drawn, unused by KZG
             for jac in points:
                 transcript.write_point(jac)
             for c in phase_challenges:
