@@ -34,6 +34,22 @@ struct fw {
 
 template <class FP>
 struct Wide {
+    // Hides from the optimiser what it has proved about a digit (a masked digit is non-negative).  A product of a
+    // sign-extended digit and a digit known to be non-negative is otherwise lowered to an UNSIGNED 64-bit multiply-add
+    // plus a second multiply-add and two moves that correct the high word for the sign; with the knowledge hidden both
+    // factors are plain sign-extended 32-bit values and the product is one v_mad_i64_i32.  Emits no instruction.
+    ZK_DEV static int32_t veil(int32_t v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        asm("" : "+v"(v));
+#endif
+        return v;
+    }
+    ZK_DEV static fw veil(const fw& a) {
+        fw o;
+#pragma unroll
+        for (int i = 0; i < 9; i++) o.d[i] = veil(a.d[i]);
+        return o;
+    }
     ZK_DEV static fw zero() {
         fw o;
 #pragma unroll
@@ -138,13 +154,15 @@ struct Wide {
         return o;
     }
     // col += a b, the 81 digit products in their 17 columns (col[17] only takes carries in reduce)
-    ZK_DEV static void mac(int64_t col[18], const fw& a, const fw& b) {
+    ZK_DEV static void mac(int64_t col[18], const fw& a_, const fw& b_) {
+        const fw a = veil(a_), b = veil(b_);
 #pragma unroll
         for (int i = 0; i < 9; i++)
 #pragma unroll
             for (int j = 0; j < 9; j++) col[i + j] += (int64_t)a.d[i] * b.d[j];
     }
-    ZK_DEV static fw mul(const fw& a, const fw& b) {
+    ZK_DEV static fw mul(const fw& a_, const fw& b_) {
+        const fw a = veil(a_), b = veil(b_);
         int64_t col[18];
 #pragma unroll
         for (int k = 0; k < 18; k++) col[k] = 0;
@@ -156,11 +174,12 @@ struct Wide {
     }
     // (a b - c d) / 2^261 with ONE reduction: both products share the columns.  All four operands must be normalised
     // or differences of normalised values (|digit| < 2^29): 18 terms of 2^58 plus the reduction stay below 2^63.
-    ZK_DEV static fw mul_sub_mul(const fw& a, const fw& b, const fw& c, const fw& d) {
+    ZK_DEV static fw mul_sub_mul(const fw& a_, const fw& b_, const fw& c_, const fw& d_) {
+        const fw a = veil(a_), b = veil(b_), c = veil(c_);
         int64_t col[18];
 #pragma unroll
         for (int k = 0; k < 18; k++) col[k] = 0;
-        const fw nd = neg(d);
+        const fw nd = veil(neg(d_));
 #pragma unroll
         for (int i = 0; i < 9; i++)
 #pragma unroll
@@ -172,7 +191,8 @@ struct Wide {
         return reduce(col);
     }
     // (a b + c d) / 2^261 with ONE reduction; same operand rule as mul_sub_mul
-    ZK_DEV static fw mul_add_mul(const fw& a, const fw& b, const fw& c, const fw& d) {
+    ZK_DEV static fw mul_add_mul(const fw& a_, const fw& b_, const fw& c_, const fw& d_) {
+        const fw a = veil(a_), b = veil(b_), c = veil(c_), d = veil(d_);
         int64_t col[18];
 #pragma unroll
         for (int k = 0; k < 18; k++) col[k] = 0;
@@ -187,7 +207,8 @@ struct Wide {
         return reduce(col);
     }
     // operand digits must stay below 2^29 in magnitude (the doubled cross terms use 2 a_i)
-    ZK_DEV static fw sqr(const fw& a) {
+    ZK_DEV static fw sqr(const fw& a_) {
+        const fw a = veil(a_);
         int64_t col[18];
 #pragma unroll
         for (int k = 0; k < 18; k++) col[k] = 0;
