@@ -35,22 +35,30 @@ __device__ __forceinline__ void xyzz_w_double_affine(g1_xyzz_w& acc, const fw& x
     acc.inf = false;
 }
 
+// acc = (qx, +-qy); q is in the packed in-memory form (identity = all zero words)
+__device__ __forceinline__ void xyzz_w_set_affine(g1_xyzz_w& acc, const g1_affine& q, bool negate) {
+    uint32_t any = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) any |= q.x.l[i] | q.y.l[i];
+    acc.x = FqW::from_fe(q.x);
+    acc.y = FqW::norm(FqW::cneg(FqW::from_fe(q.y), negate));
+    acc.zz = FqW::one();
+    acc.zzz = FqW::one();
+    acc.inf = any == 0;
+}
+
 // acc += (qx, +-qy); q is in the packed in-memory form (identity = all zero words)
 __device__ __forceinline__ void xyzz_w_add_affine(g1_xyzz_w& acc, const g1_affine& q, bool negate) {
     uint32_t any = 0;
 #pragma unroll
     for (int i = 0; i < 8; i++) any |= q.x.l[i] | q.y.l[i];
     if (any == 0) return;
-    const fw qx = FqW::from_fe(q.x);
-    const fw qy = FqW::cneg(FqW::from_fe(q.y), negate);
-    if (acc.inf) {
-        acc.x = qx;
-        acc.y = FqW::norm(qy);
-        acc.zz = FqW::one();
-        acc.zzz = FqW::one();
-        acc.inf = false;
+    if (__builtin_expect(acc.inf, 0)) {
+        xyzz_w_set_affine(acc, q, negate);
         return;
     }
+    const fw qx = FqW::from_fe(q.x);
+    const fw qy = FqW::cneg(FqW::from_fe(q.y), negate);
     const fw u2 = FqW::mul(qx, acc.zz);
     const fw s2 = FqW::mul(qy, acc.zzz);
     const fw p = FqW::sub(u2, acc.x);

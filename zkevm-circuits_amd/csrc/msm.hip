@@ -529,11 +529,24 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))
     const uint32_t lo = start[b] + (uint32_t)((uint64_t)s * c / f);
     const uint32_t hi = start[b] + (uint32_t)((uint64_t)(s + 1) * c / f);
     g1_xyzz_w acc;
-    acc.inf = true;
-    acc.x = acc.y = acc.zz = acc.zzz = FqW::zero();
+    if (lo >= hi) {   // cannot happen while a bucket has no more slots than entries; kept so that a bad plan stays harmless
+        store_xyzz(items + t, xyzz_identity());
+        return;
+    }
     uint32_t e = entries[lo];
     g1_affine p = load_affine(tables + (size_t)((e >> ENTRY_IDX_BITS) & 31) * table_stride + first + (e & ENTRY_IDX_MASK));
-    for (uint32_t k = lo; k < hi; k++) {
+    // the first point becomes the accumulator (a slot is never empty: lo < hi), so that the loop below starts from a
+    // point and "accumulator is the identity" is an exception in it, not a case of every iteration
+    {
+        const uint32_t ecur = e;
+        const g1_affine q = p;
+        if (lo + 1 < hi) {
+            e = entries[lo + 1];
+            p = load_affine(tables + (size_t)((e >> ENTRY_IDX_BITS) & 31) * table_stride + first + (e & ENTRY_IDX_MASK));
+        }
+        xyzz_w_set_affine(acc, q, (ecur & 0x80000000u) != 0);
+    }
+    for (uint32_t k = lo + 1; k < hi; k++) {
         const uint32_t ecur = e;
         const g1_affine q = p;
         if (k + 1 < hi) {   // prefetch the next point while this one is added

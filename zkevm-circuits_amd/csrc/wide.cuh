@@ -37,7 +37,8 @@ struct Wide {
     // Hides from the optimiser what it has proved about a digit (a masked digit is non-negative).  A product of a
     // sign-extended digit and a digit known to be non-negative is otherwise lowered to an UNSIGNED 64-bit multiply-add
     // plus a second multiply-add and two moves that correct the high word for the sign; with the knowledge hidden both
-    // factors are plain sign-extended 32-bit values and the product is one v_mad_i64_i32.  Emits no instruction.
+    // factors are plain sign-extended 32-bit values and the product is one v_mad_i64_i32.  Emits no instruction.  Applied
+    // where masked digits are made (from_fe, norm, reduce): the unveiled value dies there, so no copy is needed either.
     ZK_DEV static int32_t veil(int32_t v) {
 #if defined(__HIP_DEVICE_COMPILE__)
         asm("" : "+v"(v));
@@ -61,14 +62,14 @@ struct Wide {
         const d29 u = unpack29(a);
         fw o;
 #pragma unroll
-        for (int i = 0; i < 9; i++) o.d[i] = (int32_t)u.d[i];
+        for (int i = 0; i < 9; i++) o.d[i] = veil((int32_t)u.d[i]);
         return o;
     }
     // normalised digits of 32 * a for a packed a < 2^256 / 4: the same residue moved from the 2^256 to the 2^261
     // Montgomery domain (x 2^256 * 32 = x 2^261) at the price of an ordinary unpack; the value may reach 32 p
     ZK_DEV static fw from_fe_shl5(const fe& a) {
         fw o;
-        o.d[0] = (int32_t)((a.l[0] << 5) & M29);
+        o.d[0] = veil((int32_t)((a.l[0] << 5) & M29));
 #pragma unroll
         for (int i = 1; i < 9; i++) {
             const int bit = 29 * i - 5, w = bit >> 5, s = bit & 31;
@@ -76,7 +77,7 @@ struct Wide {
             if (s == 0) v = a.l[w];
             else if (w + 1 < 8) v = alignbit(a.l[w + 1], a.l[w], s);
             else v = a.l[w] >> s;
-            o.d[i] = (int32_t)(v & M29);
+            o.d[i] = veil((int32_t)(v & M29));
         }
         return o;
     }
@@ -128,7 +129,7 @@ struct Wide {
 #pragma unroll
         for (int i = 0; i < 8; i++) {
             const int32_t t = a.d[i] + c;
-            o.d[i] = t & (int32_t)M29;
+            o.d[i] = veil(t & (int32_t)M29);
             c = t >> 29;
         }
         o.d[8] = a.d[8] + c;
@@ -147,22 +148,20 @@ struct Wide {
         fw o;
 #pragma unroll
         for (int k = 9; k < 17; k++) {
-            o.d[k - 9] = (int32_t)((uint32_t)col[k] & M29);
+            o.d[k - 9] = veil((int32_t)((uint32_t)col[k] & M29));
             col[k + 1] += col[k] >> 29;
         }
         o.d[8] = (int32_t)col[17];
         return o;
     }
     // col += a b, the 81 digit products in their 17 columns (col[17] only takes carries in reduce)
-    ZK_DEV static void mac(int64_t col[18], const fw& a_, const fw& b_) {
-        const fw a = veil(a_), b = veil(b_);
+    ZK_DEV static void mac(int64_t col[18], const fw& a, const fw& b) {
 #pragma unroll
         for (int i = 0; i < 9; i++)
 #pragma unroll
             for (int j = 0; j < 9; j++) col[i + j] += (int64_t)a.d[i] * b.d[j];
     }
-    ZK_DEV static fw mul(const fw& a_, const fw& b_) {
-        const fw a = veil(a_), b = veil(b_);
+    ZK_DEV static fw mul(const fw& a, const fw& b) {
         int64_t col[18];
 #pragma unroll
         for (int k = 0; k < 18; k++) col[k] = 0;
@@ -174,12 +173,11 @@ struct Wide {
     }
     // (a b - c d) / 2^261 with ONE reduction: both products share the columns.  All four operands must be normalised
     // or differences of normalised values (|digit| < 2^29): 18 terms of 2^58 plus the reduction stay below 2^63.
-    ZK_DEV static fw mul_sub_mul(const fw& a_, const fw& b_, const fw& c_, const fw& d_) {
-        const fw a = veil(a_), b = veil(b_), c = veil(c_);
+    ZK_DEV static fw mul_sub_mul(const fw& a, const fw& b, const fw& c, const fw& d) {
         int64_t col[18];
 #pragma unroll
         for (int k = 0; k < 18; k++) col[k] = 0;
-        const fw nd = veil(neg(d_));
+        const fw nd = neg(d);
 #pragma unroll
         for (int i = 0; i < 9; i++)
 #pragma unroll
@@ -191,8 +189,7 @@ struct Wide {
         return reduce(col);
     }
     // (a b + c d) / 2^261 with ONE reduction; same operand rule as mul_sub_mul
-    ZK_DEV static fw mul_add_mul(const fw& a_, const fw& b_, const fw& c_, const fw& d_) {
-        const fw a = veil(a_), b = veil(b_), c = veil(c_), d = veil(d_);
+    ZK_DEV static fw mul_add_mul(const fw& a, const fw& b, const fw& c, const fw& d) {
         int64_t col[18];
 #pragma unroll
         for (int k = 0; k < 18; k++) col[k] = 0;
@@ -207,8 +204,7 @@ struct Wide {
         return reduce(col);
     }
     // operand digits must stay below 2^29 in magnitude (the doubled cross terms use 2 a_i)
-    ZK_DEV static fw sqr(const fw& a_) {
-        const fw a = veil(a_);
+    ZK_DEV static fw sqr(const fw& a) {
         int64_t col[18];
 #pragma unroll
         for (int k = 0; k < 18; k++) col[k] = 0;
