@@ -19,16 +19,17 @@ struct g1_xyzz_w {
 };
 
 // 2 * (x, y), an affine point that is not the identity; y may be a lazy negation
+template <class W = FqW>
 __device__ __forceinline__ void xyzz_w_double_affine(g1_xyzz_w& acc, const fw& x, const fw& y) {
-    const fw yn = FqW::norm(y);
-    const fw u = FqW::norm(FqW::dbl(yn));
-    const fw v = FqW::sqr(u);
-    const fw w = FqW::mul(u, v);
-    const fw s = FqW::mul(x, v);
-    const fw x2 = FqW::sqr(x);
-    const fw m = FqW::norm(FqW::add(FqW::dbl(x2), x2));
-    const fw x3 = FqW::norm(FqW::sub(FqW::sqr(m), FqW::dbl(s)));
-    acc.y = FqW::mul_sub_mul(m, FqW::sub(s, x3), w, yn);
+    const fw yn = W::norm(y);
+    const fw u = W::norm(W::dbl(yn));
+    const fw v = W::sqr(u);
+    const fw w = W::mul(u, v);
+    const fw s = W::mul(x, v);
+    const fw x2 = W::sqr(x);
+    const fw m = W::norm(W::add(W::dbl(x2), x2));
+    const fw x3 = W::norm(W::sub(W::sqr(m), W::dbl(s)));
+    acc.y = W::mul_sub_mul(m, W::sub(s, x3), w, yn);
     acc.x = x3;
     acc.zz = v;
     acc.zzz = w;
@@ -36,48 +37,50 @@ __device__ __forceinline__ void xyzz_w_double_affine(g1_xyzz_w& acc, const fw& x
 }
 
 // acc = (qx, +-qy); q is in the packed in-memory form (identity = all zero words)
+template <class W = FqW>
 __device__ __forceinline__ void xyzz_w_set_affine(g1_xyzz_w& acc, const g1_affine& q, bool negate) {
     uint32_t any = 0;
 #pragma unroll
     for (int i = 0; i < 8; i++) any |= q.x.l[i] | q.y.l[i];
-    acc.x = FqW::from_fe(q.x);
-    acc.y = FqW::norm(FqW::cneg(FqW::from_fe(q.y), negate));
-    acc.zz = FqW::one();
-    acc.zzz = FqW::one();
+    acc.x = W::from_fe(q.x);
+    acc.y = W::norm(W::cneg(W::from_fe(q.y), negate));
+    acc.zz = W::one();
+    acc.zzz = W::one();
     acc.inf = any == 0;
 }
 
 // acc += (qx, +-qy); q is in the packed in-memory form (identity = all zero words)
+template <class W = FqW>
 __device__ __forceinline__ void xyzz_w_add_affine(g1_xyzz_w& acc, const g1_affine& q, bool negate) {
     uint32_t any = 0;
 #pragma unroll
     for (int i = 0; i < 8; i++) any |= q.x.l[i] | q.y.l[i];
     if (any == 0) return;
     if (__builtin_expect(acc.inf, 0)) {
-        xyzz_w_set_affine(acc, q, negate);
+        xyzz_w_set_affine<W>(acc, q, negate);
         return;
     }
-    const fw qx = FqW::from_fe(q.x);
-    const fw qy = FqW::cneg(FqW::from_fe(q.y), negate);
-    const fw u2 = FqW::mul(qx, acc.zz);
-    const fw s2 = FqW::mul(qy, acc.zzz);
-    const fw p = FqW::sub(u2, acc.x);
-    const fw r = FqW::sub(s2, acc.y);
-    if (FqW::maybe_zero(p)) {          // almost never taken: the exact test costs a full canonicalisation
-        if (FqW::is_zero(p)) {
-            if (FqW::is_zero(r)) xyzz_w_double_affine(acc, qx, qy);
+    const fw qx = W::from_fe(q.x);
+    const fw qy = W::cneg(W::from_fe(q.y), negate);
+    const fw u2 = W::mul(qx, acc.zz);
+    const fw s2 = W::mul(qy, acc.zzz);
+    const fw p = W::sub(u2, acc.x);
+    const fw r = W::sub(s2, acc.y);
+    if (W::maybe_zero(p)) {          // almost never taken: the exact test costs a full canonicalisation
+        if (W::is_zero(p)) {
+            if (W::is_zero(r)) xyzz_w_double_affine<W>(acc, qx, qy);
             else acc.inf = true;
             return;
         }
     }
-    const fw pp = FqW::sqr(p);
-    const fw ppp = FqW::mul(p, pp);
-    const fw qq = FqW::mul(acc.x, pp);
-    const fw x3 = FqW::norm(FqW::sub(FqW::sub(FqW::sqr(r), ppp), FqW::dbl(qq)));
-    acc.y = FqW::mul_sub_mul(r, FqW::sub(qq, x3), acc.y, ppp);
+    const fw pp = W::sqr(p);
+    const fw ppp = W::mul(p, pp);
+    const fw qq = W::mul(acc.x, pp);
+    const fw x3 = W::norm(W::sub(W::sub(W::sqr(r), ppp), W::dbl(qq)));
+    acc.y = W::mul_sub_mul(r, W::sub(qq, x3), acc.y, ppp);
     acc.x = x3;
-    acc.zz = FqW::mul(acc.zz, pp);
-    acc.zzz = FqW::mul(acc.zzz, ppp);
+    acc.zz = W::mul(acc.zz, pp);
+    acc.zzz = W::mul(acc.zzz, ppp);
 }
 
 // 2 * a (a not the identity)

@@ -544,7 +544,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))
             e = entries[lo + 1];
             p = load_affine(tables + (size_t)((e >> ENTRY_IDX_BITS) & 31) * table_stride + first + (e & ENTRY_IDX_MASK));
         }
-        xyzz_w_set_affine(acc, q, (ecur & 0x80000000u) != 0);
+        xyzz_w_set_affine<FqWChain>(acc, q, (ecur & 0x80000000u) != 0);
     }
     for (uint32_t k = lo + 1; k < hi; k++) {
         const uint32_t ecur = e;
@@ -553,7 +553,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))
             e = entries[k + 1];
             p = load_affine(tables + (size_t)((e >> ENTRY_IDX_BITS) & 31) * table_stride + first + (e & ENTRY_IDX_MASK));
         }
-        xyzz_w_add_affine(acc, q, (ecur & 0x80000000u) != 0);
+        xyzz_w_add_affine<FqWChain>(acc, q, (ecur & 0x80000000u) != 0);
     }
     xyzz_w_store(items + t, acc);
 }

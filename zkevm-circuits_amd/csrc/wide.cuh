@@ -32,7 +32,11 @@ struct fw {
     int32_t d[9];
 };
 
-template <class FP>
+// CHAIN: the multiplier adds every column's terms to its accumulator as ONE chain of dependent multiply-adds (see chain()).
+// That is the shortest instruction stream, and right for a kernel with several waves per SIMD to fill the wait state
+// between dependent 64-bit multiply-adds; a kernel that is a lone wave's dependency chain (the MSM's merge and reduce)
+// is faster with the optimiser's own two interleaved chains per column, joined by a 64-bit addition.
+template <class FP, bool CHAIN = false>
 struct Wide {
     // Hides from the optimiser what it has proved about a digit (a masked digit is non-negative).  A product of a
     // sign-extended digit and a digit known to be non-negative is otherwise lowered to an UNSIGNED 64-bit multiply-add
@@ -161,61 +165,97 @@ struct Wide {
 #pragma unroll
             for (int j = 0; j < 9; j++) col[i + j] += (int64_t)a.d[i] * b.d[j];
     }
+    // Column-wise Montgomery product with ONE running 64-bit accumulator: for output column k the digit products of
+    // weight 2^(29 k) and the reduction terms m_i p_(k-i) are added to the accumulator, the column's multiplier m_k (k < 9)
+    // or output digit (k >= 9) is taken from its low 29 bits, and the accumulator is shifted down by one digit.  Against
+    // the row-wise form (mac + reduce: 18 columns in registers, every column's carry shifted out AND added into the next
+    // column) this keeps two registers instead of thirty-six and saves one 64-bit addition per column.
+    // products(k, acc) adds the digit products of column k (0 <= k <= 16) to acc.
+    // acc >> 29 as the START of the next column's chain of multiply-adds: the optimiser otherwise re-associates the sum,
+    // starts the chain from zero and adds the shifted carry at the end with a 64-bit addition of its own
+    ZK_DEV static int64_t carry_out(int64_t acc) {
+        acc >>= 29;
+#if defined(__HIP_DEVICE_COMPILE__)
+        if (CHAIN) asm("" : "+v"(acc));
+#endif
+        return acc;
+    }
+    // acc + x y as one link of a chain of multiply-adds (the sum is opaque afterwards, so the chain keeps its order)
+    ZK_DEV static void chain(int64_t& acc, int32_t x, int32_t y) {
+        acc += (int64_t)x * y;
+#if defined(__HIP_DEVICE_COMPILE__)
+        if (CHAIN) asm("" : "+v"(acc));
+#endif
+    }
+    template <class F>
+    ZK_DEV static fw comba(F&& products) {
+        int64_t acc = 0;
+        int32_t m[9];
+        fw o;
+#pragma unroll
+        for (int k = 0; k < 9; k++) {
+            products(k, acc);
+#pragma unroll
+            for (int i = 0; i < k; i++) chain(acc, m[i], (int32_t)FP::P29[k - i]);
+            m[k] = (int32_t)(((uint32_t)acc * FP::INV29) & M29);
+            chain(acc, m[k], (int32_t)FP::P29[0]);
+            acc = carry_out(acc);
+        }
+#pragma unroll
+        for (int k = 9; k < 17; k++) {
+            products(k, acc);
+#pragma unroll
+            for (int i = k - 8; i < 9; i++) chain(acc, m[i], (int32_t)FP::P29[k - i]);
+            o.d[k - 9] = veil((int32_t)((uint32_t)acc & M29));
+            acc = carry_out(acc);
+        }
+        o.d[8] = (int32_t)acc;
+        return o;
+    }
     ZK_DEV static fw mul(const fw& a, const fw& b) {
-        int64_t col[18];
+        return comba([&](int k, int64_t& acc) {
 #pragma unroll
-        for (int k = 0; k < 18; k++) col[k] = 0;
-#pragma unroll
-        for (int i = 0; i < 9; i++)
-#pragma unroll
-            for (int j = 0; j < 9; j++) col[i + j] += (int64_t)a.d[i] * b.d[j];
-        return reduce(col);
+            for (int i = 0; i < 9; i++)
+                if (k - i >= 0 && k - i < 9) chain(acc, a.d[i], b.d[k - i]);
+        });
     }
     // (a b - c d) / 2^261 with ONE reduction: both products share the columns.  All four operands must be normalised
     // or differences of normalised values (|digit| < 2^29): 18 terms of 2^58 plus the reduction stay below 2^63.
     ZK_DEV static fw mul_sub_mul(const fw& a, const fw& b, const fw& c, const fw& d) {
-        int64_t col[18];
-#pragma unroll
-        for (int k = 0; k < 18; k++) col[k] = 0;
         const fw nd = neg(d);
+        return comba([&](int k, int64_t& acc) {
 #pragma unroll
-        for (int i = 0; i < 9; i++)
+            for (int i = 0; i < 9; i++)
+                if (k - i >= 0 && k - i < 9) chain(acc, a.d[i], b.d[k - i]);
 #pragma unroll
-            for (int j = 0; j < 9; j++) col[i + j] += (int64_t)a.d[i] * b.d[j];
-#pragma unroll
-        for (int i = 0; i < 9; i++)
-#pragma unroll
-            for (int j = 0; j < 9; j++) col[i + j] += (int64_t)c.d[i] * nd.d[j];
-        return reduce(col);
+            for (int i = 0; i < 9; i++)
+                if (k - i >= 0 && k - i < 9) chain(acc, c.d[i], nd.d[k - i]);
+        });
     }
     // (a b + c d) / 2^261 with ONE reduction; same operand rule as mul_sub_mul
     ZK_DEV static fw mul_add_mul(const fw& a, const fw& b, const fw& c, const fw& d) {
-        int64_t col[18];
+        return comba([&](int k, int64_t& acc) {
 #pragma unroll
-        for (int k = 0; k < 18; k++) col[k] = 0;
+            for (int i = 0; i < 9; i++)
+                if (k - i >= 0 && k - i < 9) chain(acc, a.d[i], b.d[k - i]);
 #pragma unroll
-        for (int i = 0; i < 9; i++)
-#pragma unroll
-            for (int j = 0; j < 9; j++) col[i + j] += (int64_t)a.d[i] * b.d[j];
-#pragma unroll
-        for (int i = 0; i < 9; i++)
-#pragma unroll
-            for (int j = 0; j < 9; j++) col[i + j] += (int64_t)c.d[i] * d.d[j];
-        return reduce(col);
+            for (int i = 0; i < 9; i++)
+                if (k - i >= 0 && k - i < 9) chain(acc, c.d[i], d.d[k - i]);
+        });
     }
     // operand digits must stay below 2^29 in magnitude (the doubled cross terms use 2 a_i)
     ZK_DEV static fw sqr(const fw& a) {
-        int64_t col[18];
+        fw a2;
 #pragma unroll
-        for (int k = 0; k < 18; k++) col[k] = 0;
+        for (int i = 0; i < 9; i++) a2.d[i] = a.d[i] << 1;
+        return comba([&](int k, int64_t& acc) {
 #pragma unroll
-        for (int i = 0; i < 9; i++) {
-            col[2 * i] += (int64_t)a.d[i] * a.d[i];
-            const int32_t a2 = a.d[i] << 1;
-#pragma unroll
-            for (int j = i + 1; j < 9; j++) col[i + j] += (int64_t)a2 * a.d[j];
-        }
-        return reduce(col);
+            for (int i = 0; i < 9; i++) {
+                const int j = k - i;
+                if (j > i && j < 9) chain(acc, a2.d[i], a.d[j]);
+                if (j == i) chain(acc, a.d[i], a.d[i]);
+            }
+        });
     }
 
     // Cheap necessary condition for value == 0 (mod p) when |value| < 16 p: value = k p forces the low 29 bits to be
@@ -304,5 +344,6 @@ struct Wide {
 
 using FrW = Wide<FrParams>;
 using FqW = Wide<FqParams>;
+using FqWChain = Wide<FqParams, true>;
 
 }  // namespace zkhip
