@@ -31,7 +31,9 @@ from zkevm_circuits_amd import evalh_host, ffi, plonk, sharding, synthetic  # no
 K = 19
 LOG_EXT = 21
 MADS_PER_MUL, MADS_PER_SQR = 171, 135          # 81 + 81 + 9 and 45 + 81 + 9 v_mad_{u64_u32,i64_i32} / v_mul_lo_u32
-MADS_PER_MADD = 8 * MADS_PER_MUL + 2 * MADS_PER_SQR   # what this library's mixed addition issues (nine 29-bit digits)
+# what this library's mixed addition issues (nine 29-bit digits): six products, two squares and y3 = a b - c d, whose two
+# products share one reduction (81 + 81 + 81 + 9)
+MADS_PER_MADD = 6 * MADS_PER_MUL + 2 * MADS_PER_SQR + 252
 # Algorithmic price of one mixed addition: about 10 field multiplications of 8 x 8 + 8 x 8 + 8 = 136 32-bit multiply-adds
 # (the minimum over 32-bit limbs).  The roofline fraction is quoted on this count; the kernel's own count is reported beside it.
 ALG_MADS_PER_MADD = 10 * 136
