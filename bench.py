@@ -299,7 +299,7 @@ def measure_create_proof(ctx, bid, dist_=None):
     cs = synthetic.standin_cs(units=52, lanes=8, wide_lookups=8, lookup_width=10, extra_gates=38)
     dom = zk.Domain(ctx, cs.degree(), k)
     params = prover.ParamsKZG.from_registered(ctx, dom, bid, bid)
-    # the witness columns live in page-locked host memory (what INTEGRATION.md asks of the caller): the upload is a DMA
+    # the witness columns live in page-locked host memory (what the library asks of its caller): the upload is a DMA
     advice, instance, fixed, asm = synthetic.standin_witness(cs, dom.n, k, active_rows=3000, zeros=ctx.host_zeros)
     t0 = time.perf_counter()
     ctx.reset_peak()
