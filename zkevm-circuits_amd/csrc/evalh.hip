@@ -148,37 +148,34 @@ __device__ __forceinline__ void ev_stage(Staged& s, prog_ptr w, uint32_t idx, ui
     if (kb == L_ROW || kb == L_UNI) s.rb = ev_raw(s.b, idx, mask);
     if (kc == L_ROW || kc == L_UNI) s.rc = ev_raw(s.c, idx, mask);
 }
+// the multiplier of the interpreter: four waves per SIMD cover the wait state between dependent multiply-adds
+#ifndef ZKHIP_EVALH_CHAIN_MUL
+#define ZKHIP_EVALH_CHAIN_MUL 1
+#endif
+using EvW = Wide<FrParams, ZKHIP_EVALH_CHAIN_MUL != 0>;
 __device__ __forceinline__ void ev_execute(const InterpArgs& a, const Staged& s, int32_t* lds, fw& acc, fw& reg0, uint32_t idx) {
     // idx: the lane's row inside the evaluated window (value slots are per lane; columns were read while staging)
     const uint32_t w0 = s.w0, dst = w0 >> DST_SHIFT;
     fw t;
     if (w0 & F_MUL2) {
-        // a b +- c d: both products land in the same 64-bit columns and one reduction retires them.  c d goes first: it
-        // consumes two of the staged memory operands before a (a slot or the running value, never memory) and b are touched
-        int64_t col[18];
-#pragma unroll
-        for (int k = 0; k < 18; k++) col[k] = 0;
-        {
-            fw c = ev_value(a, s.c, s.rc, lds, acc, reg0, idx);
-            if (w0 & F_NORM_C) c = FrW::norm(c);
-            fw d = ev_value(a, s.d, s.rad, lds, acc, reg0, idx);
-            if (w0 & F_NORM_D) d = FrW::norm(d);
-            FrW::mac(col, FrW::cneg(c, (w0 & F_SUB) != 0), d);
-        }
-        __builtin_amdgcn_sched_barrier(0);
+        // a b +- c d: the column-wise multiplier adds both products' terms to one running accumulator and retires them with
+        // one reduction (a is a slot or the running value, never memory)
+        fw c = ev_value(a, s.c, s.rc, lds, acc, reg0, idx);
+        if (w0 & F_NORM_C) c = FrW::norm(c);
+        fw d = ev_value(a, s.d, s.rad, lds, acc, reg0, idx);
+        if (w0 & F_NORM_D) d = FrW::norm(d);
         t = ev_value(a, s.a, Fr::zero(), lds, acc, reg0, idx);
         if (w0 & F_NORM_A) t = FrW::norm(t);
         fw u = ev_value(a, s.b, s.rb, lds, acc, reg0, idx);
         if (w0 & F_NORM_B) u = FrW::norm(u);
-        FrW::mac(col, t, u);
-        t = FrW::reduce(col);
+        t = EvW::mul_add_mul(t, u, FrW::cneg(c, (w0 & F_SUB) != 0), d);
     } else {
         t = ev_value(a, s.a, s.rad, lds, acc, reg0, idx);
         if (w0 & F_NORM_A) t = FrW::norm(t);
         if (w0 & F_MUL) {
             fw u = ev_value(a, s.b, s.rb, lds, acc, reg0, idx);
             if (w0 & F_NORM_B) u = FrW::norm(u);
-            t = FrW::mul(t, u);
+            t = EvW::mul(t, u);
         }
         if (w0 & (F_ADD | F_SUB | F_RSUB)) {
             const fw c = ev_value(a, s.c, s.rc, lds, acc, reg0, idx);
