@@ -87,6 +87,12 @@ int zkhip_g1_multiples(zkhip_ctx* ctx, const uint64_t base_xy[8], uint64_t first
 /* Throughput probe: runs `iters` dependent Montgomery multiplications per lane on every CU and returns
  * achieved 32x32->64 multiply-adds per second (the VALU integer peak the MSM roofline is quoted against). */
 int zkhip_probe_mad_rate(zkhip_ctx* ctx, int iters, double* mads_per_second, double* fr_mul_per_second);
+/* Self-test of the device arithmetic (no counterpart in the reference; for integrators and the test suite): the lazy
+ * signed-digit multiplier in every form the kernels use -- product, square, a b - c d, a b + c d, lazy and negated
+ * operands, zero tests -- is checked against the packed Montgomery arithmetic on `quads` seeded quadruples of Fr and of
+ * Fq elements, edge values included.  out_failed[0..3]: bit masks of failed checks for Fr, Fr with chained columns, Fq,
+ * Fq with chained columns; all zero on a correct build. */
+int zkhip_selftest_arithmetic(zkhip_ctx* ctx, uint64_t seed, size_t quads, uint32_t out_failed[4]);
 
 /* ------------------------------------------------------------------ MSM ---------------------------
  * Replaces `halo2_proofs::arithmetic::best_multiexp(coeffs, bases) -> C::Curve` as called by

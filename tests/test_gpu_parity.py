@@ -35,6 +35,16 @@ def test_field_golden_and_random(ctx, co, fname, fid):
                           np.zeros((0, 4), np.uint64))
 
 
+def test_lazy_arithmetic_matches_packed_on_the_device(ctx):
+    """The signed-digit multiplier of the hot kernels in every form (interleaved and chained columns, products, squares,
+    a b +- c d, lazy / negated / repeated / extreme operands) against the packed Montgomery arithmetic, which the golden
+    vectors and the C oracle pin above; Fr and Fq, two seeds."""
+    for seed in (1, 0xC0FFEE):
+        assert ctx.selftest_arithmetic(seed, 1 << 16) == [0, 0, 0, 0]
+    with pytest.raises(ffi.ZkhipError):
+        ctx.selftest_arithmetic(1, 0)
+
+
 def test_poseidon_kat_through_device_fr(ctx):
     """The reference's Poseidon known answer (/root/reference/poseidon/src/hash.rs:903-918) recomputed with every
     field operation running on the device."""

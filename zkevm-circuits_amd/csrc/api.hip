@@ -3,6 +3,7 @@
 #include <memory>
 #include "common.h"
 #include "ntt.h"
+#include "wide.cuh"
 
 using namespace zkhip;
 
@@ -98,6 +99,60 @@ __global__ void __launch_bounds__(256) probe_kernel(fe* io, int iters) {
 #pragma unroll
     for (int c = 1; c < PROBE_CHAINS; c++) r = Fr::add(r, x[c]);
     store_fe(io + g, r);
+}
+
+// ---- self-test of the lazy arithmetic ----------------------------------------------------------------
+// The multiplier of wide.cuh leans on how the compiler lowers it (hidden digit signs, one chain of multiply-adds per
+// column): this checks every form of it against the packed Montgomery arithmetic on the device it will run on.
+// Returns a bit mask of the failed checks of (a, b, c, d).
+template <class FP, bool CHAIN>
+__device__ uint32_t wide_check(const fe& a, const fe& b, const fe& c, const fe& d) {
+    using F = Field<FP>;
+    using W = Wide<FP, CHAIN>;
+    uint32_t bad = 0;
+    const fw A = W::from_fe(a), B = W::from_fe(b), C = W::from_fe(c), D = W::from_fe(d);
+    const fe k32 = W::to_fe(W::one());   // 2^261 mod p: packed_mul(wide result, 32 R) undoes the wider radix
+    if (!F::eq(W::to_fe(A), a)) bad |= 1u;
+    if (!F::eq(F::mul(W::to_fe(W::mul(A, B)), k32), F::mul(a, b))) bad |= 2u;
+    if (!F::eq(F::mul(W::to_fe(W::sqr(A)), k32), F::sqr(a))) bad |= 4u;
+    const fw AB = W::sub(A, B), CD = W::sub(C, D);   // lazy differences as operands
+    if (!F::eq(F::mul(W::to_fe(W::mul(AB, CD)), k32), F::mul(F::sub(a, b), F::sub(c, d)))) bad |= 8u;
+    if (!F::eq(F::mul(W::to_fe(W::sqr(AB)), k32), F::sqr(F::sub(a, b)))) bad |= 16u;
+    if (!F::eq(F::mul(W::to_fe(W::mul(W::add(A, B), C)), k32), F::mul(F::add(a, b), c))) bad |= 32u;
+    if (!F::eq(F::mul(W::to_fe(W::mul_sub_mul(AB, C, D, CD)), k32),
+               F::sub(F::mul(F::sub(a, b), c), F::mul(d, F::sub(c, d))))) bad |= 64u;
+    if (!F::eq(F::mul(W::to_fe(W::mul_add_mul(A, CD, AB, D)), k32),
+               F::add(F::mul(a, F::sub(c, d)), F::mul(F::sub(a, b), d)))) bad |= 128u;
+    // a chain with no reduction in between, negated operands
+    fw ch = W::sub(W::mul(AB, CD), W::mul(W::cneg(A, true), B));
+    ch = W::mul(W::norm(ch), C);
+    const fe ref = F::mul(F::add(F::mul(F::sub(a, b), F::sub(c, d)), F::mul(a, b)), c);
+    if (!F::eq(F::mul(F::mul(W::to_fe(ch), k32), k32), ref)) bad |= 256u;
+    if (!W::maybe_zero(W::sub(A, A)) || !W::is_zero(W::sub(A, A)) || W::is_zero(AB) != F::eq(a, b)) bad |= 512u;
+    return bad;
+}
+__global__ void __launch_bounds__(256) wide_selftest_kernel(const fe* in, size_t quads, uint32_t* bad /*[4]*/) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= quads) return;
+    fe v[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) v[k] = load_fe(in + 4 * i + k);
+    // every eighth quadruple repeats an operand, the next one uses the extremes 0 and p - 1
+    if ((i & 7) == 1) v[1] = v[0];
+    if ((i & 7) == 2) {
+        v[2] = Fr::zero();
+#pragma unroll
+        for (int k = 0; k < 8; k++) v[3].l[k] = 0;
+    }
+    fe q[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) q[k] = v[k];
+    if ((i & 7) == 2) q[3] = Fq::neg(Fq::one()), v[3] = Fr::neg(Fr::one());
+    uint32_t r;
+    if ((r = wide_check<FrParams, false>(v[0], v[1], v[2], v[3]))) atomicOr(bad + 0, r);
+    if ((r = wide_check<FrParams, true>(v[0], v[1], v[2], v[3]))) atomicOr(bad + 1, r);
+    if ((r = wide_check<FqParams, false>(q[0], q[1], q[2], q[3]))) atomicOr(bad + 2, r);
+    if ((r = wide_check<FqParams, true>(q[0], q[1], q[2], q[3]))) atomicOr(bad + 3, r);
 }
 
 }  // namespace zkhip
@@ -360,6 +415,29 @@ int zkhip_probe_mad_rate(zkhip_ctx* ctx, int iters, double* mads_per_second, dou
     const double mps = muls / (ms * 1e-3);
     if (fr_mul_per_second) *fr_mul_per_second = mps;
     if (mads_per_second) *mads_per_second = mps * 171.0;   // 81 product + 81 reduction + 9 digit multiplies
+    return ZKHIP_OK;
+}
+
+int zkhip_selftest_arithmetic(zkhip_ctx* ctx, uint64_t seed, size_t quads, uint32_t out_failed[4]) {
+    if (!ctx || !out_failed) return ZKHIP_ERR_INVALID;
+    ZK_CHECK(ctx, quads >= 1 && quads <= ((size_t)1 << 24), "selftest: quads = %zu outside [1, 2^24]", quads);
+    ZK_HIP(ctx, hipSetDevice(ctx->device));
+    int rc = ensure_scratch(ctx, quads * 4 * 32 + 256);
+    if (rc) return rc;
+    std::vector<uint64_t> h(quads * 16);
+    uint64_t s = seed ? seed : 0x9E3779B97F4A7C15ULL;
+    for (size_t i = 0; i < h.size(); i++) {
+        s ^= s << 13; s ^= s >> 7; s ^= s << 17;
+        h[i] = (i % 4 == 3) ? (s & 0x0fffffffffffffffULL) : s;   // below 2^252, i.e. below both moduli
+    }
+    uint32_t* d_bad = (uint32_t*)((unsigned char*)ctx->scratch + quads * 4 * 32);
+    ZK_HIP(ctx, hipMemcpyAsync(ctx->scratch, h.data(), quads * 4 * 32, hipMemcpyHostToDevice, ctx->stream));
+    ZK_HIP(ctx, hipMemsetAsync(d_bad, 0, 16, ctx->stream));
+    hipLaunchKernelGGL(wide_selftest_kernel, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, ctx->stream,
+                       (const fe*)ctx->scratch, quads, d_bad);
+    ZK_HIP(ctx, hipGetLastError());
+    ZK_HIP(ctx, hipMemcpyAsync(out_failed, d_bad, 16, hipMemcpyDeviceToHost, ctx->stream));
+    ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));   // the pageable vector h must outlive its copy
     return ZKHIP_OK;
 }
 

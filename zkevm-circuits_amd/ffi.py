@@ -18,7 +18,7 @@ EXPORTS = [
     "zkhip_create", "zkhip_destroy", "zkhip_last_error", "zkhip_version", "zkhip_set_stream", "zkhip_sync",
     "zkhip_dev_alloc", "zkhip_dev_free", "zkhip_mem_info", "zkhip_upload", "zkhip_download",
     "zkhip_host_alloc", "zkhip_host_free", "zkhip_upload_async", "zkhip_upload_overlapped", "zkhip_upload_fence",
-    "zkhip_field_binop", "zkhip_field_batch_invert", "zkhip_g1_add_affine", "zkhip_g1_multiples", "zkhip_probe_mad_rate",
+    "zkhip_field_binop", "zkhip_field_batch_invert", "zkhip_g1_add_affine", "zkhip_g1_multiples", "zkhip_probe_mad_rate", "zkhip_selftest_arithmetic",
     "zkhip_register_bases", "zkhip_release_bases", "zkhip_msm", "zkhip_msm_batch_dev", "zkhip_msm_range_dev",
     "zkhip_g1_sum_jacobian", "zkhip_g1_to_affine", "zkhip_g1_fft",
     "zkhip_ntt", "zkhip_ntt_dev",
@@ -290,6 +290,12 @@ class Context:
         sc = u64(scale) if scale is not None else None
         self._ck(self._l.zkhip_g1_fft(self.h, _p(pts), C.c_uint32(log_n), _p(om), _p(sc) if sc is not None else None, _p(out)))
         return out
+
+    def selftest_arithmetic(self, seed=1, quads=1 << 16):
+        """bit masks of failed checks of the lazy device arithmetic (Fr, Fr chained, Fq, Fq chained); all zero = pass"""
+        out = (C.c_uint32 * 4)()
+        self._ck(self._l.zkhip_selftest_arithmetic(self.h, C.c_uint64(seed), C.c_size_t(quads), out))
+        return [int(v) for v in out]
 
     def probe_mad_rate(self, iters=2048):
         mads, muls = C.c_double(), C.c_double()
