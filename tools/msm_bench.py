@@ -17,4 +17,4 @@ ctx.timing_enable(True); ctx.timing_reset()
 t0 = time.perf_counter()
 for _ in range(reps): ctx.msm_range_dev(bid, 0, t.data_ptr(), n)
 dt = (time.perf_counter() - t0) / reps
-print(f"msm 2^{k}: {dt*1e3:.3f} ms  {n/dt/1e6:.1f} Mpts/s", {f: round(ctx.timing_get(f)[0],1) for f in ("msm_sort","msm_accumulate","msm_merge","msm_reduce")})
+print(f"msm 2^{k}: {dt*1e3:.3f} ms  {n/dt/1e6:.1f} Mpts/s", {f: round(ctx.timing_get(f)[0],1) for f in ("msm_sort","msm_accumulate","msm_merge","msm_reduce","msm_host_fold")})

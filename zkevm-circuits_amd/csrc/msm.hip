@@ -22,6 +22,7 @@
 //                           index has bit j set); a second level folds those over the waves in eight more rounds and
 //                           the host joins the 30 leftover points by Horner in powers of two
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -766,35 +767,6 @@ static uint32_t log2_ceil(size_t n) {
     return l;
 }
 
-// in: XYZZ with coordinates x * 2^261 (the kernels' domain); out: Jacobian with coordinates in the 2^256 domain
-static void xyzz_to_jacobian_host(uint64_t out[12], const uint64_t in_wide[16]) {
-    struct Inv32 {
-        uint64_t v[4];
-        Inv32() {
-            uint64_t k32[4];
-            h_from_u64(HFQ, k32, 32);
-            h_inv(HFQ, v, k32);
-        }
-    };
-    static const Inv32 inv32;
-    uint64_t in[16];
-    for (int k = 0; k < 4; k++) h_mul(HFQ, in + 4 * k, in_wide + 4 * k, inv32.v);
-    const uint64_t *X = in, *Y = in + 4, *ZZ = in + 8, *ZZZ = in + 12;
-    if (h_is_zero(ZZ)) {
-        memset(out, 0, 96);
-        return;
-    }
-    uint64_t zzz2[4], zz2[4], zz3[4], t[4];
-    h_mul(HFQ, zzz2, ZZZ, ZZZ);
-    h_mul(HFQ, zz2, ZZ, ZZ);
-    h_mul(HFQ, zz3, zz2, ZZ);
-    h_mul(HFQ, t, X, ZZ);
-    h_mul(HFQ, out, t, zzz2);          // X' = X * ZZ * ZZZ^2
-    h_mul(HFQ, t, Y, zz3);
-    h_mul(HFQ, out + 4, t, zzz2);      // Y' = Y * ZZ^3 * ZZZ^2
-    h_mul(HFQ, out + 8, ZZ, ZZZ);      // Z' = ZZ * ZZZ
-}
-
 static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 static uint32_t env_u32(const char* name, uint32_t dflt) {
@@ -868,7 +840,9 @@ static int ws_prepare(zkhip_ctx* ctx, MsmWorkspace& ws, const MsmTables& tb, siz
         ZK_HIP(ctx, hipMalloc((void**)&ws.base, off));
         ws.bytes = off;
     }
-    if (!ws.h_info) ZK_HIP(ctx, hipHostMalloc((void**)&ws.h_info, 64));
+    // page-locked and coherent: the plan and the reduce's leftover sums are written there by the kernels themselves
+    // (one copy command and its launch gap less on the critical path of a lone MSM, twice)
+    if (!ws.h_info) ZK_HIP(ctx, hipHostMalloc((void**)&ws.h_info, 64, hipHostMallocMapped | hipHostMallocCoherent));
     if (!ws.ev_info) {
         ZK_HIP(ctx, hipEventCreateWithFlags(&ws.ev_info, hipEventDisableTiming));
         ZK_HIP(ctx, hipEventCreateWithFlags(&ws.ev_sorted, hipEventDisableTiming));
@@ -876,7 +850,8 @@ static int ws_prepare(zkhip_ctx* ctx, MsmWorkspace& ws, const MsmTables& tb, siz
         ZK_HIP(ctx, hipEventCreateWithFlags(&ws.ev_done, hipEventDisableTiming));
     }
     ws.acc_blocks = (uint32_t)((T1_max + 255) / 256);
-    if (!ws.h_sums) ZK_HIP(ctx, hipHostMalloc((void**)&ws.h_sums, REDUCE_OUT * sizeof(g1_xyzz)));
+    if (!ws.h_sums)
+        ZK_HIP(ctx, hipHostMalloc((void**)&ws.h_sums, REDUCE_OUT * sizeof(g1_xyzz), hipHostMallocMapped | hipHostMallocCoherent));
     unsigned char* p = ws.base;
     ws.counts = (uint32_t*)(p + o_counts);
     ws.entries = (uint32_t*)(p + o_entries);
@@ -931,9 +906,8 @@ static int msm_phase1(zkhip_ctx* ctx, MsmWorkspace& ws, const MsmTables& tb, siz
 #undef ZK_LAUNCH_HIST
     hipLaunchKernelGGL(column_sum_kernel, dim3(ws.plan_blocks), dim3(COLSUM_THREADS), 0, st, ws.counts, G, B, ws.cnt, ws.ladder, ws.plan);
     hipLaunchKernelGGL(bucket_scan_kernel, dim3(1), dim3(1024), 0, st, ws.cnt, B, 0u, ws.cntA, ws.offA, ws.start, ws.cur, ws.plan,
-                       ws.plan_blocks, ws.ladder, (uint32_t)ctx->num_cus * 256u, FORCE_L, ws.info);
-    // the plan travels to the host while scatter and accumulate run
-    ZK_HIP(ctx, hipMemcpyAsync(ws.h_info, ws.info, 32, hipMemcpyDeviceToHost, st));
+                       ws.plan_blocks, ws.ladder, (uint32_t)ctx->num_cus * 256u, FORCE_L, ws.h_info);
+    // the plan is in host memory when this event completes, while scatter and accumulate run
     ZK_HIP(ctx, hipEventRecord(ws.ev_info, st));
     {
         const size_t lds_coarse = 5 * 256 * 4 + (size_t)COARSE_ROUND * 8;
@@ -1026,40 +1000,150 @@ static int msm_phase2(zkhip_ctx* ctx, MsmWorkspace& ws, const MsmTables& tb, boo
         TimedRegion tr(ctx, timed ? "msm_reduce" : nullptr, st);
         const uint32_t blocks1 = (B + 255) / 256, J = B / 64;   // B is a multiple of 128
         hipLaunchKernelGGL(reduce_level1_kernel, dim3(blocks1), dim3(256), 0, st, ws.sums, B, J, ws.l1);
-        hipLaunchKernelGGL(reduce_level2_kernel, dim3(2 * RED_STREAMS), dim3(256), 0, st, ws.l1, J, ws.out2);
+        hipLaunchKernelGGL(reduce_level2_kernel, dim3(2 * RED_STREAMS), dim3(256), 0, st, ws.l1, J,
+                           reinterpret_cast<g1_xyzz*>(ws.h_sums));
         ZK_HIP(ctx, hipGetLastError());
     }
-    ZK_HIP(ctx, hipMemcpyAsync(ws.h_sums, ws.out2, REDUCE_OUT * sizeof(g1_xyzz), hipMemcpyDeviceToHost, st));
     ZK_HIP(ctx, hipEventRecord(ws.ev_done, st));
     return ZKHIP_OK;
+}
+
+// ---- host fold in XYZZ coordinates (values in the host's 2^256 Montgomery domain; identity: zz = 0) ----
+struct HXyzz {
+    uint64_t x[4], y[4], zz[4], zzz[4];
+};
+static void hx_double(HXyzz& o, const HXyzz& p) {
+    const HostField& F = HFQ;
+    if (h_is_zero(p.zz)) {
+        o = p;
+        return;
+    }
+    uint64_t u[4], v[4], w[4], s[4], m[4], t[4], x3[4], y3[4];
+    h_add(F, u, p.y, p.y);
+    h_mul(F, v, u, u);
+    h_mul(F, w, u, v);
+    h_mul(F, s, p.x, v);
+    h_mul(F, t, p.x, p.x);
+    h_add(F, m, t, t);
+    h_add(F, m, m, t);                 // 3 x^2 (a = 0)
+    h_mul(F, x3, m, m);
+    h_sub(F, x3, x3, s);
+    h_sub(F, x3, x3, s);
+    h_sub(F, t, s, x3);
+    h_mul(F, y3, m, t);
+    h_mul(F, t, w, p.y);
+    h_sub(F, y3, y3, t);
+    h_mul(F, o.zz, v, p.zz);
+    h_mul(F, o.zzz, w, p.zzz);
+    memcpy(o.x, x3, 32);
+    memcpy(o.y, y3, 32);
+}
+static void hx_add(HXyzz& o, const HXyzz& a, const HXyzz& b) {
+    const HostField& F = HFQ;
+    if (h_is_zero(a.zz)) {
+        o = b;
+        return;
+    }
+    if (h_is_zero(b.zz)) {
+        o = a;
+        return;
+    }
+    uint64_t u1[4], u2[4], s1[4], s2[4], p[4], r[4];
+    h_mul(F, u1, a.x, b.zz);
+    h_mul(F, u2, b.x, a.zz);
+    h_mul(F, s1, a.y, b.zzz);
+    h_mul(F, s2, b.y, a.zzz);
+    h_sub(F, p, u2, u1);
+    h_sub(F, r, s2, s1);
+    if (h_is_zero(p)) {
+        if (h_is_zero(r)) {
+            hx_double(o, a);
+        } else {
+            memset(&o, 0, sizeof o);
+        }
+        return;
+    }
+    uint64_t pp[4], ppp[4], q[4], x3[4], y3[4], t[4];
+    h_mul(F, pp, p, p);
+    h_mul(F, ppp, p, pp);
+    h_mul(F, q, u1, pp);
+    h_mul(F, x3, r, r);
+    h_sub(F, x3, x3, ppp);
+    h_sub(F, x3, x3, q);
+    h_sub(F, x3, x3, q);
+    h_sub(F, t, q, x3);
+    h_mul(F, y3, r, t);
+    h_mul(F, t, s1, ppp);
+    h_sub(F, y3, y3, t);
+    h_mul(F, t, a.zz, b.zz);
+    h_mul(F, o.zz, t, pp);
+    h_mul(F, t, a.zzz, b.zzz);
+    h_mul(F, o.zzz, t, ppp);
+    memcpy(o.x, x3, 32);
+    memcpy(o.y, y3, 32);
 }
 
 // phase 3: waits for the leftover sums of the reduce and joins them on the host:
 //   result = total + sum_{t < 15} 2^t X_t,  X_t = sum over the waves of B_t for t < 6, D_(t - 6) for t >= 6
 // (bucket b = 64 h + l weighs b + 1 = 64 h + l + 1), by Horner: 14 doublings and 15 additions, after the two halves of
-// level 2 have been added up (D_8 = total of the upper half).
+// level 2 have been added up (D_8 = total of the upper half).  The fold stays in XYZZ coordinates (an addition is 14
+// field products, and nothing is converted until the end); the device's x 2^261 become the host's x 2^256 by one
+// product with 1 / 32 per coordinate.
 static int msm_phase3(zkhip_ctx* ctx, MsmWorkspace& ws, uint64_t out_jacobian[12]) {
     ZK_HIP(ctx, hipEventSynchronize(ws.ev_done));   // this MSM's sums have arrived (the stream may hold later MSMs' work)
     memset(out_jacobian, 0, 96);
     if (!ws.nonzero) return ZKHIP_OK;
-    uint64_t pt[2][15][12];
+    const auto t_begin = std::chrono::steady_clock::now();
+    struct Inv32 {
+        uint64_t v[4];
+        Inv32() {
+            uint64_t k32[4];
+            h_from_u64(HFQ, k32, 32);
+            h_inv(HFQ, v, k32);
+        }
+    };
+    static const Inv32 inv32;
+    HXyzz pt[2][15];
     for (int hf = 0; hf < 2; hf++)
-        for (int i = 0; i < 15; i++) xyzz_to_jacobian_host(pt[hf][i], ws.h_sums + 16 * (15 * hf + i));
-    uint64_t acc[12], t[12];
-    memset(acc, 0, sizeof acc);
+        for (int i = 0; i < 15; i++) {
+            const uint64_t* in = ws.h_sums + 16 * (15 * hf + i);
+            HXyzz& q = pt[hf][i];
+            h_mul(HFQ, q.x, in, inv32.v);
+            h_mul(HFQ, q.y, in + 4, inv32.v);
+            h_mul(HFQ, q.zz, in + 8, inv32.v);
+            h_mul(HFQ, q.zzz, in + 12, inv32.v);
+        }
+    HXyzz acc, t;
+    memset(&acc, 0, sizeof acc);
     for (int k = 14; k >= 0; k--) {
-        h_g1_double(acc, acc);
+        hx_double(acc, acc);
         if (k == 14) {
-            memcpy(t, pt[1][0], sizeof t);                       // D_8
+            t = pt[1][0];                                        // D_8
         } else {
             const int idx = k < 6 ? 9 + k : 1 + (k - 6);        // B_k or D_(k - 6)
-            h_g1_add(t, pt[0][idx], pt[1][idx]);
+            hx_add(t, pt[0][idx], pt[1][idx]);
         }
-        h_g1_add(acc, acc, t);
+        hx_add(acc, acc, t);
     }
-    h_g1_add(t, pt[0][0], pt[1][0]);
-    h_g1_add(acc, acc, t);
-    memcpy(out_jacobian, acc, 96);
+    hx_add(t, pt[0][0], pt[1][0]);
+    hx_add(acc, acc, t);
+    // XYZZ -> Jacobian: X' = X ZZ ZZZ^2, Y' = Y ZZ^3 ZZZ^2, Z' = ZZ ZZZ
+    if (!h_is_zero(acc.zz)) {
+        uint64_t zzz2[4], zz2[4], zz3[4], u[4];
+        h_mul(HFQ, zzz2, acc.zzz, acc.zzz);
+        h_mul(HFQ, zz2, acc.zz, acc.zz);
+        h_mul(HFQ, zz3, zz2, acc.zz);
+        h_mul(HFQ, u, acc.x, acc.zz);
+        h_mul(HFQ, out_jacobian, u, zzz2);
+        h_mul(HFQ, u, acc.y, zz3);
+        h_mul(HFQ, out_jacobian + 4, u, zzz2);
+        h_mul(HFQ, out_jacobian + 8, acc.zz, acc.zzz);
+    }
+    if (ctx->timing) {
+        auto& slot = ctx->timers["msm_host_fold"];
+        slot.total_us += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_begin).count();
+        slot.launches++;
+    }
     return ZKHIP_OK;
 }
 
