@@ -37,10 +37,6 @@ using namespace zkhip;
 namespace zkhip {
 
 constexpr int HIST_THREADS = 1024;
-// Workgroup size of the counting kernels in a pipelined batch of dense columns.  The accumulate kernels of the MSMs before
-// keep three waves of 152 registers on every SIMD: what is left is one wave of at most 56 registers per SIMD, i.e.
-// workgroups of 256 lanes.  Larger workgroups wait until a compute unit has drained (a 24 us histogram: 230 us).
-constexpr int SMALL_THREADS = 256;
 constexpr uint32_t ENTRY_IDX_BITS = 26;
 constexpr uint32_t ENTRY_IDX_MASK = (1u << ENTRY_IDX_BITS) - 1;
 
@@ -109,10 +105,10 @@ __global__ void __launch_bounds__(HIST_THREADS) digits_hist_kernel(const fe* sca
     constexpr uint32_t B = 1u << (C - 1), W = windows_for(C);
     const uint32_t g = blockIdx.x;
     uint32_t* binh = hist + B;
-    for (uint32_t b = threadIdx.x; b < B + 256; b += blockDim.x) hist[b] = 0;
+    for (uint32_t b = threadIdx.x; b < B + 256; b += HIST_THREADS) hist[b] = 0;
     __syncthreads();
     const size_t lo = (size_t)g * chunk, hi = lo + chunk < n ? lo + chunk : n;
-    for (size_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+    for (size_t i = lo + threadIdx.x; i < hi; i += HIST_THREADS) {
         int32_t d[W];
         signed_digits<C>(fr_canonical(load_fe(scalars + i)), d);
 #pragma unroll
@@ -120,7 +116,7 @@ __global__ void __launch_bounds__(HIST_THREADS) digits_hist_kernel(const fe* sca
             if (d[w] != 0) atomicAdd(&hist[(d[w] < 0 ? -d[w] : d[w]) - 1], 1u);
     }
     __syncthreads();
-    for (uint32_t b = threadIdx.x; b < B; b += blockDim.x) {   // a wave covers 64 buckets of one bin
+    for (uint32_t b = threadIdx.x; b < B; b += HIST_THREADS) {   // a wave covers 64 buckets of one bin
         const uint32_t v = hist[b];
         counts[(size_t)g * B + b] = v;
         uint32_t t = v;
@@ -128,7 +124,7 @@ __global__ void __launch_bounds__(HIST_THREADS) digits_hist_kernel(const fe* sca
         if ((threadIdx.x & 63) == 0 && t) atomicAdd(&binh[b >> 7], t);
     }
     __syncthreads();
-    for (uint32_t q = threadIdx.x; q < 256; q += blockDim.x) bincount[(size_t)g * 256 + q] = binh[q];
+    if (threadIdx.x < 256) bincount[(size_t)g * 256 + threadIdx.x] = binh[threadIdx.x];
 }
 
 // ---- two-level scatter ------------------------------------------------------------------------------
@@ -354,12 +350,11 @@ __global__ void __launch_bounds__(COLSUM_THREADS) column_sum_kernel(const uint32
                                                                     uint32_t* cnt, const SlotLadder ladder, uint32_t* plan) {
     __shared__ uint32_t sh[PLAN_STRIDE];
     __shared__ uint32_t part[COLSUM_THREADS / 64][256];
-    for (uint32_t i = threadIdx.x; i < PLAN_STRIDE; i += blockDim.x) sh[i] = 0;
-    const uint32_t nw = blockDim.x >> 6;   // waves of the workgroup: 16, or 4 in a pipelined batch
+    for (uint32_t i = threadIdx.x; i < PLAN_STRIDE; i += COLSUM_THREADS) sh[i] = 0;
     const uint32_t lane = threadIdx.x & 63, rg = threadIdx.x >> 6, b4 = blockIdx.x * 256 + 4 * lane;
     uint4 acc = make_uint4(0, 0, 0, 0);
     if (b4 < B) {   // B is a multiple of 128, so four buckets are inside together
-        for (uint32_t g = rg; g < G; g += nw) {
+        for (uint32_t g = rg; g < G; g += COLSUM_THREADS / 64) {
             const uint4 v = *reinterpret_cast<const uint4*>(counts + (size_t)g * B + b4);
             acc.x += v.x;
             acc.y += v.y;
@@ -372,7 +367,8 @@ __global__ void __launch_bounds__(COLSUM_THREADS) column_sum_kernel(const uint32
     __shared__ uint32_t cv[256];
     if (threadIdx.x < 256) {
         uint32_t run = 0;
-        for (uint32_t k = 0; k < nw; k++) run += part[k][threadIdx.x];
+#pragma unroll
+        for (int k = 0; k < COLSUM_THREADS / 64; k++) run += part[k][threadIdx.x];
         const uint32_t b = blockIdx.x * 256 + threadIdx.x;
         if (b < B) cnt[b] = run;
         cv[threadIdx.x] = run;
@@ -394,7 +390,7 @@ __global__ void __launch_bounds__(COLSUM_THREADS) column_sum_kernel(const uint32
         sh[threadIdx.x] = acc;
     }
     __syncthreads();
-    for (uint32_t i = threadIdx.x; i < PLAN_STRIDE; i += blockDim.x) plan[(size_t)blockIdx.x * PLAN_STRIDE + i] = sh[i];
+    for (uint32_t i = threadIdx.x; i < PLAN_STRIDE; i += COLSUM_THREADS) plan[(size_t)blockIdx.x * PLAN_STRIDE + i] = sh[i];
 }
 
 // One block of 1024 lanes (B a power of two, B <= 32768).
@@ -498,134 +494,6 @@ __global__ void __launch_bounds__(1024) bucket_scan_kernel(const uint32_t* cnt, 
                     start_out[idx] = be + offc[r];
                     cur_out[idx] = be + offc[r];
                 }
-            }
-        }
-    }
-    if (tid == 0) {
-        off_out[B] = total;
-        if (info) {
-            info[INFO_SLOTS] = total;
-            info[INFO_HEAVY] = heavy_total;
-        }
-    }
-}
-
-// The same scan and plan for a pipelined batch: one workgroup of SMALL_THREADS lanes and few registers, so that it finds
-// room beside the accumulate kernels of the MSMs before.  Lane t owns the consecutive buckets [t S, (t + 1) S), S = B / 256,
-// and walks them twice: totals first, then, with the lane's offsets known from a scan over the lanes, the outputs.
-__global__ void __launch_bounds__(SMALL_THREADS) bucket_scan_small_kernel(const uint32_t* cnt, uint32_t B, uint32_t D, uint32_t* f_out,
-                                                                          uint32_t* off_out, uint32_t* start_out, uint32_t* cur_out,
-                                                                          const uint32_t* plan, uint32_t plan_blocks,
-                                                                          const SlotLadder ladder, uint32_t round_lanes,
-                                                                          uint32_t force_L, uint32_t* info) {
-    __shared__ uint32_t wsum[3][SMALL_THREADS / 64];
-    __shared__ uint32_t best;
-    __shared__ uint32_t stat[PLAN_STRIDE];
-    const uint32_t tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    if (D == 0) {
-        if (tid == 0) best = 0xffffffffu;
-        if (tid < PLAN_STRIDE) stat[tid] = 0;
-        __syncthreads();
-        {
-            const uint32_t col = tid & (PLAN_STRIDE - 1);
-            uint32_t v = 0;
-#pragma unroll 4
-            for (uint32_t k = tid / PLAN_STRIDE; k < plan_blocks; k += SMALL_THREADS / PLAN_STRIDE) {
-                const uint32_t x = plan[(size_t)k * PLAN_STRIDE + col];
-                v = col == 0 ? (x > v ? x : v) : v + x;
-            }
-            if (col == 0) atomicMax(&stat[0], v);
-            else atomicAdd(&stat[col], v);
-        }
-        __syncthreads();
-        if (tid < PLAN_STRIDE) {
-            const uint32_t v = stat[tid];
-            if (tid == 0) info[INFO_MAXCNT] = v;
-            if (tid == 1) info[INFO_ENTRIES] = v;
-            if (tid >= 2) {
-                const uint32_t L = ladder.L[tid - 2];
-                if (L) {   // the cost model of bucket_scan_kernel
-                    const uint32_t rounds = v == 0 ? 1 : (v + round_lanes - 1) / round_lanes;
-                    uint64_t cost = (uint64_t)rounds * L * 16 + (uint64_t)L * 11 + (uint64_t)(v / B) * 8;
-                    if (cost >= (1u << 20)) cost = (1u << 20) - 1;
-                    atomicMin(&best, ((uint32_t)cost << 12) | (L_MAX + 1 - L));
-                }
-            }
-        }
-        __syncthreads();
-        D = force_L ? force_L : (L_MAX + 1 - (best & 0xfff));
-        if (tid == 0) info[INFO_L] = D;
-    }
-    const uint32_t S = B >= SMALL_THREADS ? B / SMALL_THREADS : 1;   // B is a power of two
-    const uint32_t b0 = tid * S;
-    uint32_t sf = 0, sc = 0, heavy = 0;
-    if (b0 < B) {
-        if (S >= 4) {
-            for (uint32_t i = 0; i < S; i += 4) {
-                const uint4 c = *reinterpret_cast<const uint4*>(cnt + b0 + i);
-                const uint32_t f0 = (c.x + D - 1) / D, f1 = (c.y + D - 1) / D, f2 = (c.z + D - 1) / D, f3 = (c.w + D - 1) / D;
-                sf += f0 + f1 + f2 + f3;
-                sc += c.x + c.y + c.z + c.w;
-                heavy += (f0 > MERGE_DIRECT_MAX ? f0 : 0) + (f1 > MERGE_DIRECT_MAX ? f1 : 0) + (f2 > MERGE_DIRECT_MAX ? f2 : 0) +
-                         (f3 > MERGE_DIRECT_MAX ? f3 : 0);
-            }
-        } else {
-            for (uint32_t i = 0; i < S; i++) {
-                const uint32_t c = cnt[b0 + i], f = (c + D - 1) / D;
-                sf += f;
-                sc += c;
-                heavy += f > MERGE_DIRECT_MAX ? f : 0;
-            }
-        }
-    }
-    const uint32_t inf = wave_inclusive_scan_u32(sf), inc = wave_inclusive_scan_u32(sc);
-    heavy = wave_sum_u32(heavy);
-    if (lane == 63) {
-        wsum[0][wv] = inf;
-        wsum[1][wv] = inc;
-        wsum[2][wv] = heavy;
-    }
-    __syncthreads();
-    uint32_t bs = 0, be = 0, total = 0, heavy_total = 0;
-    for (uint32_t k = 0; k < SMALL_THREADS / 64; k++) {
-        const uint32_t a = wsum[0][k];
-        if (k < wv) {
-            bs += a;
-            be += wsum[1][k];
-        }
-        total += a;
-        heavy_total += wsum[2][k];
-    }
-    uint32_t of = bs + inf - sf, oc = be + inc - sc;
-    if (b0 < B) {
-        if (S >= 4) {
-            for (uint32_t i = 0; i < S; i += 4) {
-                const uint4 c = *reinterpret_cast<const uint4*>(cnt + b0 + i);
-                uint4 f, o, e;
-                f.x = (c.x + D - 1) / D; f.y = (c.y + D - 1) / D; f.z = (c.z + D - 1) / D; f.w = (c.w + D - 1) / D;
-                o.x = of; o.y = o.x + f.x; o.z = o.y + f.y; o.w = o.z + f.z;
-                e.x = oc; e.y = e.x + c.x; e.z = e.y + c.y; e.w = e.z + c.z;
-                of = o.w + f.w;
-                oc = e.w + c.w;
-                // every array starts on a 256-byte boundary of the workspace
-                *reinterpret_cast<uint4*>(f_out + b0 + i) = f;
-                *reinterpret_cast<uint4*>(off_out + b0 + i) = o;
-                if (start_out) {
-                    *reinterpret_cast<uint4*>(start_out + b0 + i) = e;
-                    *reinterpret_cast<uint4*>(cur_out + b0 + i) = e;
-                }
-            }
-        } else {
-            for (uint32_t i = 0; i < S; i++) {
-                const uint32_t c = cnt[b0 + i], f = (c + D - 1) / D;
-                f_out[b0 + i] = f;
-                off_out[b0 + i] = of;
-                if (start_out) {
-                    start_out[b0 + i] = oc;
-                    cur_out[b0 + i] = oc;
-                }
-                of += f;
-                oc += c;
             }
         }
     }
@@ -928,7 +796,6 @@ struct MsmWorkspace {
     uint32_t G = 0, l_min = 0, plan_blocks = 0, acc_blocks = 0;
     SlotLadder ladder;
     bool nonzero = false;
-    bool small_kernels = false;        // counting kernels as small workgroups (set per MSM by the pipelined batch)
     uint32_t *counts, *entries, *start, *cnt, *offA, *cntA, *offB, *cntB, *info, *plan, *cur, *bincount, *hoff;
     uint2* tmp;
     g1_xyzz *itemsA, *itemsB, *sums, *l1, *out2;
@@ -1019,7 +886,6 @@ static int msm_phase1(zkhip_ctx* ctx, MsmWorkspace& ws, const MsmTables& tb, siz
     const size_t chunk = (n + G - 1) / G;
     const size_t lds_hist = (size_t)B * 4 + 256 * 4;
     hipStream_t st = ws.stream;
-    const bool small = ws.small_kernels;
     ZK_CHECK(ctx, tb.W == windows_for(c), "msm: window count %u does not match window width %u", tb.W, c);
 #define ZK_FOR_WINDOW_WIDTH(X) \
     switch (c) {               \
@@ -1035,17 +901,12 @@ static int msm_phase1(zkhip_ctx* ctx, MsmWorkspace& ws, const MsmTables& tb, siz
         default: ZK_CHECK(ctx, false, "msm: unsupported window width %u", c); \
     }
 #define ZK_LAUNCH_HIST(C) \
-    hipLaunchKernelGGL(digits_hist_kernel<C>, dim3(G), dim3(small ? SMALL_THREADS : HIST_THREADS), lds_hist, st, d_scalars, n, chunk, ws.counts, ws.bincount)
+    hipLaunchKernelGGL(digits_hist_kernel<C>, dim3(G), dim3(HIST_THREADS), lds_hist, st, d_scalars, n, chunk, ws.counts, ws.bincount)
     ZK_FOR_WINDOW_WIDTH(ZK_LAUNCH_HIST)
 #undef ZK_LAUNCH_HIST
-    hipLaunchKernelGGL(column_sum_kernel, dim3(ws.plan_blocks), dim3(small ? SMALL_THREADS : COLSUM_THREADS), 0, st, ws.counts, G, B,
-                       ws.cnt, ws.ladder, ws.plan);
-    if (small)
-        hipLaunchKernelGGL(bucket_scan_small_kernel, dim3(1), dim3(SMALL_THREADS), 0, st, ws.cnt, B, 0u, ws.cntA, ws.offA, ws.start,
-                           ws.cur, ws.plan, ws.plan_blocks, ws.ladder, (uint32_t)ctx->num_cus * 256u, FORCE_L, ws.h_info);
-    else
-        hipLaunchKernelGGL(bucket_scan_kernel, dim3(1), dim3(1024), 0, st, ws.cnt, B, 0u, ws.cntA, ws.offA, ws.start, ws.cur, ws.plan,
-                           ws.plan_blocks, ws.ladder, (uint32_t)ctx->num_cus * 256u, FORCE_L, ws.h_info);
+    hipLaunchKernelGGL(column_sum_kernel, dim3(ws.plan_blocks), dim3(COLSUM_THREADS), 0, st, ws.counts, G, B, ws.cnt, ws.ladder, ws.plan);
+    hipLaunchKernelGGL(bucket_scan_kernel, dim3(1), dim3(1024), 0, st, ws.cnt, B, 0u, ws.cntA, ws.offA, ws.start, ws.cur, ws.plan,
+                       ws.plan_blocks, ws.ladder, (uint32_t)ctx->num_cus * 256u, FORCE_L, ws.h_info);
     // the plan is in host memory when this event completes, while scatter and accumulate run
     ZK_HIP(ctx, hipEventRecord(ws.ev_info, st));
     {
@@ -1368,16 +1229,10 @@ static int msm_pipeline(zkhip_ctx* ctx, MsmState& stt, const MsmTables& tb, cons
     for (int i = 0; i < MsmState::N_STREAMS; i++) ZK_HIP(ctx, hipStreamWaitEvent(stt.batch_streams[i], stt.ev_in, 0));
     // software pipeline: phase1(j), phase2(j - 1), phase3(j - 1 - MSM_TAIL_LAG)
     int rc;
-    bool dense_seen = false;
     const size_t lag3 = 1 + MSM_TAIL_LAG;
     for (size_t j = 0; j < batch + lag3; j++) {
         if (j < batch) {
             MsmWorkspace& ws = *pipe[j % MSM_PIPE];
-            // Dense columns keep the device full of accumulate waves: their counting kernels take the small workgroups that
-            // fit beside those.  Sparse columns leave the device mostly free, where the large workgroups are faster.  The
-            // last column whose plan has reached the host stands for this one (columns of a batch are alike).
-            static const uint32_t small_mode = env_u32("ZKHIP_MSM_SMALL", 2);   // 0 never, 1 always, 2 by density
-            ws.small_kernels = small_mode == 1 || (small_mode == 2 && dense_seen);
             {
                 TimedRegion tr(ctx, timed ? "msm_sort" : nullptr, ws.stream);
                 rc = msm_phase1(ctx, ws, tb, items[j].first, items[j].d_scalars, items[j].n);
@@ -1389,10 +1244,8 @@ static int msm_pipeline(zkhip_ctx* ctx, MsmState& stt, const MsmTables& tb, cons
             if (rc) return rc;
         }
         if (j >= 1 && j - 1 < batch) {
-            MsmWorkspace& prev = *pipe[(j - 1) % MSM_PIPE];
-            rc = msm_phase2(ctx, prev, tb, timed);
+            rc = msm_phase2(ctx, *pipe[(j - 1) % MSM_PIPE], tb, timed);
             if (rc) return rc;
-            dense_seen = (uint64_t)prev.h_info[INFO_ENTRIES] * 2 > (uint64_t)prev.n * tb.W;
         }
         if (j >= lag3 && j - lag3 < batch) {
             rc = msm_phase3(ctx, *pipe[(j - lag3) % MSM_PIPE], out + 12 * (j - lag3));
@@ -1415,7 +1268,6 @@ int msm_run(zkhip_ctx* ctx, MsmState& stt, const MsmTables& tb, size_t first, co
     MsmWorkspace& ws = stt.ws[0];
     ws.stream = ctx->stream;
     ws.acc_stream = ws.tail_stream = nullptr;      // a lone MSM has nothing to overlap with: one stream
-    ws.small_kernels = false;
     {
         TimedRegion tr(ctx, "msm_sort");
         rc = msm_phase1(ctx, ws, tb, first, d_scalars, n);
