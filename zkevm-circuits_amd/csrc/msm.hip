@@ -1148,11 +1148,24 @@ static int msm_phase3(zkhip_ctx* ctx, MsmWorkspace& ws, uint64_t out_jacobian[12
 }
 
 // Workspaces of a pipelined batch: MSM j is sorted and accumulated while MSM j - 1 is merged and reduced and the sums of
-// MSM j - 1 - MSM_TAIL_LAG .. are joined on the host, so that MSM_TAIL_LAG + 1 merge + reduce tails are in flight, each
-// on its workspace's own stream.  A tail is a chain of dependent point additions (0.2 - 0.5 ms whatever the size): for
-// sparse witness columns, whose other phases take tens of microseconds, the tails in flight set the rate of the batch.
-constexpr int MSM_TAIL_LAG = 3;
-constexpr int MSM_PIPE = 2 + MSM_TAIL_LAG;
+// MSM j - 1 - lag .. are joined on the host, so that lag + 1 merge + reduce tails are in flight, each on its workspace's
+// own stream.  A tail is a chain of dependent point additions (0.2 - 0.5 ms whatever the size): for sparse witness
+// columns, whose other phases take tens of microseconds, the tails in flight set the rate of the batch (64 byte columns
+// of 2^19: 0.252 ms per MSM with a lag of 3, 0.228 with 6 or 8; dense columns 0.79 -> 0.765 ms when they are
+// cache-resident, unchanged when they stream from HBM).  The lag is MSM_TAIL_LAG (ZKHIP_MSM_TAIL_LAG overrides it for
+// measurements), less when the workspaces of that many MSMs would exceed WS_BUDGET_BYTES.
+constexpr int MSM_TAIL_LAG_MAX = 8;
+constexpr int MSM_PIPE = 2 + MSM_TAIL_LAG_MAX;   // workspaces that exist; 2 + the tail lag in use take part
+static const uint32_t MSM_TAIL_LAG = std::min<uint32_t>(MSM_TAIL_LAG_MAX, std::max<uint32_t>(1, env_u32("ZKHIP_MSM_TAIL_LAG", 8)));
+constexpr size_t WS_BUDGET_BYTES = (size_t)8 << 30;
+// upper estimate of one workspace for n scalars (the large arrays of ws_prepare)
+static size_t ws_bytes_estimate(zkhip_ctx* ctx, const MsmTables& tb, size_t n) {
+    const size_t B = (size_t)1 << (tb.c - 1), E = n * tb.W, round_lanes = (size_t)ctx->num_cus * 256;
+    const size_t l_min = std::min<size_t>(64, std::max<size_t>(8, E / (8 * round_lanes)));
+    const size_t G = std::min<size_t>((size_t)ctx->num_cus, (n + HIST_THREADS - 1) / HIST_THREADS);
+    const size_t T1 = E / l_min + B + 1;
+    return E * 12 + (T1 + T1 / 8 + 3 * B + 64) * sizeof(g1_xyzz) + B * std::max<size_t>(G, 1) * 4 + ((size_t)1 << 20);
+}
 struct MsmState {
     std::map<uint32_t, MsmTables> tables;
     MsmWorkspace ws[MSM_PIPE];
@@ -1219,6 +1232,11 @@ static int msm_pipeline(zkhip_ctx* ctx, MsmState& stt, const MsmTables& tb, cons
                 ZK_HIP(ctx, hipStreamCreateWithFlags(&stt.batch_streams[i], hipStreamNonBlocking));
         }
     }
+    size_t n_max = 1;
+    for (const MsmItem& it : items) n_max = std::max(n_max, it.n);
+    const size_t fit = WS_BUDGET_BYTES / ws_bytes_estimate(ctx, tb, n_max);
+    const size_t lag = std::min<size_t>(MSM_TAIL_LAG, fit > 3 ? fit - 2 : 1);
+    const size_t depth = 2 + lag;   // workspaces in the rotation
     for (int i = 0; i < MSM_PIPE; i++) {
         stt.ws[i].stream = stt.batch_streams[0];
         stt.ws[i].acc_stream = stt.batch_streams[1];
@@ -1229,10 +1247,10 @@ static int msm_pipeline(zkhip_ctx* ctx, MsmState& stt, const MsmTables& tb, cons
     for (int i = 0; i < MsmState::N_STREAMS; i++) ZK_HIP(ctx, hipStreamWaitEvent(stt.batch_streams[i], stt.ev_in, 0));
     // software pipeline: phase1(j), phase2(j - 1), phase3(j - 1 - MSM_TAIL_LAG)
     int rc;
-    const size_t lag3 = 1 + MSM_TAIL_LAG;
+    const size_t lag3 = 1 + lag;
     for (size_t j = 0; j < batch + lag3; j++) {
         if (j < batch) {
-            MsmWorkspace& ws = *pipe[j % MSM_PIPE];
+            MsmWorkspace& ws = *pipe[j % depth];
             {
                 TimedRegion tr(ctx, timed ? "msm_sort" : nullptr, ws.stream);
                 rc = msm_phase1(ctx, ws, tb, items[j].first, items[j].d_scalars, items[j].n);
@@ -1244,11 +1262,11 @@ static int msm_pipeline(zkhip_ctx* ctx, MsmState& stt, const MsmTables& tb, cons
             if (rc) return rc;
         }
         if (j >= 1 && j - 1 < batch) {
-            rc = msm_phase2(ctx, *pipe[(j - 1) % MSM_PIPE], tb, timed);
+            rc = msm_phase2(ctx, *pipe[(j - 1) % depth], tb, timed);
             if (rc) return rc;
         }
         if (j >= lag3 && j - lag3 < batch) {
-            rc = msm_phase3(ctx, *pipe[(j - lag3) % MSM_PIPE], out + 12 * (j - lag3));
+            rc = msm_phase3(ctx, *pipe[(j - lag3) % depth], out + 12 * (j - lag3));
             if (rc) return rc;
         }
     }
