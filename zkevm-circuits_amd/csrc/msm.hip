@@ -1170,7 +1170,7 @@ struct MsmState {
     std::map<uint32_t, MsmTables> tables;
     MsmWorkspace ws[MSM_PIPE];
     // streams: [0] recode / count / plan / scatter, [1] accumulate, [2 + i] merge + reduce of workspace i
-    static constexpr int N_STREAMS = 2 + MSM_PIPE;
+    static constexpr int N_STREAMS = 3 + MSM_PIPE;   // the last one: the sort stream of the odd workspaces
     hipEvent_t ev_in = nullptr, ev_out[N_STREAMS] = {};
     hipStream_t batch_streams[N_STREAMS] = {};
 };
@@ -1238,7 +1238,12 @@ static int msm_pipeline(zkhip_ctx* ctx, MsmState& stt, const MsmTables& tb, cons
     const size_t lag = std::min<size_t>(MSM_TAIL_LAG, fit > 3 ? fit - 2 : 1);
     const size_t depth = 2 + lag;   // workspaces in the rotation
     for (int i = 0; i < MSM_PIPE; i++) {
-        stt.ws[i].stream = stt.batch_streams[0];
+        // Two sort streams, for the workspaces of even and odd MSMs: the sort of a 2^19 column is five kernels of which
+        // none fills the device, so two of them overlap well (64 distinct dense columns 0.79 -> 0.765 ms per MSM, sparse
+        // columns 0.18 -> 0.148; byte columns, whose heavy buckets keep the tails busy, 0.232 -> 0.246).
+        // ZKHIP_MSM_TWO_SORT=0 puts every sort on one stream (measurements).
+        static const bool two_sort = env_u32("ZKHIP_MSM_TWO_SORT", 1) != 0;
+        stt.ws[i].stream = (two_sort && (i & 1)) ? stt.batch_streams[MsmState::N_STREAMS - 1] : stt.batch_streams[0];
         stt.ws[i].acc_stream = stt.batch_streams[1];
         stt.ws[i].tail_stream = stt.batch_streams[2 + i];
         pipe[i] = &stt.ws[i];
