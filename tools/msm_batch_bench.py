@@ -45,8 +45,13 @@ if mode == "permuted":
         dom.lookup_permute_dev(inp.data_ptr(), t.data_ptr(), n - 6, pa.data_ptr(), ps.data_ptr())
         out += [pa, ps]
     cols = out[:8]
+if mode == "distinct":      # as many different dense columns as the batch has members: they stream from HBM, as in a proof
+    cols = []
+    for _ in range(batch):
+        t = torch.randint(-(1 << 63), (1 << 63) - 1, (n, 4), dtype=torch.int64, device="cuda", generator=gen); t[:, 3] &= 0x0FFFFFFFFFFFFFFF
+        cols.append(t)
 torch.cuda.synchronize()
-ptrs = [cols[i % 8].data_ptr() for i in range(batch)]
+ptrs = [cols[i % len(cols)].data_ptr() for i in range(batch)]
 ctx.msm_batch_dev(bid, ptrs[:4], n)
 t0 = time.perf_counter()
 ctx.msm_batch_dev(bid, ptrs, n)
