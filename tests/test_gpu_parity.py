@@ -170,6 +170,13 @@ def test_msm_batch_with_skewed_columns_matches_single_calls(ctx):
         assert np.array_equal(ctx.g1_to_affine(batch[i]), ctx.g1_to_affine(ctx.msm_range_dev(bid, 0, d, n))), i
     # all ones: sum of the bases = (n (n + 1) / 2) G
     assert affine_pt(ctx.g1_to_affine(batch[3])) == bn.g1_mul(bn.G1_GENERATOR, n * (n + 1) // 2)
+    # a batch longer than the ring of workspaces (ten, with two sort and two accumulate streams and nine tails in
+    # flight): every workspace is reused, with a column of another distribution than it held before
+    singles = [ctx.g1_to_affine(ctx.msm_range_dev(bid, 0, d, n)) for d in d_cols]
+    order = [(5 * i + 3) % len(d_cols) for i in range(27)]
+    long_batch = ctx.msm_batch_dev(bid, [d_cols[k] for k in order], n)
+    for i, k in enumerate(order):
+        assert np.array_equal(ctx.g1_to_affine(long_batch[i]), singles[k]), (i, k)
     for d in d_cols:
         ctx.free(d)
     ctx.release_bases(bid)
