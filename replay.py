@@ -158,10 +158,10 @@ def main():
     # draws its values from the table, as a satisfied lookup does
     usable = n - (cs.blinding_factors() + 1)
 
-    def lookup_permute():
-        for i in range(L):
-            dom.lookup_permute_dev(colptr(lk_cols, 4 * i, n), colptr(lk_cols, 4 * i + 1, n), usable,
-                                   colptr(lk_cols, 4 * i + 2, n), colptr(lk_cols, 4 * i + 3, n))
+    def lookup_permute():   # all lookups of the proof in one batched call, as prover.create_proof issues them
+        dom.lookup_permute_batch_dev([colptr(lk_cols, 4 * i, n) for i in range(L)], [colptr(lk_cols, 4 * i + 1, n) for i in range(L)],
+                                     usable, [colptr(lk_cols, 4 * i + 2, n) for i in range(L)],
+                                     [colptr(lk_cols, 4 * i + 3, n) for i in range(L)])
     with torch.cuda.stream(stream):
         view = lk_cols.view(L, 4, n, 4)
         pick = torch.randint(0, usable, (n,), device="cuda", generator=gen)
