@@ -151,9 +151,25 @@ class Context:
         self._pinned = {}                 # address -> bytes of the page-locked host buffers handed out by host_zeros
         self.allocated_bytes = 0
         self.peak_allocated_bytes = 0
+        # Freed blocks are kept by size and handed out again: a proof allocates and frees well over a hundred column-sized
+        # buffers, and every hipFree waits for the device.  Reuse is safe on the context's stream order (the library's
+        # internal streams join it at the end of each call; overlapped uploads start behind it).
+        self._pool = {}
+        self._pooled_bytes = 0
+
+    POOL_CAP_BYTES = 4 << 30
+
+    def release_pool(self):
+        """returns every pooled block to the device"""
+        for size, blocks in self._pool.items():
+            for d in blocks:
+                self._l.zkhip_dev_free(self.h, C.c_void_p(d))
+        self._pool = {}
+        self._pooled_bytes = 0
 
     def close(self):
         if getattr(self, "h", None):
+            self.release_pool()
             for addr in list(getattr(self, "_pinned", {})):
                 self._l.zkhip_host_free(self.h, C.c_void_p(addr))
             self._pinned = {}
@@ -178,22 +194,41 @@ class Context:
         self._ck(self._l.zkhip_sync(self.h))
 
     def alloc(self, nbytes: int) -> int:
-        d = C.c_void_p()
-        self._ck(self._l.zkhip_dev_alloc(self.h, C.c_size_t(nbytes), C.byref(d)))
-        self._sizes[d.value] = nbytes
+        blocks = self._pool.get(nbytes)
+        if blocks:
+            addr = blocks.pop()
+            self._pooled_bytes -= nbytes
+        else:
+            d = C.c_void_p()
+            rc = self._l.zkhip_dev_alloc(self.h, C.c_size_t(nbytes), C.byref(d))
+            if rc != 0 and self._pooled_bytes:        # the pool may hold what this request needs
+                self.release_pool()
+                rc = self._l.zkhip_dev_alloc(self.h, C.c_size_t(nbytes), C.byref(d))
+            self._ck(rc)
+            addr = d.value
+        self._sizes[addr] = nbytes
         self.allocated_bytes += nbytes
         self.peak_allocated_bytes = max(self.peak_allocated_bytes, self.allocated_bytes)
-        return d.value
+        return addr
 
     def free(self, dptr: int):
-        self._ck(self._l.zkhip_dev_free(self.h, C.c_void_p(dptr)))
-        self.allocated_bytes -= self._sizes.pop(dptr, 0)
+        size = self._sizes.pop(dptr, None)
+        if size is None:                              # not one of alloc()'s blocks
+            self._ck(self._l.zkhip_dev_free(self.h, C.c_void_p(dptr)))
+            return
+        self.allocated_bytes -= size
+        if self._pooled_bytes + size <= self.POOL_CAP_BYTES:
+            self._pool.setdefault(size, []).append(dptr)
+            self._pooled_bytes += size
+        else:
+            self._ck(self._l.zkhip_dev_free(self.h, C.c_void_p(dptr)))
 
     def mem_info(self):
-        """(free, total) bytes of device memory"""
+        """(free, total) bytes of device memory; blocks waiting in the pool count as free (alloc gives them back to the
+        device when a request needs the room)"""
         free, total = C.c_size_t(), C.c_size_t()
         self._ck(self._l.zkhip_mem_info(self.h, C.byref(free), C.byref(total)))
-        return free.value, total.value
+        return free.value + self._pooled_bytes, total.value
 
     def reset_peak(self):
         self.peak_allocated_bytes = self.allocated_bytes

@@ -161,12 +161,17 @@ class OsFieldRng:
 
 
 def collect_queries(cs: ConstraintSystem):
-    """(advice_queries, fixed_queries, instance_queries) as [(column, rotation)], each in order of first appearance."""
-    out = {"advice": [], "fixed": [], "instance": []}
+    """(advice_queries, fixed_queries, instance_queries) as [(column, rotation)], each in order of first appearance.
+    Upstream's ConstraintSystem carries these lists as fields filled while the circuit is configured; here they are
+    derived once per constraint system and kept on it."""
+    return cs._memo("queries", lambda: _collect_queries(cs))
+
+
+def _collect_queries(cs: ConstraintSystem):
+    out = {"advice": {}, "fixed": {}, "instance": {}}     # insertion-ordered sets
 
     def add(kind, q):
-        if q not in out[kind]:
-            out[kind].append(q)
+        out[kind].setdefault(q, None)
 
     def walk(e):
         t = e[0]
@@ -187,7 +192,7 @@ def collect_queries(cs: ConstraintSystem):
     names = {ANY_ADVICE: "advice", ANY_FIXED: "fixed", ANY_INSTANCE: "instance"}
     for kind, idx in cs.permutation_columns:
         add(names[kind], (idx, 0))
-    return out["advice"], out["fixed"], out["instance"]
+    return list(out["advice"]), list(out["fixed"]), list(out["instance"])
 
 
 class ParamsKZG:
