@@ -73,6 +73,8 @@ int zkhip_upload_overlapped(zkhip_ctx* ctx, void* dptr, const void* host, size_t
 int zkhip_upload_fence(zkhip_ctx* ctx);
 int zkhip_upload(zkhip_ctx* ctx, void* dptr, const void* host, size_t bytes);
 int zkhip_download(zkhip_ctx* ctx, void* host, const void* dptr, size_t bytes);
+/* device-to-device copy on the context's stream, asynchronous (a column kept in two forms at once) */
+int zkhip_copy_dev(zkhip_ctx* ctx, void* d_dst, const void* d_src, size_t bytes);
 
 /* ------------------------------------------------------------------ field / curve vector ops -----
  * Element-wise helpers used by the parity tests and by callers that keep polynomials on the device

@@ -295,6 +295,11 @@ int zkhip_upload(zkhip_ctx* ctx, void* dptr, const void* host, size_t bytes) {
     ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return ZKHIP_OK;
 }
+int zkhip_copy_dev(zkhip_ctx* ctx, void* d_dst, const void* d_src, size_t bytes) {
+    if (!ctx || ((!d_dst || !d_src) && bytes)) return ZKHIP_ERR_INVALID;
+    if (bytes) ZK_HIP(ctx, hipMemcpyAsync(d_dst, d_src, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+    return ZKHIP_OK;
+}
 int zkhip_download(zkhip_ctx* ctx, void* host, const void* dptr, size_t bytes) {
     if (!ctx || (!dptr && bytes) || (!host && bytes)) return ZKHIP_ERR_INVALID;
     ZK_HIP(ctx, hipMemcpyAsync(host, dptr, bytes, hipMemcpyDeviceToHost, ctx->stream));

@@ -16,7 +16,7 @@ _LIB = None
 
 EXPORTS = [
     "zkhip_create", "zkhip_destroy", "zkhip_last_error", "zkhip_version", "zkhip_set_stream", "zkhip_sync",
-    "zkhip_dev_alloc", "zkhip_dev_free", "zkhip_mem_info", "zkhip_upload", "zkhip_download",
+    "zkhip_dev_alloc", "zkhip_dev_free", "zkhip_mem_info", "zkhip_upload", "zkhip_download", "zkhip_copy_dev",
     "zkhip_host_alloc", "zkhip_host_free", "zkhip_upload_async", "zkhip_upload_overlapped", "zkhip_upload_fence",
     "zkhip_field_binop", "zkhip_field_batch_invert", "zkhip_g1_add_affine", "zkhip_g1_multiples", "zkhip_probe_mad_rate", "zkhip_selftest_arithmetic",
     "zkhip_register_bases", "zkhip_release_bases", "zkhip_msm", "zkhip_msm_batch_dev", "zkhip_msm_range_dev",
@@ -279,6 +279,10 @@ class Context:
             if base <= addr and addr + arr.nbytes <= base + size:
                 return True
         return False
+
+    def copy_dev(self, d_dst: int, d_src: int, nbytes: int):
+        """device-to-device copy on the context's stream (asynchronous)"""
+        self._ck(self._l.zkhip_copy_dev(self.h, C.c_void_p(d_dst), C.c_void_p(d_src), C.c_size_t(nbytes)))
 
     def download(self, dptr: int, shape) -> np.ndarray:
         out = np.empty(shape, dtype=np.uint64)

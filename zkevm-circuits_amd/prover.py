@@ -412,6 +412,38 @@ def create_proof(ctx, dom, params: ParamsKZG, pk: ProvingKey, advice, instance, 
         adv, inst = slot[:n_adv], slot[n_adv:n_adv + n_inst]
         lk_slots = [slot[n_adv + n_inst + 3 * i:n_adv + n_inst + 3 * i + 3] for i in range(n_lk)]
         perm_z = slot[total - sets:]
+        # When every extended coset fits the device at once (the single-GPU path of the quotient phase below), the
+        # extended form of an advice column is computed as soon as the column has arrived and been committed: it needs no
+        # challenge, and while the witness crosses the host link the multiplier has little else to do.  The column then
+        # exists in three forms: Lagrange (where it was uploaded: lookups and the permutation argument read it),
+        # coefficient (`early_coeff`, moved over the Lagrange form when the quotient phase starts) and extended.
+        BATCH = 64
+        sharded = dist is not None and dist.is_initialized() and dist.get_world_size() > 1
+        early_ext = early_coeff = None
+        early_done = set()
+        if (not sharded and coset_groups in (None, 1) and pk.polys.cosets is None and n_adv
+                and en * 32 * (total + 3 * BATCH) + n * 32 * n_adv <= 0.85 * ctx.mem_info()[0]):
+            early_ext = alloc(en * max(total, 1))
+            early_coeff = alloc(n * n_adv)
+
+        def extend_early(cols):
+            """coefficient and extended form of freshly committed advice columns (maximal runs of neighbouring columns
+            go out as batches)"""
+            if early_ext is None:
+                return
+            cols = sorted(cols)
+            i = 0
+            while i < len(cols):
+                j = i
+                while j + 1 < len(cols) and cols[j + 1] == cols[j] + 1 and j + 1 - i < BATCH:
+                    j += 1
+                c0, cnt = cols[i], j - i + 1
+                ctx.copy_dev(early_coeff + c0 * n * 32, adv[c0], cnt * n * 32)
+                dom.lagrange_to_coeff_dev(early_coeff + c0 * n * 32, cnt)
+                dom.coeff_to_extended_dev(early_coeff + c0 * n * 32, early_ext + c0 * en * 32, cnt)
+                early_done.update(cols[i:j + 1])
+                i = j + 1
+
         for col, d in zip(instance, inst):
             for v in col:
                 transcript.common_scalar(v)
@@ -436,18 +468,25 @@ def create_proof(ctx, dom, params: ParamsKZG, pk: ProvingKey, advice, instance, 
                 GROUP = 32
                 stage = ctx.host_zeros((len(columns), n - usable, 4))      # the blinding rows of every column
                 try:
-                    pending = None
-                    for g0 in range(0, len(columns), GROUP):
-                        group = columns[g0:g0 + GROUP]
-                        for i, c in enumerate(group, g0):
+                    groups = [columns[g0:g0 + GROUP] for g0 in range(0, len(columns), GROUP)]
+
+                    def issue(gi):
+                        for i, c in enumerate(groups[gi], gi * GROUP):
                             stage[i] = fr_limbs(draws(n - usable))
                             ctx.upload_overlapped(assigned[c], adv[c])
                             ctx.upload_overlapped(stage[i], adv[c] + usable * 32)
-                        if pending is not None:
-                            points.extend(params.commit_lagrange(pending, dist))
-                        ctx.upload_fence()
-                        pending = [adv[c] for c in group]
-                    points.extend(params.commit_lagrange(pending, dist))
+
+                    issue(0)
+                    for gi, group in enumerate(groups):
+                        ctx.upload_fence()                      # the compute stream waits for this group's copies
+                        if gi + 1 < len(groups):
+                            # queued before any kernel of this round: the first copy after a fence starts behind what the
+                            # compute stream holds at that moment, which is nothing but the wait above
+                            issue(gi + 1)
+                        if gi:
+                            extend_early(groups[gi - 1])
+                        points.extend(params.commit_lagrange([adv[c] for c in group], dist))
+                    extend_early(groups[-1])
                 finally:
                     ctx.host_free(stage)
             else:
@@ -535,14 +574,27 @@ def create_proof(ctx, dom, params: ParamsKZG, pk: ProvingKey, advice, instance, 
         mark("quotient")
         per_lookup = [(lk[4], lk[2], lk[3]) for lk in lookups]
         assert [p for t in per_lookup for p in t] == slot[n_adv + n_inst:total - sets]
-        BATCH = 64
-        for s0 in range(0, total, BATCH):
-            dom.lagrange_to_coeff_dev(slot[s0], min(BATCH, total - s0))
+        todo = [i for i in range(total) if i not in early_done]      # slots still in Lagrange form only (advice slots come first)
+
+        def runs(idx):
+            """maximal runs of neighbouring slots, at most BATCH long: (first, count)"""
+            out, i = [], 0
+            while i < len(idx):
+                j = i
+                while j + 1 < len(idx) and idx[j + 1] == idx[j] + 1 and j + 1 - i < BATCH:
+                    j += 1
+                out.append((idx[i], j - i + 1))
+                i = j + 1
+            return out
+
+        for s0, cnt in runs(todo):
+            dom.lagrange_to_coeff_dev(slot[s0], cnt)
+        for c0, cnt in runs(sorted(early_done)):                     # their coefficient form replaces the Lagrange form
+            ctx.copy_dev(slot[c0], early_coeff + c0 * n * 32, cnt * n * 32)
         call = evalh_host.EvalhCall(cs, pk.ev)
         call.challenges = ch_limbs
         call.y, call.beta, call.gamma, call.theta = limb(y), limb(beta), limb(gamma), limb(theta)
         d_h = alloc(en)
-        sharded = dist is not None and dist.is_initialized() and dist.get_world_size() > 1
 
         def fill(of_poly, of_key):
             """of_poly: coefficient polynomial -> its evaluations; of_key: extended key vector -> the same rows of it"""
@@ -563,6 +615,8 @@ def create_proof(ctx, dom, params: ParamsKZG, pk: ProvingKey, advice, instance, 
             # (what the ranks of the multi-GPU split do side by side), which holds 1 / groups of the cosets at a time.
             free_bytes = ctx.mem_info()[0]
             m = en // n
+            if early_ext is not None:
+                coset_groups = 1                   # the block of all extended cosets is already there
             if coset_groups is None:
                 coset_groups = 1
                 while coset_groups < m and (en // coset_groups) * 32 * (total + 3 * BATCH) > 0.85 * free_bytes:
@@ -571,9 +625,9 @@ def create_proof(ctx, dom, params: ParamsKZG, pk: ProvingKey, advice, instance, 
                 raise ValueError("coset_groups must be a power of two between 1 and the number of cosets")
             BATCH = max(1, min(BATCH, int(0.1 * free_bytes) // (3 * en * 32)))
         if not sharded and coset_groups == 1:
-            ext_block = alloc(en * max(total, 1))
-            for s0 in range(0, total, BATCH):
-                dom.coeff_to_extended_dev(slot[s0], ext_block + s0 * en * 32, min(BATCH, total - s0))
+            ext_block = early_ext if early_ext is not None else alloc(en * max(total, 1))
+            for s0, cnt in runs(todo):
+                dom.coeff_to_extended_dev(slot[s0], ext_block + s0 * en * 32, cnt)
             fill(lambda p: ext_block + (p - block) // (n * 32) * en * 32, lambda p: p)
             mark("quotient_evaluate_h")
             dom.evaluate_h(call.build(ffi.MEM_DEVICE, ffi.FORM_EXTENDED), d_h)
