@@ -7,6 +7,9 @@ sys.path.insert(0, ROOT)
 import zkhip_pkg
 zk = zkhip_pkg.load()
 ctx = zk.Context(0)
+if os.environ.get("TORCH_STREAM"):        # as bench.py and the prover run: the context on a stream of torch's
+    _stream = torch.cuda.Stream()
+    ctx.set_stream(_stream.cuda_stream)
 k, batch = 19, int(sys.argv[1]) if len(sys.argv) > 1 else 64
 n = 1 << k
 bases = ctx.g1_multiples(n); bid = ctx.register_bases(bases)

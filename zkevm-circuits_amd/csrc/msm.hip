@@ -1169,10 +1169,12 @@ static size_t ws_bytes_estimate(zkhip_ctx* ctx, const MsmTables& tb, size_t n) {
 struct MsmState {
     std::map<uint32_t, MsmTables> tables;
     MsmWorkspace ws[MSM_PIPE];
-    // streams: [0] recode / count / plan / scatter, [1] accumulate, [2 + i] merge + reduce of workspace i
-    static constexpr int N_STREAMS = 4 + MSM_PIPE;   // the last two: sort stream and accumulate stream of the odd workspaces
+    // streams: [0] recode / count / plan / scatter and [1] accumulate of the even workspaces, [2] and [3] the same of the
+    // odd ones, [4 + i] merge + reduce of workspace i
+    static constexpr int N_STREAMS = 4 + MSM_PIPE;
     hipEvent_t ev_in = nullptr, ev_out[N_STREAMS] = {};
     hipStream_t batch_streams[N_STREAMS] = {};
+    hipStream_t opener_streams[4] = {};
 };
 // Per-context MSM state.  The map is shared by all contexts of the process (one per device), so lookups are
 // serialised; a context itself is not re-entrant, so the state found is then used without the lock.  std::map never
@@ -1226,9 +1228,25 @@ static int msm_pipeline(zkhip_ctx* ctx, MsmState& stt, const MsmTables& tb, cons
         static const bool with_priority = getenv("ZKHIP_MSM_STREAM_PRIORITY") != nullptr;
         int least = 0, greatest = 0;
         ZK_HIP(ctx, hipDeviceGetStreamPriorityRange(&least, &greatest));
-        for (int i = 0; i < MsmState::N_STREAMS; i++) {
+        // The runtime places each new stream on one of its few hardware queues (four unless GPU_MAX_HW_QUEUES says
+        // otherwise): the first streams of a process open the queues one by one, each later one goes to the queue with
+        // the fewest streams, which hands the queues out in turn d, c, b, a, d, ...  Which streams share a queue decides
+        // the batch rate: with both sort streams beside an accumulate stream on one queue, as creation in index order
+        // gave in a process that had made one stream more beforehand, an MSM of a batch takes 0.79 ms instead of 0.72.
+        // So four streams that stay idle are created first, which opens every queue whatever the process did before,
+        // and then the others in the order that gives the best layout found:
+        //   d: accumulate (even), tails 0, 4, 8     c: sort (even), tails 1, 5, 9
+        //   b: tails 2, 6, accumulate (odd)         a: tails 3, 7, sort (odd)
+        // ZKHIP_MSM_STREAM_ORDER=0 creates them in index order (measurements).
+        static_assert(MSM_PIPE == 10, "the creation order below is written out for ten tail streams");
+        static const int best_order[MsmState::N_STREAMS] = {1, 0, 4 + 2, 4 + 3, 4 + 0, 4 + 1, 4 + 6, 4 + 7, 4 + 4, 4 + 5, 3, 2, 4 + 8, 4 + 9};
+        static const bool in_index_order = env_u32("ZKHIP_MSM_STREAM_ORDER", 1) == 0;
+        if (!in_index_order)
+            for (int k = 0; k < 4; k++) ZK_HIP(ctx, hipStreamCreateWithFlags(&stt.opener_streams[k], hipStreamNonBlocking));
+        for (int k = 0; k < MsmState::N_STREAMS; k++) {
+            const int i = in_index_order ? k : best_order[k];
             if (with_priority)
-                ZK_HIP(ctx, hipStreamCreateWithPriority(&stt.batch_streams[i], hipStreamNonBlocking, i == 1 ? least : greatest));
+                ZK_HIP(ctx, hipStreamCreateWithPriority(&stt.batch_streams[i], hipStreamNonBlocking, (i == 1 || i == 3) ? least : greatest));
             else
                 ZK_HIP(ctx, hipStreamCreateWithFlags(&stt.batch_streams[i], hipStreamNonBlocking));
         }
@@ -1244,13 +1262,13 @@ static int msm_pipeline(zkhip_ctx* ctx, MsmState& stt, const MsmTables& tb, cons
         // columns 0.18 -> 0.148; byte columns, whose heavy buckets keep the tails busy, 0.232 -> 0.246).
         // ZKHIP_MSM_TWO_SORT=0 puts every sort on one stream (measurements).
         static const bool two_sort = env_u32("ZKHIP_MSM_TWO_SORT", 1) != 0;
-        stt.ws[i].stream = (two_sort && (i & 1)) ? stt.batch_streams[MsmState::N_STREAMS - 1] : stt.batch_streams[0];
+        stt.ws[i].stream = stt.batch_streams[(two_sort && (i & 1)) ? 2 : 0];
         // ... and two accumulate streams: the accumulate kernel of MSM j + 1 starts while that of MSM j drains (byte
         // columns 0.26 -> 0.198 ms per MSM, dense cache-resident columns 0.774 -> 0.733, dense columns from HBM unchanged).
         // ZKHIP_MSM_TWO_ACC=0: one accumulate stream (measurements).
         static const bool two_acc = env_u32("ZKHIP_MSM_TWO_ACC", 1) != 0;
-        stt.ws[i].acc_stream = (two_acc && (i & 1)) ? stt.batch_streams[MsmState::N_STREAMS - 2] : stt.batch_streams[1];
-        stt.ws[i].tail_stream = stt.batch_streams[2 + i];
+        stt.ws[i].acc_stream = stt.batch_streams[(two_acc && (i & 1)) ? 3 : 1];
+        stt.ws[i].tail_stream = stt.batch_streams[4 + i];
         pipe[i] = &stt.ws[i];
     }
     ZK_HIP(ctx, hipEventRecord(stt.ev_in, ctx->stream));
@@ -1339,6 +1357,7 @@ void msm_drop_ctx(zkhip_ctx* ctx) {
     }
     for (int i = 0; i < MsmState::N_STREAMS; i++) {
         if (st.batch_streams[i]) (void)hipStreamDestroy(st.batch_streams[i]);
+        if (i < 4 && st.opener_streams[i]) (void)hipStreamDestroy(st.opener_streams[i]);
         if (st.ev_out[i]) (void)hipEventDestroy(st.ev_out[i]);
     }
     if (st.ev_in) (void)hipEventDestroy(st.ev_in);
