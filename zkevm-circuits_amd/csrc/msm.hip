@@ -1174,7 +1174,7 @@ struct MsmState {
     static constexpr int N_STREAMS = 4 + MSM_PIPE;
     hipEvent_t ev_in = nullptr, ev_out[N_STREAMS] = {};
     hipStream_t batch_streams[N_STREAMS] = {};
-    hipStream_t opener_streams[4] = {};
+    std::vector<hipStream_t> idle_streams;   // never used: they take turns of the runtime's queue assignment
 };
 // Per-context MSM state.  The map is shared by all contexts of the process (one per device), so lookups are
 // serialised; a context itself is not re-entrant, so the state found is then used without the lock.  std::map never
@@ -1234,21 +1234,37 @@ static int msm_pipeline(zkhip_ctx* ctx, MsmState& stt, const MsmTables& tb, cons
         // the batch rate: with both sort streams beside an accumulate stream on one queue, as creation in index order
         // gave in a process that had made one stream more beforehand, an MSM of a batch takes 0.79 ms instead of 0.72.
         // So four streams that stay idle are created first, which opens every queue whatever the process did before,
-        // and then the others in the order that gives the best layout found:
+        // and then the others queue by queue, with more idle streams where a queue's turn comes and no stream is left
+        // for it.  The layout, one letter per stream in index order (ZKHIP_MSM_LAYOUT overrides it, measurements):
         //   d: accumulate (even), tails 0, 4, 8     c: sort (even), tails 1, 5, 9
-        //   b: tails 2, 6, accumulate (odd)         a: tails 3, 7, sort (odd)
-        // ZKHIP_MSM_STREAM_ORDER=0 creates them in index order (measurements).
-        static_assert(MSM_PIPE == 10, "the creation order below is written out for ten tail streams");
-        static const int best_order[MsmState::N_STREAMS] = {1, 0, 4 + 2, 4 + 3, 4 + 0, 4 + 1, 4 + 6, 4 + 7, 4 + 4, 4 + 5, 3, 2, 4 + 8, 4 + 9};
-        static const bool in_index_order = env_u32("ZKHIP_MSM_STREAM_ORDER", 1) == 0;
-        if (!in_index_order)
-            for (int k = 0; k < 4; k++) ZK_HIP(ctx, hipStreamCreateWithFlags(&stt.opener_streams[k], hipStreamNonBlocking));
-        for (int k = 0; k < MsmState::N_STREAMS; k++) {
-            const int i = in_index_order ? k : best_order[k];
-            if (with_priority)
-                ZK_HIP(ctx, hipStreamCreateWithPriority(&stt.batch_streams[i], hipStreamNonBlocking, (i == 1 || i == 3) ? least : greatest));
-            else
-                ZK_HIP(ctx, hipStreamCreateWithFlags(&stt.batch_streams[i], hipStreamNonBlocking));
+        //   b: accumulate (odd), tails 2, 6         a: sort (odd), tails 3, 7
+        const char* layout = getenv("ZKHIP_MSM_LAYOUT");
+        if (!layout || strlen(layout) != (size_t)MsmState::N_STREAMS || strspn(layout, "abcd") != (size_t)MsmState::N_STREAMS)
+            layout = "cdabdcbadcbadc";
+        static_assert(sizeof("cdabdcbadcbadc") - 1 == MsmState::N_STREAMS, "one letter per stream");
+        // (all tails on the queues of the accumulate streams: the same within 1 %; all on those of the sort streams:
+        // dense columns 2 % slower, byte columns 20 to 30 %)
+        auto create = [&](hipStream_t* st, int i) {
+            if (with_priority) return hipStreamCreateWithPriority(st, hipStreamNonBlocking, (i == 1 || i == 3) ? least : greatest);
+            return hipStreamCreateWithFlags(st, hipStreamNonBlocking);
+        };
+        for (int k = 0; k < 4; k++) {
+            hipStream_t idle;
+            ZK_HIP(ctx, create(&idle, -1));
+            stt.idle_streams.push_back(idle);
+        }
+        for (int placed = 0, turn = 0; placed < MsmState::N_STREAMS; turn++) {
+            const char queue = "dcba"[turn % 4];
+            int i = 0;
+            while (i < MsmState::N_STREAMS && (stt.batch_streams[i] || layout[i] != queue)) i++;
+            if (i < MsmState::N_STREAMS) {
+                ZK_HIP(ctx, create(&stt.batch_streams[i], i));
+                placed++;
+            } else {
+                hipStream_t idle;
+                ZK_HIP(ctx, create(&idle, -1));
+                stt.idle_streams.push_back(idle);
+            }
         }
     }
     size_t n_max = 1;
@@ -1355,9 +1371,9 @@ void msm_drop_ctx(zkhip_ctx* ctx) {
         if (w.ev_acc) (void)hipEventDestroy(w.ev_acc);
         if (w.ev_done) (void)hipEventDestroy(w.ev_done);
     }
+    for (hipStream_t idle : st.idle_streams) (void)hipStreamDestroy(idle);
     for (int i = 0; i < MsmState::N_STREAMS; i++) {
         if (st.batch_streams[i]) (void)hipStreamDestroy(st.batch_streams[i]);
-        if (i < 4 && st.opener_streams[i]) (void)hipStreamDestroy(st.opener_streams[i]);
         if (st.ev_out[i]) (void)hipEventDestroy(st.ev_out[i]);
     }
     if (st.ev_in) (void)hipEventDestroy(st.ev_in);
