@@ -57,6 +57,13 @@ ZK_DEV fe omega_pow(const NttPassArgs& a, uint32_t e) {
 
 ZK_DEV uint32_t bitrev(uint32_t v, uint32_t bits) { return bits ? (__brev(v) >> (32 - bits)) : 0; }
 
+// The butterfly products as single dependent multiply-add chains per column (see Wide::chain): the tile kernel runs
+// enough waves per SIMD to cover the wait states; 2^19 -> 2^21 0.289 -> 0.280 ms, 64 columns 0.2325 -> 0.2295 ms each.
+#ifndef ZKHIP_NTT_CHAIN_MUL
+#define ZKHIP_NTT_CHAIN_MUL 1
+#endif
+using NttW = Wide<FrParams, ZKHIP_NTT_CHAIN_MUL != 0>;
+
 __global__ void __launch_bounds__(NTT_THREADS) ntt_pass_kernel(const NttPassArgs a) {
     extern __shared__ __align__(16) unsigned char smem_raw[];
     fe* x = reinterpret_cast<fe*>(smem_raw);                 // [R][J]
@@ -253,10 +260,10 @@ __device__ __forceinline__ void tile_stages(fw e[TK_E], const uint32_t pos[TK_E]
             if (FIRST) {
                 const uint32_t km = (uint32_t)m & ((1u << i) - 1);   // compile-time
                 if (km == 0) t = (i == 0) ? e[mb] : FrW::norm(e[mb]);
-                else t = FrW::mul(e[mb], tw_get(tw, half_r, km << (r - 1 - s)));
+                else t = NttW::mul(e[mb], tw_get(tw, half_r, km << (r - 1 - s)));
             } else {
                 const uint32_t k = (pos[m] & ((1u << s) - 1)) << (r - 1 - s);
-                t = FrW::mul(e[mb], tw_get(tw, half_r, k));
+                t = NttW::mul(e[mb], tw_get(tw, half_r, k));
             }
             e[mb] = FrW::sub(e[m], t);
             e[m] = FrW::add(e[m], t);
@@ -298,7 +305,7 @@ __global__ void __launch_bounds__(TK_THREADS) ntt_tile_kernel(const NttTileArgs 
                 e[m] = FrW::from_fe(load_fe(in + gi));
                 if (a.pre_mode == 1) {
                     const uint32_t q = gi % 3;
-                    if (q) e[m] = FrW::mul(e[m], FrW::from_fe(a.pre[q]));
+                    if (q) e[m] = NttW::mul(e[m], FrW::from_fe(a.pre[q]));
                 }
             } else {
                 e[m] = FrW::zero();
@@ -347,8 +354,8 @@ __global__ void __launch_bounds__(TK_THREADS) ntt_tile_kernel(const NttTileArgs 
             const uint32_t oi = place(idx, q, cc);
             if (oi >= a.n_out) continue;
             fw v = FrW::norm(lds_get(x, tile_at(q, cc, a.logJ)));
-            if (a.post_mode == 1) v = FrW::mul(v, FrW::from_fe(a.post[0]));
-            else if (a.post_mode == 2) v = FrW::mul(v, FrW::from_fe(a.post[oi % 3]));
+            if (a.post_mode == 1) v = NttW::mul(v, FrW::from_fe(a.post[0]));
+            else if (a.post_mode == 2) v = NttW::mul(v, FrW::from_fe(a.post[oi % 3]));
             store_fe(out + oi, FrW::to_fe(v));
         }
         return;
@@ -384,8 +391,8 @@ __global__ void __launch_bounds__(TK_THREADS) ntt_tile_kernel(const NttTileArgs 
             two = twiddle_reads(oi, ra, rb);
         }
         fw v = FrW::norm(lds_get(x, tile_at(cur_q, cur_cc, a.logJ)));
-        v = FrW::mul(v, FrW::from_fe(ca));
-        if (cur_two) v = FrW::mul(v, FrW::from_fe(cb));
+        v = NttW::mul(v, FrW::from_fe(ca));
+        if (cur_two) v = NttW::mul(v, FrW::from_fe(cb));
         // v in (-p/100, 1.01 p): v + p is a non-negative residue below 2^256
         store_fe(out + cur_oi, FrW::pack_nonneg(FrW::norm(FrW::add(v, pp))));
     }
