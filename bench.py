@@ -14,6 +14,7 @@ import argparse
 import json
 import os
 import sys
+import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -40,6 +41,8 @@ ALG_MADS_PER_MADD = 10 * 136
 VALU_MAD_PEAK = 256 * 4 * 16 * 2.4e9           # nominal: a quarter-rate 32x32+64 multiply-add, 16 lanes per SIMD per clock,
                                                # 256 CUs x 4 SIMDs x 2.4 GHz = 39.3 T/s
 HBM_PEAK = 8000.0                              # GB/s
+EXTRAS_LIMIT_SECONDS = 420                      # multi-rank runs: the extras are abandoned after this long (see main)
+PREHEAT_SECONDS = 0.1                          # untimed steps before the warm-up: clocks ramp for about 30 ms under load
 PROFILES = os.path.join(ROOT, "profiles")
 
 
@@ -230,9 +233,18 @@ def main():
         dom.coeff_to_extended_dev(coeff.data_ptr(), ext.data_ptr())
         return jac
 
+    # the chip needs about 30 ms of sustained load to reach its steady clocks (the accumulate kernel of the first MSM after
+    # an idle period takes 615 us, from the thirtieth on 555 us): the same step, untimed, before the warm-up steps
+    preheat_steps = 0
+    t_pre = time.perf_counter()
+    while time.perf_counter() - t_pre < PREHEAT_SECONDS:
+        step()
+        preheat_steps += 1
     for _ in range(args.warmup):
         step()
-    ctx.timing_enable(True)
+    # HIP events around the two kernels the rooflines are quoted for only: bracketing all four stages of the MSM costs the
+    # step about 30 us of idle queue; the stage figures come from a separate pass below
+    ctx.timing_enable(2)
     ctx.timing_reset()
     if world > 1:
         dist.barrier()
@@ -253,19 +265,50 @@ def main():
     msm_ms = sum(ev[2 * s].elapsed_time(ev[2 * s + 1]) for s in range(args.steps)) / args.steps
     ntt_ms = sum(ev[2 * s + 1].elapsed_time(ev[2 * s + 2]) for s in range(args.steps)) / args.steps
     acc_us, acc_launches = ctx.timing_get("msm_accumulate")
+    ntt_us, _ = ctx.timing_get("ntt")
+    # the stages of the MSM: the same MSM again, outside the timed steps, with every stage bracketed
+    ctx.timing_enable(True)
+    ctx.timing_reset()
+    for _ in range(args.steps):
+        ctx.msm_range_dev(bid, 0, scalars.data_ptr(), n)
+    torch.cuda.synchronize()
     sort_us, _ = ctx.timing_get("msm_sort")
     merge_us, _ = ctx.timing_get("msm_merge")
     reduce_us, _ = ctx.timing_get("msm_reduce")
-    ntt_us, _ = ctx.timing_get("ntt")
+    fold_us, _ = ctx.timing_get("msm_host_fold")
+    acc_bracketed_us, _ = ctx.timing_get("msm_accumulate")
     ctx.timing_enable(False)
+    extra_phases = {"sort": sort_us, "accumulate": acc_bracketed_us, "merge": merge_us, "reduce": reduce_us, "host_fold": fold_us,
+                    "what": "separate pass after the timed steps with every stage bracketed by HIP events (about 30 us more per MSM)"}
 
     if world > 1:
         t = torch.tensor([elapsed, msm_ms, ntt_ms], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed, msm_ms, ntt_ms = (float(x) for x in t.cpu())
 
+    # With several ranks some extras below are collective (split evaluate_h, sharded proof, split MSM): a rank that fails or
+    # hangs inside one would leave the others waiting until the collective library aborts the job, and the measured line
+    # would be lost with it.  Every rank therefore arms a timer: when it fires, rank 0 prints the line of the timed steps
+    # (complete at this point) without the extras and every rank leaves.
+    watchdog = None
+    if world > 1:
+        def abandon_extras():
+            try:
+                if rank == 0:
+                    finish(args, ctx, dist, world, rank, device_index, bid, scalars, n, en, elapsed, msm_ms, ntt_ms, acc_us,
+                           acc_launches, ntt_us, {"extras": f"abandoned after {EXTRAS_LIMIT_SECONDS} s: a rank failed or hung in a "
+                                                  "multi-rank extra measurement; the timed steps are complete"}, None, minimal=True)
+                    sys.stdout.flush()
+            finally:
+                os._exit(0)
+        watchdog = threading.Timer(EXTRAS_LIMIT_SECONDS, abandon_extras)
+        watchdog.daemon = True
+        watchdog.start()
+
     # ---- extra measurements outside the timed steps (rank-local) ---------------------------------------
-    extra = {}
+    extra = {"preheat": {"steps": preheat_steps, "seconds": PREHEAT_SECONDS,
+                         "what": "untimed steps before the warm-up steps, until the chip holds its steady clocks"},
+             "msm_phases_us": extra_phases}
     if not args.skip_extras:
         measure_extras(ctx, dom, bid, stream, gen, n, en, extra)
     evalh = None
@@ -285,8 +328,8 @@ def main():
             extra["create_proof_k19"] = {"error": f"{type(exc).__name__}: {exc}"}
     if replay is not None:
         extra["replay_supercircuit_shape"] = replay
-    finish(args, ctx, dist, world, rank, device_index, bid, scalars, n, en, elapsed, msm_ms, ntt_ms, acc_us, acc_launches, sort_us,
-           merge_us, reduce_us, ntt_us, extra, evalh)
+    finish(args, ctx, dist, world, rank, device_index, bid, scalars, n, en, elapsed, msm_ms, ntt_ms, acc_us, acc_launches, ntt_us,
+           extra, evalh, watchdog=watchdog)
 
 
 def measure_create_proof(ctx, bid, dist_=None):
@@ -509,10 +552,11 @@ def measure_evalh_split(ctx, dom, stream, gen, world, rank):
             "seconds_including_all_gather": float(t.cpu()[0]), "rows_gathered": int(sum(p.shape[0] for _, _, p in pieces))}
 
 
-def finish(args, ctx, dist, world, rank, local_rank, bid, scalars, n, en, elapsed, msm_ms, ntt_ms, acc_us, acc_launches, sort_us,
-           merge_us, reduce_us, ntt_us, extra, evalh):
+def finish(args, ctx, dist, world, rank, local_rank, bid, scalars, n, en, elapsed, msm_ms, ntt_ms, acc_us, acc_launches, ntt_us,
+           extra, evalh, watchdog=None, minimal=False):
+    """Builds and prints the line.  minimal: called by the watchdog of a multi-rank run, no collective and no GPU call."""
     split_ok = None
-    if world > 1:
+    if world > 1 and not minimal:
         # one MSM split by base range over the ranks: every rank takes rank 0's scalars, commits its own range, the partial
         # sums are all-gathered and folded; the fold must be the point a single GPU computes over the whole range
         try:
@@ -568,7 +612,6 @@ def finish(args, ctx, dist, world, rank, local_rank, bid, scalars, n, en, elapse
                                      "replay_supercircuit_shape_s": replay.get("total_s"),
                                      "what": "stand-in circuits, see create_proof_k19 / replay_supercircuit_shape below"},
             "msm_ms": msm_ms, "msm_Mpts_per_s_per_gpu": n / (msm_ms * 1e-3) / 1e6,
-            "msm_phases_us": {"sort": sort_us, "accumulate": acc_us, "merge": merge_us, "reduce": reduce_us},
             "coset_ntt_ms": ntt_ms, "coset_ntt_GBps": world * ntt_bytes / (ntt_ms * 1e-3) / 1e9,
             "coset_ntt_frac_of_hbm_peak": ntt_bytes / (ntt_ms * 1e-3) / 1e9 / HBM_PEAK,
             "roofline": {"bound": "valu", "bound_note": "32x32+64 integer multiply-add issue rate of the vector ALUs: the kernel is no dense contraction (no MFMA) and moves 0.75 GB per launch (not HBM-bound)", "kernel": "accumulate_kernel",
@@ -598,7 +641,13 @@ def finish(args, ctx, dist, world, rank, local_rank, bid, scalars, n, en, elapse
             "evaluate_h": evalh, "cpu_baseline": cpu, "msm_base_split_ok": split_ok,
         }
         line.update(extra)
+        if watchdog is not None:
+            watchdog.cancel()
         print(json.dumps(line))
+    if minimal:
+        return
+    if watchdog is not None:
+        watchdog.cancel()
     ctx.release_bases(bid)
     if world > 1:
         dist.barrier()

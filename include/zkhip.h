@@ -331,7 +331,9 @@ int zkhip_cosets_to_extended_dev(zkhip_domain* dom, const uint64_t* d_compact, c
 /* Kernel timing hook: average duration in microseconds of the launches of the named kernel family issued on
  * this context since the last zkhip_timing_reset (measured with HIP events on the launch stream).
  * families: "ntt", "msm_sort", "msm_accumulate", "msm_merge", "msm_reduce", "evalh", "batch_invert",
- * "prefix_product", "grand_product", "eval_polynomial", "poly_lincomb", "kate_division", "lookup_permute".  A family brackets every launch of its stage in one call (e.g. the passes of one NTT). */
+ * "prefix_product", "grand_product", "eval_polynomial", "poly_lincomb", "kate_division", "lookup_permute".  A family brackets every launch of its stage in one call (e.g. the passes of one NTT).
+ * on = 1 times every family; on = 2 only "msm_accumulate" and "ntt" (each bracket puts two event packets on the
+ * stream, about 30 us per MSM when all four of its stages are bracketed); on = 0 none. */
 int zkhip_timing_enable(zkhip_ctx* ctx, int on);
 int zkhip_timing_reset(zkhip_ctx* ctx);
 int zkhip_timing_get(zkhip_ctx* ctx, const char* family, double* avg_us, uint64_t* launches);

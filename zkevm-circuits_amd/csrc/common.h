@@ -33,7 +33,7 @@ struct zkhip_ctx {
     // scratch arena reused across calls (grown on demand, never shrunk)
     void* scratch = nullptr;
     size_t scratch_bytes = 0;
-    bool timing = false;
+    int timing = 0;   // 0 off, 1 every family, 2 only the dominant kernels ("msm_accumulate", "ntt")
     std::map<std::string, zkhip::TimingSlot> timers;
     int num_cus = 256;
     std::vector<zkhip::NttPlan*> plans;   // cached per (log_n, omega)

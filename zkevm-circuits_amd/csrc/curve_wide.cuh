@@ -130,6 +130,57 @@ __device__ __forceinline__ g1_xyzz_w xyzz_w_add(const g1_xyzz_w& a, const g1_xyz
     return o;
 }
 
+// ---- a + b by TWO neighbouring lanes ---------------------------------------------------------------
+// For kernels that are one dependency chain of point additions per wave (the MSM's reduce): lanes 2i and 2i + 1 hold
+// the same a and b, each computes half of the field products, and both end with the same sum.  Lane role 0 takes the
+// x side (u1, u2, zz_a zz_b, p^2, u1 p^2, zz3, r (q - x3)), role 1 the y side (s1, s2, zzz_a zzz_b, r^2, p^3, zzz3,
+// s1 p^3): six products and a square per lane instead of twelve and two, with five exchanges of one value between the
+// two lanes (data-parallel-primitive moves inside a quad, no LDS).  Both lanes of a pair must be active together.
+__device__ __forceinline__ fw fw_pair_other(const fw& v) {
+    fw o;
+#pragma unroll
+    for (int i = 0; i < 9; i++) o.d[i] = __builtin_amdgcn_update_dpp(0, v.d[i], 0xB1, 0xf, 0xf, false);   // quad_perm:[1,0,3,2]
+    return o;
+}
+__device__ __forceinline__ fw fw_sel(bool c, const fw& t, const fw& f) {
+    fw o;
+#pragma unroll
+    for (int i = 0; i < 9; i++) o.d[i] = c ? t.d[i] : f.d[i];
+    return o;
+}
+__device__ __forceinline__ g1_xyzz_w xyzz_w_add_pair(const g1_xyzz_w& a, const g1_xyzz_w& b, bool role) {
+    if (a.inf) return b;
+    if (b.inf) return a;
+    const fw xy1 = fw_sel(role, a.y, a.x), xy2 = fw_sel(role, b.y, b.x);
+    const fw z1 = fw_sel(role, a.zzz, a.zz), z2 = fw_sel(role, b.zzz, b.zz);
+    const fw t1 = FqW::mul(xy1, z2);            // u1 | s1
+    const fw t2 = FqW::mul(xy2, z1);            // u2 | s2
+    const fw t3 = FqW::mul(z1, z2);             // zz_a zz_b | zzz_a zzz_b
+    const fw d = FqW::sub(t2, t1);              // p | r
+    // p == 0 (equal or opposite points) is decided by the x lane for the pair; the pair then takes the one-lane
+    // addition with its exact tests, both lanes alike
+    const int mz = FqW::maybe_zero(d) ? 1 : 0;
+    const int mz_o = __builtin_amdgcn_update_dpp(0, mz, 0xB1, 0xf, 0xf, false);   // read with both lanes active
+    const int mz_x = role ? mz_o : mz;
+    if (__builtin_expect(mz_x != 0, 0)) return xyzz_w_add(a, b);
+    const fw sq = FqW::sqr(d);                  // p^2 | r^2
+    const fw sq_o = fw_pair_other(sq), d_o = fw_pair_other(d);
+    const fw pp = fw_sel(role, sq_o, sq), rr = fw_sel(role, sq, sq_o);
+    const fw m1 = FqW::mul(fw_sel(role, d_o, t1), pp);        // q = u1 p^2 | p^3
+    const fw m2 = FqW::mul(t3, fw_sel(role, m1, pp));         // zz3 | zzz3
+    const fw m1_o = fw_pair_other(m1);
+    const fw qq = fw_sel(role, m1_o, m1), ppp = fw_sel(role, m1, m1_o);
+    g1_xyzz_w o;
+    o.x = FqW::norm(FqW::sub(FqW::sub(rr, ppp), FqW::dbl(qq)));
+    const fw m3 = FqW::mul(fw_sel(role, t1, d_o), fw_sel(role, ppp, FqW::sub(qq, o.x)));   // r (q - x3) | s1 p^3
+    const fw m3_o = fw_pair_other(m3), m2_o = fw_pair_other(m2);
+    o.y = FqW::norm(role ? FqW::sub(m3_o, m3) : FqW::sub(m3, m3_o));
+    o.zz = fw_sel(role, m2_o, m2);
+    o.zzz = fw_sel(role, m2, m2_o);
+    o.inf = false;
+    return o;
+}
+
 __device__ __forceinline__ g1_xyzz_w xyzz_w_identity() {
     g1_xyzz_w o;
     o.x = o.y = o.zz = o.zzz = FqW::zero();

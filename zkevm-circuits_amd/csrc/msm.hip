@@ -682,59 +682,91 @@ __global__ void __launch_bounds__(256) merge_final_kernel(const g1_xyzz* in, con
 //   round r: every lane whose bit r is clear adds the value of lane l | 2^r.
 // The lanes with low r bits clear carry the running totals of their 2^r-blocks; the upper half of each pair keeps its
 // total U, which from then on is only summed over the higher bits (it sits in the lanes with lowest set bit r).
-// A lone wave needs ~8 us per dependent point addition, so the chain length is what this phase costs: 6 additions in
-// level 1 and 9 in level 2, against 12 + 12 for a suffix-scan formulation.
-template <int NB>
-__device__ __forceinline__ g1_xyzz_w lanes_bit_sums(g1_xyzz_w p, uint32_t lane) {
-#pragma unroll 1
-    for (int r = 0; r < NB; r++) {
-        g1_xyzz_w o = xyzz_w_shfl(p, (int)(lane | (1u << r)));
-        // a lane whose bit r is set would read itself: give it the identity, or the whole wave walks through the
-        // doubling branch of the addition for nothing
-        if ((lane >> r) & 1u) o.inf = true;
-        p = xyzz_w_add(p, o);
-    }
-    return p;
-}
+// A lone wave needs ~9 us per dependent point addition (~6 us when two lanes share it, below), so the chain length is
+// what this phase costs: 6 additions in level 1 and 7 in level 2, against 12 + 12 for a suffix-scan formulation.
 constexpr uint32_t RED_STREAMS = 7;    // the total and six bit sums of every wave of level 1
-constexpr size_t REDUCE_OUT = 30;      // two halves of 15 points each, see reduce_level2_kernel
 
-// level 1: sums[b] for b < B (B a multiple of 64) -> l1[0][h] = A_h, l1[1 + j][h] = B_{h,j} for wave h = b / 64
-// (J = number of waves = row stride of l1)
+// Both levels run with TWO lanes per point (xyzz_w_add_pair): physical lanes 2 i and 2 i + 1 of a wave are logical lane i
+// and hold the same point, an addition costs each lane half of the field products, and the dependency chain that this
+// phase consists of shortens by a third (level 1 + level 2: 127 -> 88 us at 2^15 buckets).  A wave holds 32 points: the
+// rounds over the low five bits of the logical lane index run inside the wave, the later ones go through LDS.
+// one round: logical lanes whose bit `bit` is clear add the value of logical lane ll | 2^bit
+__device__ __forceinline__ g1_xyzz_w pairs_round_operand(const g1_xyzz_w& p, uint32_t ll, uint32_t bit, bool role) {
+    g1_xyzz_w o = xyzz_w_shfl(p, (int)(((ll | (1u << bit)) << 1) | (role ? 1u : 0u)));
+    if ((ll >> bit) & 1u) o.inf = true;
+    return o;
+}
+constexpr size_t REDUCE_OUT = 56;      // four quarters of 14 points each, see reduce_level2_kernel
+
+// level 1: sums[b] for b < B (B a multiple of 128) -> l1[0][h] = A_h, l1[1 + j][h] = B_{h,j} for the 64-bucket group
+// h = b / 64 (J = number of groups = row stride of l1).  A workgroup of four waves takes 128 buckets; waves 2 g and
+// 2 g + 1 are the lower and upper 32 logical lanes of the 64-bucket group g, and the round over bit 5 takes the upper
+// wave's sums from LDS
 __global__ void __launch_bounds__(256) reduce_level1_kernel(const g1_xyzz* sums, uint32_t B, uint32_t J, g1_xyzz* l1) {
-    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x, lane = threadIdx.x & 63;
+    __shared__ g1_xyzz_w ex[2][32];
+    const uint32_t w = threadIdx.x >> 6, lane = threadIdx.x & 63, ll = lane >> 1, g = w >> 1, upper = w & 1;
+    const bool role = (lane & 1u) != 0;
+    const uint32_t b = blockIdx.x * 128 + g * 64 + upper * 32 + ll;
     g1_xyzz_w p = b < B ? xyzz_w_load(sums + b) : xyzz_w_identity();
-    p = lanes_bit_sums<6>(p, lane);
-    if (b < B && (lane & (lane - 1)) == 0) {   // lanes 0, 1, 2, 4, 8, 16, 32
-        const uint32_t stream = lane ? 1u + (uint32_t)__builtin_ctz(lane) : 0u;
-        xyzz_w_store(l1 + (size_t)stream * J + (b >> 6), p);
+    // ONE copy of the addition's code for all six rounds (a second copy after the loop is another 17 KB of instructions
+    // that every wave of the chip fetches once, cold)
+#pragma unroll 1
+    for (uint32_t r = 0; r < 6; r++) {
+        g1_xyzz_w o;
+        if (r < 5) {
+            o = pairs_round_operand(p, ll, r, role);
+        } else {
+            if (upper && !role) ex[g][ll] = p;
+            __syncthreads();
+            o = ex[g][ll];
+            if (upper) o.inf = true;
+        }
+        p = xyzz_w_add_pair(p, o, role);
+    }
+    if (b < B && !role && (ll & (ll - 1)) == 0) {
+        // lower wave: logical lanes 0, 1, 2, 4, 8, 16 = total and bit sums 0..4; upper wave: logical lane 0 = bit sum 5
+        const uint32_t stream = upper ? 6u : (ll ? 1u + (uint32_t)__builtin_ctz(ll) : 0u);
+        if (!upper || ll == 0) xyzz_w_store(l1 + (size_t)stream * J + (b >> 6), p);
     }
 }
-// level 2: workgroup (stream, half) folds l1[stream][256 half .. 256 half + 256), J <= 512, with four waves -- one per SIMD
-// of its CU: two waves on one SIMD would halve each other's issue rate, and this phase is nothing but one dependency
-// chain.  Wave w takes the waves h = 256 half + 64 w + lane of level 1; then one wave folds the four results.  Stream 0
-// (the totals A_h) keeps its bit sums: over the lane bits they are D_0..D_5, over the wave index D_6, D_7, with
-// D_i = sum of the A_h with bit i of h set; D_8 is the total of the upper half, which the host reads off.
-// out[15 half + ..]: [0] total, [1 + i] D_i (i < 8, this half's part), [9 + j] this half's sum of B_j (j < 6)
+// level 2: workgroup (stream, quarter) folds l1[stream][128 quarter .. 128 quarter + 128), J <= 512, with four waves of 32
+// logical lanes (one wave per SIMD of its CU); then wave 0 folds the four results of the six groups (total and bit sums
+// 0..4 of the waves).  Over the bits of h = 128 quarter + 32 w + ll the totals' bit sums are D_0..D_4 (ll), D_5, D_6 (w);
+// D_7 and D_8 are sums of quarter totals, which the host forms.
+// out[14 quarter + ..]: [0] total, [1 + i] D_i (i < 7, this quarter's part), [8 + j] this quarter's sum of B_j (j < 6)
 __global__ void __launch_bounds__(256) reduce_level2_kernel(const g1_xyzz* l1, uint32_t J, g1_xyzz* out) {
-    __shared__ g1_xyzz_w ex[4][RED_STREAMS];
-    const uint32_t stream = blockIdx.x >> 1, half = blockIdx.x & 1, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const uint32_t h = half * 256 + w * 64 + lane;
+    __shared__ g1_xyzz_w ex[4][6];
+    const uint32_t stream = blockIdx.x >> 2, quarter = blockIdx.x & 3, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const uint32_t ll = lane >> 1;
+    const bool role = (lane & 1u) != 0;
+    const uint32_t h = quarter * 128 + w * 32 + ll;
     g1_xyzz_w p = h < J ? xyzz_w_load(l1 + (size_t)stream * J + h) : xyzz_w_identity();
-    p = lanes_bit_sums<6>(p, lane);
-    if ((lane & (lane - 1)) == 0) ex[w][lane ? 1 + __builtin_ctz(lane) : 0] = p;
-    __syncthreads();
-    if (w != 0) return;
-    // lane 4 g + u: element u (the wave index of above) of group g; group 0 = totals, group 1 + j = bit sums j
-    const uint32_t g = lane >> 2, u = lane & 3;
-    g1_xyzz_w q = g < RED_STREAMS ? ex[u][g] : xyzz_w_identity();
-    q = lanes_bit_sums<2>(q, lane);
-    g1_xyzz* o = out + 15 * half;
+    // rounds 0..4 over the bits of ll inside every wave; then wave 0 alone takes logical lane 4 g + u = element u (the wave
+    // index of above) of group g (group 0 = totals, group 1 + j = bit sums j) and runs rounds 5, 6 over the bits of u.
+    // One loop, so that the kernel holds one copy of the addition's code.
+    uint32_t g = 0, u = 0;
+#pragma unroll 1
+    for (uint32_t r = 0; r < 7; r++) {
+        if (r == 5) {
+            if (!role && (ll & (ll - 1)) == 0) ex[w][ll ? 1 + __builtin_ctz(ll) : 0] = p;
+            __syncthreads();
+            if (w != 0) return;
+            g = ll >> 2;
+            u = ll & 3;
+            if (g < 6) p = ex[u][g];
+            else p = xyzz_w_identity();
+        }
+        const g1_xyzz_w o = pairs_round_operand(p, ll, r < 5 ? r : r - 5, role);
+        p = xyzz_w_add_pair(p, o, role);
+    }
+    const g1_xyzz_w q = p;
+    if (role) return;
+    g1_xyzz* o = out + 14 * quarter;
     if (stream == 0) {
-        if (g == 0 && u != 3) xyzz_w_store(o + (u ? 6 + u : 0), q);              // total, D_6 (u = 1), D_7 (u = 2)
-        else if (g >= 1 && g < RED_STREAMS && u == 0) xyzz_w_store(o + g, q);     // D_0..D_5
-    } else if (lane == 0) {
-        xyzz_w_store(o + 8 + stream, q);                                         // sum of B_{., stream - 1}
+        if (g == 0 && u != 3) xyzz_w_store(o + (u ? 5 + u : 0), q);        // total, D_5 (u = 1), D_6 (u = 2)
+        else if (g >= 1 && g < 6 && u == 0) xyzz_w_store(o + g, q);         // D_0..D_4
+    } else if (ll == 0) {
+        xyzz_w_store(o + 7 + stream, q);                                    // sum of B_{., stream - 1}
     }
 }
 
@@ -789,7 +821,7 @@ struct MsmWorkspace {
     unsigned char* base = nullptr;
     size_t bytes = 0;
     uint32_t* h_info = nullptr;        // pinned copy of info[0..3]
-    uint64_t* h_sums = nullptr;        // pinned: the 24 leftover sums of the reduce (XYZZ)
+    uint64_t* h_sums = nullptr;        // pinned: the REDUCE_OUT leftover sums of the reduce (XYZZ)
     // per-call state
     size_t n = 0, first = 0;
     const fe* d_scalars = nullptr;
@@ -998,9 +1030,9 @@ static int msm_phase2(zkhip_ctx* ctx, MsmWorkspace& ws, const MsmTables& tb, boo
     }
     {
         TimedRegion tr(ctx, timed ? "msm_reduce" : nullptr, st);
-        const uint32_t blocks1 = (B + 255) / 256, J = B / 64;   // B is a multiple of 128
-        hipLaunchKernelGGL(reduce_level1_kernel, dim3(blocks1), dim3(256), 0, st, ws.sums, B, J, ws.l1);
-        hipLaunchKernelGGL(reduce_level2_kernel, dim3(2 * RED_STREAMS), dim3(256), 0, st, ws.l1, J,
+        const uint32_t J = B / 64;   // B is a multiple of 128
+        hipLaunchKernelGGL(reduce_level1_kernel, dim3(B / 128), dim3(256), 0, st, ws.sums, B, J, ws.l1);
+        hipLaunchKernelGGL(reduce_level2_kernel, dim3(4 * RED_STREAMS), dim3(256), 0, st, ws.l1, J,
                            reinterpret_cast<g1_xyzz*>(ws.h_sums));
         ZK_HIP(ctx, hipGetLastError());
     }
@@ -1085,8 +1117,8 @@ static void hx_add(HXyzz& o, const HXyzz& a, const HXyzz& b) {
 
 // phase 3: waits for the leftover sums of the reduce and joins them on the host:
 //   result = total + sum_{t < 15} 2^t X_t,  X_t = sum over the waves of B_t for t < 6, D_(t - 6) for t >= 6
-// (bucket b = 64 h + l weighs b + 1 = 64 h + l + 1), by Horner: 14 doublings and 15 additions, after the two halves of
-// level 2 have been added up (D_8 = total of the upper half).  The fold stays in XYZZ coordinates (an addition is 14
+// (bucket b = 64 h + l weighs b + 1 = 64 h + l + 1), by Horner: 14 doublings and 15 additions, after the four quarters
+// of level 2 have been added up (D_7, D_8 = sums of quarter totals).  The fold stays in XYZZ coordinates (an addition is 14
 // field products, and nothing is converted until the end); the device's x 2^261 become the host's x 2^256 by one
 // product with 1 / 32 per coordinate.
 static int msm_phase3(zkhip_ctx* ctx, MsmWorkspace& ws, uint64_t out_jacobian[12]) {
@@ -1103,29 +1135,31 @@ static int msm_phase3(zkhip_ctx* ctx, MsmWorkspace& ws, uint64_t out_jacobian[12
         }
     };
     static const Inv32 inv32;
-    HXyzz pt[2][15];
-    for (int hf = 0; hf < 2; hf++)
-        for (int i = 0; i < 15; i++) {
-            const uint64_t* in = ws.h_sums + 16 * (15 * hf + i);
+    constexpr int parts = 4, per = 14;           // level 2 leaves four quarters of 14 points each
+    HXyzz pt[parts][per];
+    for (int hf = 0; hf < parts; hf++)
+        for (int i = 0; i < per; i++) {
+            const uint64_t* in = ws.h_sums + 16 * (per * hf + i);
             HXyzz& q = pt[hf][i];
             h_mul(HFQ, q.x, in, inv32.v);
             h_mul(HFQ, q.y, in + 4, inv32.v);
             h_mul(HFQ, q.zz, in + 8, inv32.v);
             h_mul(HFQ, q.zzz, in + 12, inv32.v);
         }
+    auto over_parts = [&](HXyzz& o, int idx) {
+        o = pt[0][idx];
+        for (int q = 1; q < parts; q++) hx_add(o, o, pt[q][idx]);
+    };
     HXyzz acc, t;
     memset(&acc, 0, sizeof acc);
     for (int k = 14; k >= 0; k--) {
         hx_double(acc, acc);
-        if (k == 14) {
-            t = pt[1][0];                                        // D_8
-        } else {
-            const int idx = k < 6 ? 9 + k : 1 + (k - 6);        // B_k or D_(k - 6)
-            hx_add(t, pt[0][idx], pt[1][idx]);
-        }
+        if (k == 14) hx_add(t, pt[2][0], pt[3][0]);          // D_8: the totals of quarters 2 and 3
+        else if (k == 13) hx_add(t, pt[1][0], pt[3][0]);     // D_7: quarters 1 and 3
+        else over_parts(t, k < 6 ? 8 + k : 1 + (k - 6));     // B_k or D_(k - 6)
         hx_add(acc, acc, t);
     }
-    hx_add(t, pt[0][0], pt[1][0]);
+    over_parts(t, 0);
     hx_add(acc, acc, t);
     // XYZZ -> Jacobian: X' = X ZZ ZZZ^2, Y' = Y ZZ^3 ZZZ^2, Z' = ZZ ZZZ
     if (!h_is_zero(acc.zz)) {
@@ -1139,7 +1173,7 @@ static int msm_phase3(zkhip_ctx* ctx, MsmWorkspace& ws, uint64_t out_jacobian[12
         h_mul(HFQ, out_jacobian + 4, u, zzz2);
         h_mul(HFQ, out_jacobian + 8, acc.zz, acc.zzz);
     }
-    if (ctx->timing) {
+    if (ctx->timing == 1) {
         auto& slot = ctx->timers["msm_host_fold"];
         slot.total_us += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_begin).count();
         slot.launches++;
