@@ -14,5 +14,5 @@ for C in FETCH_SIZE WRITE_SIZE; do
   timeout -s KILL 120 rocprofv3 --pmc $C --output-format csv -d "$OUT/probe_$C" -- ./tools/gather_probe > "$OUT/probe_$C.log" 2>&1
 done
 timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/bench_trace" -- $BENCH > "$OUT/bench_trace.log" 2>&1
-tail -1 "$OUT/bench_trace.log" > "$OUT/bench_line_under_rocprof.json"
+grep "^{" "$OUT/bench_trace.log" > "$OUT/bench_line_under_rocprof.json"
 echo done
