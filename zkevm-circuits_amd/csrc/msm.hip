@@ -568,14 +568,6 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))
 constexpr uint32_t MERGE_WAVE = 64;    // items one wave folds in a pre-level for few, very heavy buckets
 constexpr uint32_t MERGE_LANE = 16;    // items one lane folds in a pre-level for many heavy buckets
 
-__device__ __forceinline__ g1_xyzz_w wave_sum_xyzz(g1_xyzz_w v, uint32_t lane) {
-    for (int d = 32; d >= 1; d >>= 1) {
-        const g1_xyzz_w o = xyzz_w_shfl(v, (int)(lane ^ d));
-        v = xyzz_w_add(v, o);
-    }
-    return v;
-}
-
 // one block: hoff = exclusive scan of f(b) = cnt > direct_max ? ceil(cnt / fold) : 0 (hoff[B] = total), and the
 // bucket view after the level: heavy buckets at out_base + hoff[b] with f(b) items, light buckets unchanged
 __global__ void __launch_bounds__(1024) heavy_scan_kernel(const uint32_t* off_in, const uint32_t* cnt_in, uint32_t B, uint32_t fold,
@@ -620,15 +612,25 @@ __global__ void __launch_bounds__(1024) heavy_scan_kernel(const uint32_t* off_in
     if (threadIdx.x == 0) hoff[B] = total;
 }
 
-// wave t of the launch folds items [lo, lo + 64) of its heavy bucket into items[out_base + t]
+// wave t of the launch folds items [lo, lo + 64) of its heavy bucket into items[out_base + t].  Two lanes per point
+// (xyzz_w_add_pair): logical lane ll = lane / 2 first adds items 2 ll and 2 ll + 1, then five butterfly rounds join the 32
+// logical lanes -- six dependent two-lane additions (~6 us each) where one lane per item took six one-lane additions
+// (~9 us each).  One loop, so that the kernel holds one copy of the addition's code.
 __global__ void __launch_bounds__(256) merge_wave_kernel(g1_xyzz* items, const uint32_t* off_in, const uint32_t* cnt_in,
                                                          const uint32_t* hoff, uint32_t B, uint32_t out_base) {
-    const uint32_t t = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+    const uint32_t t = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63, ll = lane >> 1;
+    const bool role = (lane & 1u) != 0;
     if (t >= hoff[B]) return;
     const uint32_t b = find_bucket(hoff, B, t);
     const uint32_t lo = off_in[b] + (t - hoff[b]) * MERGE_WAVE, end = off_in[b] + cnt_in[b];
-    g1_xyzz_w p = lo + lane < end ? xyzz_w_load(items + lo + lane) : xyzz_w_identity();
-    p = wave_sum_xyzz(p, lane);
+    g1_xyzz_w p = lo + 2 * ll < end ? xyzz_w_load(items + lo + 2 * ll) : xyzz_w_identity();
+    const g1_xyzz_w second = lo + 2 * ll + 1 < end ? xyzz_w_load(items + lo + 2 * ll + 1) : xyzz_w_identity();
+#pragma unroll 1
+    for (uint32_t r = 0; r < 6; r++) {
+        g1_xyzz_w o = second;
+        if (r) o = xyzz_w_shfl(p, (int)(((ll ^ (32u >> r)) << 1) | (role ? 1u : 0u)));
+        p = xyzz_w_add_pair(p, o, role);
+    }
     if (lane == 0) xyzz_w_store(items + out_base + t, p);
 }
 
