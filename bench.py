@@ -235,6 +235,15 @@ def main():
 
     # the chip needs about 30 ms of sustained load to reach its steady clocks (the accumulate kernel of the first MSM after
     # an idle period takes 615 us, from the thirtieth on 555 us): the same step, untimed, before the warm-up steps
+    # (the first steps after set-up are timed too and reported as `cold_start`, so that the line shows both states)
+    cold_n = 5
+    step()
+    torch.cuda.synchronize()
+    t_cold = time.perf_counter()
+    for _ in range(cold_n):
+        step()
+    torch.cuda.synchronize()
+    cold_ms = (time.perf_counter() - t_cold) * 1e3 / cold_n
     preheat_steps = 0
     t_pre = time.perf_counter()
     while time.perf_counter() - t_pre < PREHEAT_SECONDS:
@@ -308,6 +317,9 @@ def main():
     # ---- extra measurements outside the timed steps (rank-local) ---------------------------------------
     extra = {"preheat": {"steps": preheat_steps, "seconds": PREHEAT_SECONDS,
                          "what": "untimed steps before the warm-up steps, until the chip holds its steady clocks"},
+             "cold_start": {"ms_per_step": cold_ms, "steps": cold_n,
+                            "what": "the same step timed right after set-up (one step run before), before the preheat: the chip "
+                                    "has not reached its steady clocks yet"},
              "msm_phases_us": extra_phases}
     if not args.skip_extras:
         measure_extras(ctx, dom, bid, stream, gen, n, en, extra)

@@ -393,114 +393,138 @@ __global__ void __launch_bounds__(COLSUM_THREADS) column_sum_kernel(const uint32
     for (uint32_t i = threadIdx.x; i < PLAN_STRIDE; i += COLSUM_THREADS) plan[(size_t)blockIdx.x * PLAN_STRIDE + i] = sh[i];
 }
 
-// One block of 1024 lanes (B a power of two, B <= 32768).
-//   D != 0 : f(b) = ceil(cnt[b] / D)
-//   D == 0 : folds the plan statistics of `plan_blocks` blocks, picks the slot length L (info[INFO_L]) that minimises
-//            rounds * L for `round_lanes` lanes per round, and uses f(b) = ceil(cnt[b] / L);
-//            also writes start_out = cur_out = exclusive scan of cnt, info[INFO_MAXCNT], info[INFO_ENTRIES]
-//   f_out[b] = f(b), off_out[b] = exclusive scan of f, off_out[B] = info[INFO_SLOTS] = total
-__global__ void __launch_bounds__(1024) bucket_scan_kernel(const uint32_t* cnt, uint32_t B, uint32_t D, uint32_t* f_out,
-                                                           uint32_t* off_out, uint32_t* start_out, uint32_t* cur_out,
-                                                           const uint32_t* plan,
-                                                           uint32_t plan_blocks, const SlotLadder ladder, uint32_t round_lanes,
-                                                           uint32_t force_L, uint32_t* info) {
-    __shared__ uint32_t wsum[3][16];
-    __shared__ uint32_t best;
-    const uint32_t tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    if (D == 0) {
-        if (tid == 0) best = 0xffffffffu;
-        __syncthreads();
-        __shared__ uint32_t stat[PLAN_STRIDE];
-        if (tid < PLAN_STRIDE) stat[tid] = 0;
-        __syncthreads();
-        {
-            const uint32_t col = tid & (PLAN_STRIDE - 1);
-            uint32_t v = 0;
-#pragma unroll 4
-            for (uint32_t k = tid / PLAN_STRIDE; k < plan_blocks; k += 1024 / PLAN_STRIDE) {
-                const uint32_t x = plan[(size_t)k * PLAN_STRIDE + col];
-                v = col == 0 ? (x > v ? x : v) : v + x;
-            }
-            if (col == 0) atomicMax(&stat[0], v);
-            else atomicAdd(&stat[col], v);
-        }
-        __syncthreads();
-        if (tid < PLAN_STRIDE) {
-            const uint32_t v = stat[tid];
-            if (tid == 0) info[INFO_MAXCNT] = v;
-            if (tid == 1) info[INFO_ENTRIES] = v;
-            if (tid >= 2) {
-                // candidate index tid - 2: recompute its L
-                const uint32_t L = ladder.L[tid - 2];
-                if (L) {
-                    const uint32_t rounds = v == 0 ? 1 : (v + round_lanes - 1) / round_lanes;
-                    // in 1/16 of a mixed addition per SIMD: the accumulate rounds, the partly filled last round
-                    // (about 0.7 L, measured) and the merge of v / B partial sums per bucket; ties go to the longer slot
-                    uint64_t cost = (uint64_t)rounds * L * 16 + (uint64_t)L * 11 + (uint64_t)(v / B) * 8;
-                    if (cost >= (1u << 20)) cost = (1u << 20) - 1;
-                    atomicMin(&best, ((uint32_t)cost << 12) | (L_MAX + 1 - L));
-                }
-            }
-        }
-        __syncthreads();
-        D = force_L ? force_L : (L_MAX + 1 - (best & 0xfff));
-        if (tid == 0) info[INFO_L] = D;
-    }
-    // wave wv owns rows r < per of 64 consecutive buckets each (coalesced); prefix sums stay in registers
-    const uint32_t per = B >= 1024 ? B / 1024 : 1;
-    const uint32_t base = wv * per * 64 + lane;
-    uint32_t offf[32], offc[32];
-    uint32_t carry_f = 0, carry_c = 0, heavy = 0;
+// Thread t of a 1024-lane block owns the `per` = B / 1024 consecutive buckets from t * per (B a power of two, at most
+// 32768; one bucket per thread below 1024): helpers of the one-block heavy-bucket scan.  The block then needs one serial
+// pass over a thread's own values, ONE scan over the 1024 thread sums and a second serial pass, instead of a wave scan
+// per 64 buckets with a carry from step to step (35 -> 27 us at 32768 buckets: 675 instructions instead of 4016, what is
+// left is the 64 cache lines that every strided load and store of a wave touches).
+__device__ __forceinline__ void load_owned(const uint32_t* src, uint32_t base, uint32_t per, bool live, uint32_t (&v)[32]) {
 #pragma unroll
-    for (uint32_t r = 0; r < 32; r++) {
-        offf[r] = offc[r] = 0;
-        if (r < per) {
-            const uint32_t idx = base + r * 64;
-            const uint32_t c = idx < B ? cnt[idx] : 0;
-            const uint32_t f = (c + D - 1) / D;
-            if (idx < B) f_out[idx] = f;
-            heavy += f > MERGE_DIRECT_MAX ? f : 0;
-            const uint32_t inf = wave_inclusive_scan_u32(f), inc = wave_inclusive_scan_u32(c);
-            offf[r] = carry_f + inf - f;
-            offc[r] = carry_c + inc - c;
-            carry_f += __shfl(inf, 63, 64);
-            carry_c += __shfl(inc, 63, 64);
-        }
+    for (int i = 0; i < 32; i++) v[i] = 0;
+    if (!live) return;
+    if (per >= 4) {
+#pragma unroll
+        for (int j = 0; j < 8; j++)
+            if ((uint32_t)(4 * j) < per) {
+                const uint4 q = *reinterpret_cast<const uint4*>(src + base + 4 * j);
+                v[4 * j] = q.x;
+                v[4 * j + 1] = q.y;
+                v[4 * j + 2] = q.z;
+                v[4 * j + 3] = q.w;
+            }
+    } else {
+        v[0] = src[base];
+        if (per > 1) v[1] = src[base + 1];
     }
-    heavy = wave_sum_u32(heavy);
-    if (lane == 0) {
-        wsum[0][wv] = carry_f;
-        wsum[1][wv] = carry_c;
-        wsum[2][wv] = heavy;
+}
+__device__ __forceinline__ void store_owned(uint32_t* dst, uint32_t base, uint32_t per, bool live, const uint32_t (&v)[32]) {
+    if (!live) return;
+    if (per >= 4) {
+#pragma unroll
+        for (int j = 0; j < 8; j++)
+            if ((uint32_t)(4 * j) < per)
+                *reinterpret_cast<uint4*>(dst + base + 4 * j) = make_uint4(v[4 * j], v[4 * j + 1], v[4 * j + 2], v[4 * j + 3]);
+    } else {
+        dst[base] = v[0];
+        if (per > 1) dst[base + 1] = v[1];
+    }
+}
+
+// Block j (256 lanes) covers the buckets [256 j, 256 j + 256) -- the buckets of block j of column_sum_kernel, whose row
+// of plan statistics already holds this block's entries and, for every ladder step, its slots.  Every block folds ALL
+// rows (64 KiB at 32768 buckets, out of L2): the totals give it the slot length L that minimises rounds * L for
+// `round_lanes` lanes per round, the rows before its own the start of its buckets' entries and slots.  With
+// f(b) = ceil(cnt[b] / L): f_out[b] = f(b), off_out[b] = exclusive scan of f, off_out[B] = info[INFO_SLOTS] = total,
+// start_out = cur_out = exclusive scan of cnt, info[INFO_L, INFO_MAXCNT, INFO_ENTRIES, INFO_HEAVY].  (One block of 1024
+// lanes scanning all buckets took 26 us at 32768 buckets, on every MSM's critical path; 128 blocks take 9 us, and a
+// 256-lane block of few registers finds room beside the accumulate kernel of the MSM before in a batch.)
+// sync[0] collects the blocks' heavy counts, sync[1] counts finished blocks; the last one publishes and clears both.
+constexpr int SCAN_THREADS = 256;
+__global__ void __launch_bounds__(SCAN_THREADS) bucket_scan_kernel(const uint32_t* cnt, uint32_t B, uint32_t* f_out,
+                                                                   uint32_t* off_out, uint32_t* start_out, uint32_t* cur_out,
+                                                                   const uint32_t* plan, uint32_t plan_blocks,
+                                                                   const SlotLadder ladder, uint32_t round_lanes,
+                                                                   uint32_t* sync, uint32_t* info) {
+    __shared__ uint32_t tot[PLAN_STRIDE], pre[PLAN_STRIDE], wsum[3][SCAN_THREADS / 64];
+    __shared__ uint32_t best, best_idx;
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, j = blockIdx.x;
+    const uint32_t b = j * SCAN_THREADS + tid;
+    const uint32_t c = b < B ? cnt[b] : 0;           // travels while the plan is folded
+    if (tid < PLAN_STRIDE) tot[tid] = pre[tid] = 0;
+    if (tid == 0) best = 0xffffffffu;
+    __syncthreads();
+    {
+        const uint32_t col = tid & (PLAN_STRIDE - 1);
+        uint32_t v = 0, before = 0;
+#pragma unroll 8
+        for (uint32_t k = tid / PLAN_STRIDE; k < plan_blocks; k += SCAN_THREADS / PLAN_STRIDE) {
+            const uint32_t x = plan[(size_t)k * PLAN_STRIDE + col];
+            v = col == 0 ? (x > v ? x : v) : v + x;
+            before += k < j ? x : 0;
+        }
+        if (col == 0) atomicMax(&tot[0], v);
+        else {
+            atomicAdd(&tot[col], v);
+            atomicAdd(&pre[col], before);
+        }
     }
     __syncthreads();
-    uint32_t bs = 0, be = 0, total = 0, heavy_total = 0;
-    for (uint32_t k = 0; k < 16; k++) {
-        const uint32_t a = wsum[0][k];
-        if (k < wv) {
-            bs += a;
-            be += wsum[1][k];
+    if (tid >= 2 && tid < PLAN_STRIDE) {
+        // candidate index tid - 2
+        const uint32_t L = ladder.L[tid - 2], v = tot[tid];
+        if (L) {
+            const uint32_t rounds = v == 0 ? 1 : (v + round_lanes - 1) / round_lanes;
+            // in 1/16 of a mixed addition per SIMD: the accumulate rounds, the partly filled last round
+            // (about 0.7 L, measured) and the merge of v / B partial sums per bucket; ties go to the longer slot
+            uint64_t cost = (uint64_t)rounds * L * 16 + (uint64_t)L * 11 + (uint64_t)(v / B) * 8;
+            if (cost >= (1u << 20)) cost = (1u << 20) - 1;
+            atomicMin(&best, ((uint32_t)cost << 12) | (L_MAX + 1 - L));
         }
-        total += a;
-        heavy_total += wsum[2][k];
     }
-#pragma unroll
-    for (uint32_t r = 0; r < 32; r++) {
-        if (r < per) {
-            const uint32_t idx = base + r * 64;
-            if (idx < B) {
-                off_out[idx] = bs + offf[r];
-                if (start_out) {
-                    start_out[idx] = be + offc[r];
-                    cur_out[idx] = be + offc[r];
-                }
-            }
+    __syncthreads();
+    const uint32_t D = L_MAX + 1 - (best & 0xfff);
+    if (tid >= 2 && tid < PLAN_STRIDE && ladder.L[tid - 2] == D) best_idx = tid;   // ladder steps are distinct
+    __syncthreads();
+    const uint32_t col_f = best_idx;
+    // ceil(c / D) = floor((c + D - 1) ceil(2^32 / D) / 2^32), one too large at most (c < 2^27, D <= 256): corrected
+    const uint32_t magic = (uint32_t)((0x100000000ull + D - 1) / D);
+    const uint32_t x = c + D - 1;
+    uint32_t f = __umulhi(x, magic);
+    if (f * D > x) f--;
+    const uint32_t inc_f = wave_inclusive_scan_u32(f), inc_c = wave_inclusive_scan_u32(c);
+    const uint32_t heavy = wave_sum_u32(f > MERGE_DIRECT_MAX ? f : 0);
+    if (lane == 63) {
+        wsum[0][wv] = inc_f;
+        wsum[1][wv] = inc_c;
+    }
+    if (lane == 0) wsum[2][wv] = heavy;
+    __syncthreads();
+    uint32_t run_f = pre[col_f] + inc_f - f, run_c = pre[1] + inc_c - c, heavy_block = 0;
+    for (uint32_t k = 0; k < SCAN_THREADS / 64; k++) {
+        if (k < wv) {
+            run_f += wsum[0][k];
+            run_c += wsum[1][k];
         }
+        heavy_block += wsum[2][k];
+    }
+    if (b < B) {
+        f_out[b] = f;
+        off_out[b] = run_f;
+        start_out[b] = run_c;
+        cur_out[b] = run_c;
     }
     if (tid == 0) {
-        off_out[B] = total;
-        if (info) {
-            info[INFO_SLOTS] = total;
+        if (heavy_block) atomicAdd(&sync[0], heavy_block);
+        __threadfence();
+        if (atomicAdd(&sync[1], 1u) == gridDim.x - 1) {
+            __threadfence();
+            const uint32_t heavy_total = atomicExch(&sync[0], 0u);
+            atomicExch(&sync[1], 0u);
+            off_out[B] = tot[col_f];
+            info[INFO_SLOTS] = tot[col_f];
+            info[INFO_MAXCNT] = tot[0];
+            info[INFO_L] = D;
+            info[INFO_ENTRIES] = tot[1];
             info[INFO_HEAVY] = heavy_total;
         }
     }
@@ -567,49 +591,67 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))
 // (offset, count) of the next level points either at the old items or at the new ones; both live in one array.
 constexpr uint32_t MERGE_WAVE = 64;    // items one wave folds in a pre-level for few, very heavy buckets
 constexpr uint32_t MERGE_LANE = 16;    // items one lane folds in a pre-level for many heavy buckets
+static_assert(MERGE_WAVE == 1u << 6 && MERGE_LANE == 1u << 4, "heavy_scan_kernel is given log2 of the fold");
 
-// one block: hoff = exclusive scan of f(b) = cnt > direct_max ? ceil(cnt / fold) : 0 (hoff[B] = total), and the
+// one block: hoff = exclusive scan of f(b) = cnt > direct_max ? ceil(cnt / 2^fold_log) : 0 (hoff[B] = total), and the
 // bucket view after the level: heavy buckets at out_base + hoff[b] with f(b) items, light buckets unchanged
-__global__ void __launch_bounds__(1024) heavy_scan_kernel(const uint32_t* off_in, const uint32_t* cnt_in, uint32_t B, uint32_t fold,
+__global__ void __launch_bounds__(1024) heavy_scan_kernel(const uint32_t* off_in, const uint32_t* cnt_in, uint32_t B, uint32_t fold_log,
                                                           uint32_t direct_max, uint32_t out_base, uint32_t* hoff, uint32_t* off_out, uint32_t* cnt_out) {
-    // wave w scans the segment [w S, (w + 1) S) of the buckets, 64 consecutive buckets per step (coalesced), with a
-    // running carry and no barrier; the sixteen segment totals then give every wave its base
-    __shared__ uint32_t seg_tot[16];
-    constexpr int STEPS = 32;   // 32768 buckets at most = 16 waves x 32 steps x 64 lanes
-    const uint32_t w = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const uint32_t S = B / 16 > 64 ? B / 16 : 64;   // B is a power of two >= 128
-    uint32_t ex[STEPS], cs[STEPS];
-    uint32_t run = 0;
+    __shared__ uint32_t wtot[16];
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const uint32_t per = B >= 1024 ? B >> 10 : 1, base = tid * per;   // B is a power of two >= 128
+    const bool live = base < B;
+    const uint32_t fold_mask = (1u << fold_log) - 1;
+    uint32_t c[32];
+    load_owned(cnt_in, base, per, live, c);
+    uint32_t sum = 0;
 #pragma unroll
-    for (int i = 0; i < STEPS; i++) {
-        const uint32_t b = w * S + i * 64 + lane;
-        const bool in = (uint32_t)(i * 64) < S && b < B;
-        const uint32_t c = in ? cnt_in[b] : 0;
-        const uint32_t f = c > direct_max ? (c + fold - 1) / fold : 0;
-        const uint32_t inc = wave_inclusive_scan_u32(f);
-        cs[i] = c;
-        ex[i] = run + inc - f;
-        run += __shfl(inc, 63, 64);
-    }
-    if (lane == 0) seg_tot[w] = run;
+    for (int i = 0; i < 32; i++) sum += c[i] > direct_max ? (c[i] + fold_mask) >> fold_log : 0;
+    const uint32_t inc = wave_inclusive_scan_u32(sum);
+    if (lane == 63) wtot[wv] = inc;
     __syncthreads();
-    uint32_t base = 0, total = 0;
+    uint32_t run = inc - sum, total = 0;
     for (uint32_t k = 0; k < 16; k++) {
-        if (k < w) base += seg_tot[k];
-        total += seg_tot[k];
+        if (k < wv) run += wtot[k];
+        total += wtot[k];
     }
+    // second pass in groups of four buckets, loaded and stored as they come (two more arrays of 32 values would not fit
+    // the 128 registers that a 1024-lane block leaves a lane)
+    const uint32_t group = per >= 4 ? 4 : per;
 #pragma unroll
-    for (int i = 0; i < STEPS; i++) {
-        const uint32_t b = w * S + i * 64 + lane;
-        if ((uint32_t)(i * 64) < S && b < B) {
-            const uint32_t c = cs[i], at = base + ex[i];
-            const bool heavy = c > direct_max;
-            hoff[b] = at;
-            off_out[b] = heavy ? out_base + at : off_in[b];
-            cnt_out[b] = heavy ? (c + fold - 1) / fold : c;
+    for (int j = 0; j < 8; j++) {
+        if (!live || (uint32_t)(4 * j) >= per) continue;
+        uint32_t o4[4] = {0, 0, 0, 0}, h4[4], c4[4];
+        if (group == 4) {
+            const uint4 q = *reinterpret_cast<const uint4*>(off_in + base + 4 * j);
+            o4[0] = q.x, o4[1] = q.y, o4[2] = q.z, o4[3] = q.w;
+        } else {
+            o4[0] = off_in[base];
+            if (group > 1) o4[1] = off_in[base + 1];
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const uint32_t ck = c[4 * j + k];
+            const bool heavy = ck > direct_max;
+            const uint32_t f = heavy ? (ck + fold_mask) >> fold_log : 0;
+            h4[k] = run;
+            o4[k] = heavy ? out_base + run : o4[k];
+            c4[k] = heavy ? f : ck;
+            run += f;
+        }
+        if (group == 4) {
+            *reinterpret_cast<uint4*>(hoff + base + 4 * j) = make_uint4(h4[0], h4[1], h4[2], h4[3]);
+            *reinterpret_cast<uint4*>(off_out + base + 4 * j) = make_uint4(o4[0], o4[1], o4[2], o4[3]);
+            *reinterpret_cast<uint4*>(cnt_out + base + 4 * j) = make_uint4(c4[0], c4[1], c4[2], c4[3]);
+        } else {
+            for (uint32_t k = 0; k < group; k++) {
+                hoff[base + k] = h4[k];
+                off_out[base + k] = o4[k];
+                cnt_out[base + k] = c4[k];
+            }
         }
     }
-    if (threadIdx.x == 0) hoff[B] = total;
+    if (tid == 0) hoff[B] = total;
 }
 
 // wave t of the launch folds items [lo, lo + 64) of its heavy bucket into items[out_base + t].  Two lanes per point
@@ -845,6 +887,10 @@ static int ws_prepare(zkhip_ctx* ctx, MsmWorkspace& ws, const MsmTables& tb, siz
     ws.l_min = (uint32_t)std::min<size_t>(64, std::max<size_t>(8, E_max / (8 * round_lanes)));
     if (FORCE_L) ws.l_min = std::min(ws.l_min, FORCE_L);
     ws.ladder = make_ladder(ws.l_min);
+    if (FORCE_L) {                       // measurements: the forced length is the only candidate
+        for (uint32_t i = 0; i < PLAN_STRIDE; i++) ws.ladder.L[i] = 0;
+        ws.ladder.L[0] = std::min(FORCE_L, L_MAX);
+    }
     ws.plan_blocks = (B + 255) / 256;
     const size_t T1_max = E_max / ws.l_min + B + 1;
     const size_t J = (B + 63) / 64;
@@ -854,10 +900,11 @@ static int ws_prepare(zkhip_ctx* ctx, MsmWorkspace& ws, const MsmTables& tb, siz
         off = align_up(off + bytes, 256);
         return o;
     };
+    const size_t o_info = take(64);      // first, so that the scan's two counters keep their place (and their zeros) whatever n is
     const size_t o_counts = take((size_t)B * G * 4), o_entries = take(E_max * 4), o_tmp = take(E_max * 8),
                  o_cur = take((size_t)B * 4), o_bin = take((size_t)G * 256 * 4), o_start = take(((size_t)B + 1) * 4),
                  o_cnt = take((size_t)B * 4), o_offA = take(((size_t)B + 1) * 4), o_cntA = take((size_t)B * 4),
-                 o_offB = take(((size_t)B + 1) * 4), o_cntB = take((size_t)B * 4), o_info = take(64),
+                 o_offB = take(((size_t)B + 1) * 4), o_cntB = take((size_t)B * 4),
                  o_plan = take((size_t)ws.plan_blocks * PLAN_STRIDE * 4), o_itemsA = take(T1_max * sizeof(g1_xyzz)),
                  o_itemsB = take((T1_max / 8 + 2 * (size_t)B + 64) * sizeof(g1_xyzz)), o_hoff = take(((size_t)B + 1) * 4), o_sums = take((size_t)B * sizeof(g1_xyzz)),
                  o_l1 = take((size_t)RED_STREAMS * J * sizeof(g1_xyzz)),
@@ -873,6 +920,7 @@ static int ws_prepare(zkhip_ctx* ctx, MsmWorkspace& ws, const MsmTables& tb, siz
         }
         ZK_HIP(ctx, hipMalloc((void**)&ws.base, off));
         ws.bytes = off;
+        ZK_HIP(ctx, hipMemsetAsync(ws.base + o_info, 0, 64, ws.stream));
     }
     // page-locked and coherent: the plan and the reduce's leftover sums are written there by the kernels themselves
     // (one copy command and its launch gap less on the critical path of a lone MSM, twice)
@@ -939,8 +987,8 @@ static int msm_phase1(zkhip_ctx* ctx, MsmWorkspace& ws, const MsmTables& tb, siz
     ZK_FOR_WINDOW_WIDTH(ZK_LAUNCH_HIST)
 #undef ZK_LAUNCH_HIST
     hipLaunchKernelGGL(column_sum_kernel, dim3(ws.plan_blocks), dim3(COLSUM_THREADS), 0, st, ws.counts, G, B, ws.cnt, ws.ladder, ws.plan);
-    hipLaunchKernelGGL(bucket_scan_kernel, dim3(1), dim3(1024), 0, st, ws.cnt, B, 0u, ws.cntA, ws.offA, ws.start, ws.cur, ws.plan,
-                       ws.plan_blocks, ws.ladder, (uint32_t)ctx->num_cus * 256u, FORCE_L, ws.h_info);
+    hipLaunchKernelGGL(bucket_scan_kernel, dim3(ws.plan_blocks), dim3(SCAN_THREADS), 0, st, ws.cnt, B, ws.cntA, ws.offA, ws.start,
+                       ws.cur, ws.plan, ws.plan_blocks, ws.ladder, (uint32_t)ctx->num_cus * 256u, ws.info, ws.h_info);
     // the plan is in host memory when this event completes, while scatter and accumulate run
     ZK_HIP(ctx, hipEventRecord(ws.ev_info, st));
     {
@@ -1009,7 +1057,7 @@ static int msm_phase2(zkhip_ctx* ctx, MsmWorkspace& ws, const MsmTables& tb, boo
             const bool by_wave = level_heavy / MERGE_WAVE <= 8u * 1024u;
             const uint32_t fold = by_wave ? MERGE_WAVE : MERGE_LANE;
             hipLaunchKernelGGL(heavy_scan_kernel, dim3(1), dim3(1024), 0, st, (const uint32_t*)cur_off, (const uint32_t*)cur_cnt, B,
-                               fold, direct_max, out_base, ws.hoff, nxt_off, nxt_cnt);
+                               by_wave ? 6u : 4u /* log2 fold */, direct_max, out_base, ws.hoff, nxt_off, nxt_cnt);
             // a heavy bucket yields at most cnt / fold + 1 outputs, and there are at most min(B, heavy / 33) of them; all
             // levels together stay below the T1 / 8 + 2 B + 64 items reserved behind the slot sums
             const uint32_t bound = level_heavy / fold + std::min(B, level_heavy / (MERGE_DIRECT_MAX + 1)) + 1;
