@@ -393,43 +393,6 @@ __global__ void __launch_bounds__(COLSUM_THREADS) column_sum_kernel(const uint32
     for (uint32_t i = threadIdx.x; i < PLAN_STRIDE; i += COLSUM_THREADS) plan[(size_t)blockIdx.x * PLAN_STRIDE + i] = sh[i];
 }
 
-// Thread t of a 1024-lane block owns the `per` = B / 1024 consecutive buckets from t * per (B a power of two, at most
-// 32768; one bucket per thread below 1024): helpers of the one-block heavy-bucket scan.  The block then needs one serial
-// pass over a thread's own values, ONE scan over the 1024 thread sums and a second serial pass, instead of a wave scan
-// per 64 buckets with a carry from step to step (35 -> 27 us at 32768 buckets: 675 instructions instead of 4016, what is
-// left is the 64 cache lines that every strided load and store of a wave touches).
-__device__ __forceinline__ void load_owned(const uint32_t* src, uint32_t base, uint32_t per, bool live, uint32_t (&v)[32]) {
-#pragma unroll
-    for (int i = 0; i < 32; i++) v[i] = 0;
-    if (!live) return;
-    if (per >= 4) {
-#pragma unroll
-        for (int j = 0; j < 8; j++)
-            if ((uint32_t)(4 * j) < per) {
-                const uint4 q = *reinterpret_cast<const uint4*>(src + base + 4 * j);
-                v[4 * j] = q.x;
-                v[4 * j + 1] = q.y;
-                v[4 * j + 2] = q.z;
-                v[4 * j + 3] = q.w;
-            }
-    } else {
-        v[0] = src[base];
-        if (per > 1) v[1] = src[base + 1];
-    }
-}
-__device__ __forceinline__ void store_owned(uint32_t* dst, uint32_t base, uint32_t per, bool live, const uint32_t (&v)[32]) {
-    if (!live) return;
-    if (per >= 4) {
-#pragma unroll
-        for (int j = 0; j < 8; j++)
-            if ((uint32_t)(4 * j) < per)
-                *reinterpret_cast<uint4*>(dst + base + 4 * j) = make_uint4(v[4 * j], v[4 * j + 1], v[4 * j + 2], v[4 * j + 3]);
-    } else {
-        dst[base] = v[0];
-        if (per > 1) dst[base + 1] = v[1];
-    }
-}
-
 // Block j (256 lanes) covers the buckets [256 j, 256 j + 256) -- the buckets of block j of column_sum_kernel, whose row
 // of plan statistics already holds this block's entries and, for every ladder step, its slots.  Every block folds ALL
 // rows (64 KiB at 32768 buckets, out of L2): the totals give it the slot length L that minimises rounds * L for
@@ -593,65 +556,45 @@ constexpr uint32_t MERGE_WAVE = 64;    // items one wave folds in a pre-level fo
 constexpr uint32_t MERGE_LANE = 16;    // items one lane folds in a pre-level for many heavy buckets
 static_assert(MERGE_WAVE == 1u << 6 && MERGE_LANE == 1u << 4, "heavy_scan_kernel is given log2 of the fold");
 
-// one block: hoff = exclusive scan of f(b) = cnt > direct_max ? ceil(cnt / 2^fold_log) : 0 (hoff[B] = total), and the
-// bucket view after the level: heavy buckets at out_base + hoff[b] with f(b) items, light buckets unchanged
-__global__ void __launch_bounds__(1024) heavy_scan_kernel(const uint32_t* off_in, const uint32_t* cnt_in, uint32_t B, uint32_t fold_log,
-                                                          uint32_t direct_max, uint32_t out_base, uint32_t* hoff, uint32_t* off_out, uint32_t* cnt_out) {
-    __shared__ uint32_t wtot[16];
-    const uint32_t tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const uint32_t per = B >= 1024 ? B >> 10 : 1, base = tid * per;   // B is a power of two >= 128
-    const bool live = base < B;
-    const uint32_t fold_mask = (1u << fold_log) - 1;
-    uint32_t c[32];
-    load_owned(cnt_in, base, per, live, c);
-    uint32_t sum = 0;
-#pragma unroll
-    for (int i = 0; i < 32; i++) sum += c[i] > direct_max ? (c[i] + fold_mask) >> fold_log : 0;
-    const uint32_t inc = wave_inclusive_scan_u32(sum);
-    if (lane == 63) wtot[wv] = inc;
+// hoff = exclusive scan of f(b) = cnt > direct_max ? ceil(cnt / 2^fold_log) : 0 (hoff[B] = total), and the bucket view
+// after the level: heavy buckets at out_base + hoff[b] with f(b) items, light buckets unchanged.  Block j (256 lanes)
+// covers the buckets [256 j, 256 j + 256) and sums f over all buckets before its own by itself (at most 128 KiB out of
+// L2, four values per load): no block waits for another, and 128 small blocks take 5 us where one block of 1024 lanes
+// scanning all 32768 buckets took 27 - 35 us (two such levels sit in the tail of every sparse witness column).
+__global__ void __launch_bounds__(SCAN_THREADS) heavy_scan_kernel(const uint32_t* off_in, const uint32_t* cnt_in, uint32_t B,
+                                                                  uint32_t fold_log, uint32_t direct_max, uint32_t out_base,
+                                                                  uint32_t* hoff, uint32_t* off_out, uint32_t* cnt_out) {
+    __shared__ uint32_t wsum[SCAN_THREADS / 64], wpre[SCAN_THREADS / 64];
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, j = blockIdx.x;
+    const uint32_t b = j * SCAN_THREADS + tid, fold_mask = (1u << fold_log) - 1;
+    const uint32_t c = b < B ? cnt_in[b] : 0, o = b < B ? off_in[b] : 0;
+    uint32_t before = 0;
+#pragma unroll 4
+    for (uint32_t i = 4 * tid; i < j * SCAN_THREADS; i += 4 * SCAN_THREADS) {   // whole blocks of 256 buckets: no tail
+        const uint4 q = *reinterpret_cast<const uint4*>(cnt_in + i);
+        before += q.x > direct_max ? (q.x + fold_mask) >> fold_log : 0;
+        before += q.y > direct_max ? (q.y + fold_mask) >> fold_log : 0;
+        before += q.z > direct_max ? (q.z + fold_mask) >> fold_log : 0;
+        before += q.w > direct_max ? (q.w + fold_mask) >> fold_log : 0;
+    }
+    before = wave_sum_u32(before);
+    const bool heavy = c > direct_max;
+    const uint32_t f = heavy ? (c + fold_mask) >> fold_log : 0;
+    const uint32_t inc = wave_inclusive_scan_u32(f);
+    if (lane == 63) wsum[wv] = inc;
+    if (lane == 0) wpre[wv] = before;
     __syncthreads();
-    uint32_t run = inc - sum, total = 0;
-    for (uint32_t k = 0; k < 16; k++) {
-        if (k < wv) run += wtot[k];
-        total += wtot[k];
+    uint32_t run = inc - f;
+    for (uint32_t k = 0; k < SCAN_THREADS / 64; k++) {
+        run += wpre[k];
+        if (k < wv) run += wsum[k];
     }
-    // second pass in groups of four buckets, loaded and stored as they come (two more arrays of 32 values would not fit
-    // the 128 registers that a 1024-lane block leaves a lane)
-    const uint32_t group = per >= 4 ? 4 : per;
-#pragma unroll
-    for (int j = 0; j < 8; j++) {
-        if (!live || (uint32_t)(4 * j) >= per) continue;
-        uint32_t o4[4] = {0, 0, 0, 0}, h4[4], c4[4];
-        if (group == 4) {
-            const uint4 q = *reinterpret_cast<const uint4*>(off_in + base + 4 * j);
-            o4[0] = q.x, o4[1] = q.y, o4[2] = q.z, o4[3] = q.w;
-        } else {
-            o4[0] = off_in[base];
-            if (group > 1) o4[1] = off_in[base + 1];
-        }
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const uint32_t ck = c[4 * j + k];
-            const bool heavy = ck > direct_max;
-            const uint32_t f = heavy ? (ck + fold_mask) >> fold_log : 0;
-            h4[k] = run;
-            o4[k] = heavy ? out_base + run : o4[k];
-            c4[k] = heavy ? f : ck;
-            run += f;
-        }
-        if (group == 4) {
-            *reinterpret_cast<uint4*>(hoff + base + 4 * j) = make_uint4(h4[0], h4[1], h4[2], h4[3]);
-            *reinterpret_cast<uint4*>(off_out + base + 4 * j) = make_uint4(o4[0], o4[1], o4[2], o4[3]);
-            *reinterpret_cast<uint4*>(cnt_out + base + 4 * j) = make_uint4(c4[0], c4[1], c4[2], c4[3]);
-        } else {
-            for (uint32_t k = 0; k < group; k++) {
-                hoff[base + k] = h4[k];
-                off_out[base + k] = o4[k];
-                cnt_out[base + k] = c4[k];
-            }
-        }
+    if (b < B) {
+        hoff[b] = run;
+        off_out[b] = heavy ? out_base + run : o;
+        cnt_out[b] = heavy ? f : c;
+        if (b == B - 1) hoff[B] = run + f;
     }
-    if (tid == 0) hoff[B] = total;
 }
 
 // wave t of the launch folds items [lo, lo + 64) of its heavy bucket into items[out_base + t].  Two lanes per point
@@ -1056,7 +999,7 @@ static int msm_phase2(zkhip_ctx* ctx, MsmWorkspace& ws, const MsmTables& tb, boo
         while (level_max > direct_max) {
             const bool by_wave = level_heavy / MERGE_WAVE <= 8u * 1024u;
             const uint32_t fold = by_wave ? MERGE_WAVE : MERGE_LANE;
-            hipLaunchKernelGGL(heavy_scan_kernel, dim3(1), dim3(1024), 0, st, (const uint32_t*)cur_off, (const uint32_t*)cur_cnt, B,
+            hipLaunchKernelGGL(heavy_scan_kernel, dim3((B + SCAN_THREADS - 1) / SCAN_THREADS), dim3(SCAN_THREADS), 0, st, (const uint32_t*)cur_off, (const uint32_t*)cur_cnt, B,
                                by_wave ? 6u : 4u /* log2 fold */, direct_max, out_base, ws.hoff, nxt_off, nxt_cnt);
             // a heavy bucket yields at most cnt / fold + 1 outputs, and there are at most min(B, heavy / 33) of them; all
             // levels together stay below the T1 / 8 + 2 B + 64 items reserved behind the slot sums
