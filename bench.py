@@ -288,7 +288,8 @@ def main():
     acc_bracketed_us, _ = ctx.timing_get("msm_accumulate")
     ctx.timing_enable(False)
     extra_phases = {"sort": sort_us, "accumulate": acc_bracketed_us, "merge": merge_us, "reduce": reduce_us, "host_fold": fold_us,
-                    "what": "separate pass after the timed steps with every stage bracketed by HIP events (about 30 us more per MSM)"}
+                    "what": "separate pass after the timed steps with every stage bracketed by HIP events (about 30 us more per MSM); "
+                            "merge = the final merge level fused with level 1 of the reduce, reduce = its level 2"}
 
     if world > 1:
         t = torch.tensor([elapsed, msm_ms, ntt_ms], dtype=torch.float64, device="cuda")

@@ -210,6 +210,27 @@ __device__ __forceinline__ g1_xyzz xyzz_w_pack(const g1_xyzz_w& a) {
 }
 __device__ __forceinline__ void xyzz_w_store(g1_xyzz* p, const g1_xyzz_w& a) { store_xyzz(p, xyzz_w_pack(a)); }
 
+// c ? t : f, field by field (a conditional expression over whole structs selects between their ADDRESSES, which puts both
+// on the stack)
+__device__ __forceinline__ g1_xyzz_w xyzz_w_sel(bool c, const g1_xyzz_w& t, const g1_xyzz_w& f) {
+    g1_xyzz_w o;
+    o.x = fw_sel(c, t.x, f.x);
+    o.y = fw_sel(c, t.y, f.y);
+    o.zz = fw_sel(c, t.zz, f.zz);
+    o.zzz = fw_sel(c, t.zzz, f.zzz);
+    o.inf = c ? t.inf : f.inf;
+    return o;
+}
+// the point held by the other lane of a pair (lanes 2 i <-> 2 i + 1)
+__device__ __forceinline__ g1_xyzz_w xyzz_w_pair_other(const g1_xyzz_w& v) {
+    g1_xyzz_w o;
+    o.x = fw_pair_other(v.x);
+    o.y = fw_pair_other(v.y);
+    o.zz = fw_pair_other(v.zz);
+    o.zzz = fw_pair_other(v.zzz);
+    o.inf = __builtin_amdgcn_update_dpp(0, (int)v.inf, 0xB1, 0xf, 0xf, false) != 0;
+    return o;
+}
 __device__ __forceinline__ g1_xyzz_w xyzz_w_shfl(const g1_xyzz_w& v, int src_lane) {
     g1_xyzz_w o;
 #pragma unroll

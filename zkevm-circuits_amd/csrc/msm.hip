@@ -347,8 +347,10 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
 // Each block also leaves its share of the plan statistics in plan[blockIdx.x][*].
 constexpr int COLSUM_THREADS = 1024;
 __global__ void __launch_bounds__(COLSUM_THREADS) column_sum_kernel(const uint32_t* counts /*[G][B]*/, uint32_t G, uint32_t B,
-                                                                    uint32_t* cnt, const SlotLadder ladder, uint32_t* plan) {
+                                                                    uint32_t* cnt, const SlotLadder ladder, uint32_t* plan,
+                                                                    uint32_t* scan_sync) {
     __shared__ uint32_t sh[PLAN_STRIDE];
+    if (blockIdx.x == 0 && threadIdx.x < 2) scan_sync[threadIdx.x] = 0;   // the two counters of bucket_scan_kernel, which runs next
     __shared__ uint32_t part[COLSUM_THREADS / 64][256];
     for (uint32_t i = threadIdx.x; i < PLAN_STRIDE; i += COLSUM_THREADS) sh[i] = 0;
     const uint32_t lane = threadIdx.x & 63, rg = threadIdx.x >> 6, b4 = blockIdx.x * 256 + 4 * lane;
@@ -401,7 +403,8 @@ __global__ void __launch_bounds__(COLSUM_THREADS) column_sum_kernel(const uint32
 // start_out = cur_out = exclusive scan of cnt, info[INFO_L, INFO_MAXCNT, INFO_ENTRIES, INFO_HEAVY].  (One block of 1024
 // lanes scanning all buckets took 26 us at 32768 buckets, on every MSM's critical path; 128 blocks take 9 us, and a
 // 256-lane block of few registers finds room beside the accumulate kernel of the MSM before in a batch.)
-// sync[0] collects the blocks' heavy counts, sync[1] counts finished blocks; the last one publishes and clears both.
+// sync[0] collects the blocks' heavy counts, sync[1] counts finished blocks (both zeroed by column_sum_kernel, which runs
+// before on the same stream); the last block publishes.
 constexpr int SCAN_THREADS = 256;
 __global__ void __launch_bounds__(SCAN_THREADS) bucket_scan_kernel(const uint32_t* cnt, uint32_t B, uint32_t* f_out,
                                                                    uint32_t* off_out, uint32_t* start_out, uint32_t* cur_out,
@@ -481,8 +484,7 @@ __global__ void __launch_bounds__(SCAN_THREADS) bucket_scan_kernel(const uint32_
         __threadfence();
         if (atomicAdd(&sync[1], 1u) == gridDim.x - 1) {
             __threadfence();
-            const uint32_t heavy_total = atomicExch(&sync[0], 0u);
-            atomicExch(&sync[1], 0u);
+            const uint32_t heavy_total = atomicAdd(&sync[0], 0u);
             off_out[B] = tot[col_f];
             info[INFO_SLOTS] = tot[col_f];
             info[INFO_MAXCNT] = tot[0];
@@ -633,35 +635,6 @@ __global__ void __launch_bounds__(256) merge_lane_kernel(g1_xyzz* items, const u
     xyzz_w_store(items + out_base + t, acc);
 }
 
-// final level: MERGE_P neighbouring lanes share one bucket; lane r folds items r, r + P, ... and a shuffle tree joins
-// the P partial sums.  out[b] = bucket sum (identity for an empty bucket).
-constexpr int MERGE_P = 2;
-__global__ void __launch_bounds__(256) merge_final_kernel(const g1_xyzz* in, const uint32_t* off_in, const uint32_t* cnt_in,
-                                                          uint32_t B, g1_xyzz* out) {
-    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    const uint32_t b = t / MERGE_P, r = t % MERGE_P;
-    const uint32_t lane = threadIdx.x & 63;
-    g1_xyzz_w acc = xyzz_w_identity();
-    if (b < B) {
-        const uint32_t c = cnt_in[b], base = off_in[b];
-        if (r < c) {
-            acc = xyzz_w_load(in + base + r);
-            g1_xyzz nxt;
-            if (r + MERGE_P < c) nxt = load_xyzz(in + base + r + MERGE_P);
-            for (uint32_t i = r + MERGE_P; i < c; i += MERGE_P) {
-                const g1_xyzz cur = nxt;
-                if (i + MERGE_P < c) nxt = load_xyzz(in + base + i + MERGE_P);   // in flight during the addition
-                acc = xyzz_w_add(acc, xyzz_w_unpack(cur));
-            }
-        }
-    }
-    for (int d = MERGE_P / 2; d >= 1; d >>= 1) {
-        const g1_xyzz_w o = xyzz_w_shfl(acc, (int)(lane ^ d));
-        acc = xyzz_w_add(acc, o);
-    }
-    if (b < B && r == 0) xyzz_w_store(out + b, acc);
-}
-
 // ---- reduce ----------------------------------------------------------------------------------------
 // sum over b of (b + 1) * S_b without scalar multiplications and with a short dependency chain.  For 2^NB points P_l
 // held one per lane, NB rounds of one point addition each leave in lane 0 the total A = sum P_l and in lane 2^j the
@@ -685,24 +658,46 @@ __device__ __forceinline__ g1_xyzz_w pairs_round_operand(const g1_xyzz_w& p, uin
 }
 constexpr size_t REDUCE_OUT = 56;      // four quarters of 14 points each, see reduce_level2_kernel
 
-// level 1: sums[b] for b < B (B a multiple of 128) -> l1[0][h] = A_h, l1[1 + j][h] = B_{h,j} for the 64-bucket group
+// The final merge level and level 1 of the reduce in one kernel.
+// Merge: the two lanes of a pair share bucket b; lane r folds its items r, r + 2, ... with one-lane additions (the next
+// item is in flight during an addition), then the lanes exchange their partial sums and join them with a two-lane
+// addition, which leaves the bucket's sum in both lanes -- what the rounds of level 1 start from.  (Four lanes per
+// bucket lose: 100 us against 92, and 89 against 74 as two cooperating pairs; their 2048 waves share SIMDs two by two.)
+// Level 1: bucket sums of b < B (B a multiple of 128) -> l1[0][h] = A_h, l1[1 + j][h] = B_{h,j} for the 64-bucket group
 // h = b / 64 (J = number of groups = row stride of l1).  A workgroup of four waves takes 128 buckets; waves 2 g and
 // 2 g + 1 are the lower and upper 32 logical lanes of the 64-bucket group g, and the round over bit 5 takes the upper
-// wave's sums from LDS
-__global__ void __launch_bounds__(256) reduce_level1_kernel(const g1_xyzz* sums, uint32_t B, uint32_t J, g1_xyzz* l1) {
+// wave's sums from LDS.
+// As two kernels (merge, then level 1 from memory) this took 20 us more of a lone MSM's 830: a launch gap, the
+// canonicalisation and store / load and unpack of 32768 bucket sums, and a one-lane addition for the join.
+__global__ void __launch_bounds__(256) merge_reduce_level1_kernel(const g1_xyzz* in, const uint32_t* off_in, const uint32_t* cnt_in,
+                                                                  uint32_t B, uint32_t J, g1_xyzz* l1) {
     __shared__ g1_xyzz_w ex[2][32];
-    const uint32_t w = threadIdx.x >> 6, lane = threadIdx.x & 63, ll = lane >> 1, g = w >> 1, upper = w & 1;
-    const bool role = (lane & 1u) != 0;
+    const uint32_t w = threadIdx.x >> 6, lane = threadIdx.x & 63, ll = lane >> 1, g = w >> 1, upper = w & 1, r = lane & 1u;
+    const bool role = r != 0;
     const uint32_t b = blockIdx.x * 128 + g * 64 + upper * 32 + ll;
-    g1_xyzz_w p = b < B ? xyzz_w_load(sums + b) : xyzz_w_identity();
-    // ONE copy of the addition's code for all six rounds (a second copy after the loop is another 17 KB of instructions
-    // that every wave of the chip fetches once, cold)
+    g1_xyzz_w acc = xyzz_w_identity();
+    if (b < B) {
+        const uint32_t c = cnt_in[b], base = off_in[b];
+        if (r < c) {
+            acc = xyzz_w_load(in + base + r);
+            g1_xyzz nxt;
+            if (r + 2 < c) nxt = load_xyzz(in + base + r + 2);
+            for (uint32_t i = r + 2; i < c; i += 2) {
+                const g1_xyzz cur = nxt;
+                if (i + 2 < c) nxt = load_xyzz(in + base + i + 2);   // in flight during the addition
+                acc = xyzz_w_add(acc, xyzz_w_unpack(cur));
+            }
+        }
+    }
+    // both lanes need the same two operands in the same order: a = the even lane's sum, b = the odd lane's
+    const g1_xyzz_w other = xyzz_w_pair_other(acc);
+    g1_xyzz_w p = xyzz_w_sel(role, other, acc), o = xyzz_w_sel(role, acc, other);
+    // ONE copy of the two-lane addition's code for the join (round 0) and the six rounds of level 1
 #pragma unroll 1
-    for (uint32_t r = 0; r < 6; r++) {
-        g1_xyzz_w o;
-        if (r < 5) {
-            o = pairs_round_operand(p, ll, r, role);
-        } else {
+    for (uint32_t k = 0; k < 7; k++) {
+        if (k >= 1 && k < 6) {
+            o = pairs_round_operand(p, ll, k - 1, role);
+        } else if (k == 6) {
             if (upper && !role) ex[g][ll] = p;
             __syncthreads();
             o = ex[g][ll];
@@ -716,6 +711,7 @@ __global__ void __launch_bounds__(256) reduce_level1_kernel(const g1_xyzz* sums,
         if (!upper || ll == 0) xyzz_w_store(l1 + (size_t)stream * J + (b >> 6), p);
     }
 }
+
 // level 2: workgroup (stream, quarter) folds l1[stream][128 quarter .. 128 quarter + 128), J <= 512, with four waves of 32
 // logical lanes (one wave per SIMD of its CU); then wave 0 folds the four results of the six groups (total and bit sums
 // 0..4 of the waves).  Over the bits of h = 128 quarter + 32 w + ll the totals' bit sums are D_0..D_4 (ll), D_5, D_6 (w);
@@ -817,7 +813,7 @@ struct MsmWorkspace {
     bool nonzero = false;
     uint32_t *counts, *entries, *start, *cnt, *offA, *cntA, *offB, *cntB, *info, *plan, *cur, *bincount, *hoff;
     uint2* tmp;
-    g1_xyzz *itemsA, *itemsB, *sums, *l1, *out2;
+    g1_xyzz *itemsA, *itemsB, *l1, *out2;
 };
 
 static int ws_prepare(zkhip_ctx* ctx, MsmWorkspace& ws, const MsmTables& tb, size_t n) {
@@ -843,13 +839,13 @@ static int ws_prepare(zkhip_ctx* ctx, MsmWorkspace& ws, const MsmTables& tb, siz
         off = align_up(off + bytes, 256);
         return o;
     };
-    const size_t o_info = take(64);      // first, so that the scan's two counters keep their place (and their zeros) whatever n is
+    const size_t o_info = take(64);
     const size_t o_counts = take((size_t)B * G * 4), o_entries = take(E_max * 4), o_tmp = take(E_max * 8),
                  o_cur = take((size_t)B * 4), o_bin = take((size_t)G * 256 * 4), o_start = take(((size_t)B + 1) * 4),
                  o_cnt = take((size_t)B * 4), o_offA = take(((size_t)B + 1) * 4), o_cntA = take((size_t)B * 4),
                  o_offB = take(((size_t)B + 1) * 4), o_cntB = take((size_t)B * 4),
                  o_plan = take((size_t)ws.plan_blocks * PLAN_STRIDE * 4), o_itemsA = take(T1_max * sizeof(g1_xyzz)),
-                 o_itemsB = take((T1_max / 8 + 2 * (size_t)B + 64) * sizeof(g1_xyzz)), o_hoff = take(((size_t)B + 1) * 4), o_sums = take((size_t)B * sizeof(g1_xyzz)),
+                 o_itemsB = take((T1_max / 8 + 2 * (size_t)B + 64) * sizeof(g1_xyzz)), o_hoff = take(((size_t)B + 1) * 4),
                  o_l1 = take((size_t)RED_STREAMS * J * sizeof(g1_xyzz)),
                  o_out2 = take(REDUCE_OUT * sizeof(g1_xyzz));
     if (off > ws.bytes) {
@@ -863,7 +859,6 @@ static int ws_prepare(zkhip_ctx* ctx, MsmWorkspace& ws, const MsmTables& tb, siz
         }
         ZK_HIP(ctx, hipMalloc((void**)&ws.base, off));
         ws.bytes = off;
-        ZK_HIP(ctx, hipMemsetAsync(ws.base + o_info, 0, 64, ws.stream));
     }
     // page-locked and coherent: the plan and the reduce's leftover sums are written there by the kernels themselves
     // (one copy command and its launch gap less on the critical path of a lone MSM, twice)
@@ -893,7 +888,6 @@ static int ws_prepare(zkhip_ctx* ctx, MsmWorkspace& ws, const MsmTables& tb, siz
     ws.plan = (uint32_t*)(p + o_plan);
     ws.itemsA = (g1_xyzz*)(p + o_itemsA);
     ws.itemsB = (g1_xyzz*)(p + o_itemsB);
-    ws.sums = (g1_xyzz*)(p + o_sums);
     ws.l1 = (g1_xyzz*)(p + o_l1);
     ws.hoff = (uint32_t*)(p + o_hoff);
     ws.out2 = (g1_xyzz*)(p + o_out2);
@@ -929,7 +923,7 @@ static int msm_phase1(zkhip_ctx* ctx, MsmWorkspace& ws, const MsmTables& tb, siz
     hipLaunchKernelGGL(digits_hist_kernel<C>, dim3(G), dim3(HIST_THREADS), lds_hist, st, d_scalars, n, chunk, ws.counts, ws.bincount)
     ZK_FOR_WINDOW_WIDTH(ZK_LAUNCH_HIST)
 #undef ZK_LAUNCH_HIST
-    hipLaunchKernelGGL(column_sum_kernel, dim3(ws.plan_blocks), dim3(COLSUM_THREADS), 0, st, ws.counts, G, B, ws.cnt, ws.ladder, ws.plan);
+    hipLaunchKernelGGL(column_sum_kernel, dim3(ws.plan_blocks), dim3(COLSUM_THREADS), 0, st, ws.counts, G, B, ws.cnt, ws.ladder, ws.plan, ws.info);
     hipLaunchKernelGGL(bucket_scan_kernel, dim3(ws.plan_blocks), dim3(SCAN_THREADS), 0, st, ws.cnt, B, ws.cntA, ws.offA, ws.start,
                        ws.cur, ws.plan, ws.plan_blocks, ws.ladder, (uint32_t)ctx->num_cus * 256u, ws.info, ws.h_info);
     // the plan is in host memory when this event completes, while scatter and accumulate run
@@ -1017,14 +1011,13 @@ static int msm_phase2(zkhip_ctx* ctx, MsmWorkspace& ws, const MsmTables& tb, boo
             level_max = (level_max + fold - 1) / fold;
             level_heavy = bound;
         }
-        hipLaunchKernelGGL(merge_final_kernel, dim3((B * MERGE_P + 255) / 256), dim3(256), 0, st, (const g1_xyzz*)items,
-                           (const uint32_t*)cur_off, (const uint32_t*)cur_cnt, B, ws.sums);
+        hipLaunchKernelGGL(merge_reduce_level1_kernel, dim3(B / 128), dim3(256), 0, st, (const g1_xyzz*)items,
+                           (const uint32_t*)cur_off, (const uint32_t*)cur_cnt, B, B / 64, ws.l1);
         ZK_HIP(ctx, hipGetLastError());
     }
     {
         TimedRegion tr(ctx, timed ? "msm_reduce" : nullptr, st);
         const uint32_t J = B / 64;   // B is a multiple of 128
-        hipLaunchKernelGGL(reduce_level1_kernel, dim3(B / 128), dim3(256), 0, st, ws.sums, B, J, ws.l1);
         hipLaunchKernelGGL(reduce_level2_kernel, dim3(4 * RED_STREAMS), dim3(256), 0, st, ws.l1, J,
                            reinterpret_cast<g1_xyzz*>(ws.h_sums));
         ZK_HIP(ctx, hipGetLastError());
