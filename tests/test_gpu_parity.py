@@ -66,6 +66,31 @@ def test_poseidon_kat_through_device_fr(ctx):
     assert fr_ints(st)[0] == int(kat["expected"], 16)
 
 
+def test_timing_levels_bracket_the_named_stages_only(ctx, co):
+    """zkhip_timing_enable: level 1 brackets every stage of an MSM with HIP events, level 2 only the accumulate kernel (and
+    the NTT), level 0 nothing; the result does not depend on the level."""
+    rng = np.random.default_rng(5)
+    n = 4096
+    bases = co.g1_bases(n)
+    bid = ctx.register_bases(bases)
+    sc = rand_fr(rng, n)
+    points = []
+    for level, expect in ((1, {"msm_sort": 1, "msm_accumulate": 1, "msm_merge": 1, "msm_reduce": 1}),
+                          (2, {"msm_sort": 0, "msm_accumulate": 1, "msm_merge": 0, "msm_reduce": 0}),
+                          (False, {"msm_sort": 0, "msm_accumulate": 0, "msm_merge": 0, "msm_reduce": 0})):
+        ctx.timing_enable(level)
+        ctx.timing_reset()
+        points.append(ctx.g1_to_affine(ctx.msm(bid, sc)))
+        for family, launches in expect.items():
+            us, cnt = ctx.timing_get(family)
+            assert cnt == launches, (level, family)
+            assert (us > 0) == (launches > 0), (level, family)
+    ctx.timing_enable(False)
+    ctx.release_bases(bid)
+    assert np.array_equal(points[0], points[1]) and np.array_equal(points[0], points[2])
+    assert np.array_equal(points[0], co.g1_to_affine(co.best_multiexp(sc, bases, threads=4)))
+
+
 def test_curve_add_golden(ctx, co):
     g = golden("curve.json")
     p = affine_arr([hex_pt(c["p"]) for c in g["add"]])
