@@ -5,6 +5,7 @@ points, 12 for Jacobian), exactly the in-memory layout of `halo2curves::bn256::{
 """
 from __future__ import annotations
 
+import bisect
 import ctypes as C
 import os
 
@@ -149,6 +150,10 @@ class Context:
         # bytes handed out by alloc() and not yet freed, and their high-water mark: what a rank keeps resident
         self._sizes = {}
         self._pinned = {}                 # address -> bytes of the page-locked host buffers handed out by host_zeros
+        self._pinned_index = None         # sorted (base, end) pairs of the above, rebuilt after a change
+        self._stage = None                # page-locked ring for small uploads (see upload)
+        self._stage_at = 0
+        self._stage_small = os.environ.get("ZKHIP_STAGE_SMALL", "1") != "0"
         self.allocated_bytes = 0
         self.peak_allocated_bytes = 0
         # Freed blocks are kept by size and handed out again: a proof allocates and frees well over a hundred column-sized
@@ -233,6 +238,9 @@ class Context:
     def reset_peak(self):
         self.peak_allocated_bytes = self.allocated_bytes
 
+    STAGE_BYTES = 8 << 20          # ring of page-locked memory for small uploads
+    STAGE_MAX = 256 << 10          # arrays up to this size go through the ring
+
     def upload(self, arr, dptr: int | None = None) -> int:
         arr = u64(arr)
         if dptr is None:
@@ -240,6 +248,21 @@ class Context:
         if self.is_pinned(arr):
             # page-locked source: a DMA ordered on the context's stream, no wait (the buffer outlives the context's work)
             self._ck(self._l.zkhip_upload_async(self.h, C.c_void_p(dptr), _p(arr), C.c_size_t(arr.nbytes)))
+        elif 0 < arr.nbytes <= self.STAGE_MAX and self._stage_small:
+            # small arrays in ordinary memory (blinding rows, scalars of a phase): copied into a page-locked ring and sent
+            # from there without waiting.  A synchronous copy would make the host wait for everything queued before it
+            # -- two hundred times in a proof, with the device idle while the host catches up afterwards.
+            if self._stage is None:
+                self._stage = self.host_zeros((self.STAGE_BYTES // 8,))
+                self._stage_at = 0
+            words = (arr.size + 31) // 32 * 32                     # slots start on 256-byte boundaries
+            if self._stage_at + words > self._stage.size:
+                self.sync()                                        # every copy out of the ring has been made
+                self._stage_at = 0
+            view = self._stage[self._stage_at:self._stage_at + arr.size]
+            view[...] = arr.reshape(-1)
+            self._stage_at += words
+            self._ck(self._l.zkhip_upload_async(self.h, C.c_void_p(dptr), _p(view), C.c_size_t(arr.nbytes)))
         else:
             self._ck(self._l.zkhip_upload(self.h, C.c_void_p(dptr), _p(arr), C.c_size_t(arr.nbytes)))
         return dptr
@@ -262,6 +285,7 @@ class Context:
         h = C.c_void_p()
         self._ck(self._l.zkhip_host_alloc(self.h, C.c_size_t(max(nbytes, 8)), C.byref(h)))
         self._pinned[h.value] = max(nbytes, 8)
+        self._pinned_index = None
         buf = (C.c_uint8 * max(nbytes, 8)).from_address(h.value)
         a = np.frombuffer(buf, dtype=np.uint64, count=nbytes // 8).reshape(shape)
         a[...] = 0
@@ -272,13 +296,14 @@ class Context:
         if addr in self._pinned:
             self._ck(self._l.zkhip_host_free(self.h, C.c_void_p(addr)))
             del self._pinned[addr]
+            self._pinned_index = None
 
     def is_pinned(self, arr: np.ndarray) -> bool:
+        if self._pinned_index is None:
+            self._pinned_index = sorted((base, base + size) for base, size in self._pinned.items())
         addr = arr.ctypes.data
-        for base, size in self._pinned.items():
-            if base <= addr and addr + arr.nbytes <= base + size:
-                return True
-        return False
+        i = bisect.bisect_right(self._pinned_index, (addr, float("inf"))) - 1
+        return i >= 0 and addr + arr.nbytes <= self._pinned_index[i][1]
 
     def copy_dev(self, d_dst: int, d_src: int, nbytes: int):
         """device-to-device copy on the context's stream (asynchronous)"""
