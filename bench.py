@@ -20,6 +20,83 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+LAUNCH_LIMIT_SECONDS = 1500                     # a self-launched job that has not ended by then is killed (exit 124)
+
+
+def requested_gpus(argv):
+    ap = argparse.ArgumentParser(add_help=False)
+    ap.add_argument("--gpus", type=int, default=1)
+    return ap.parse_known_args(argv)[0].gpus
+
+
+def visible_devices():
+    """GPUs this process could use, counted by a child process so that the launcher itself never touches the GPU"""
+    import subprocess
+    out = subprocess.run([sys.executable, "-c", "import torch; print(torch.cuda.device_count())"],
+                         capture_output=True, text=True, timeout=600)
+    try:
+        return int(out.stdout.strip().splitlines()[-1])
+    except (ValueError, IndexError):
+        raise RuntimeError(f"could not count the GPUs: {out.stderr[-300:]}")
+
+
+def launch_ranks(n, argv):
+    """`bench.py --gpus N` without a launcher's environment: N child processes of this script, one rank per GPU, rendezvous on
+    127.0.0.1 (the same environment `python -m torch.distributed.run --nnodes=1 --nproc-per-node N` would set).  The
+    parent makes no GPU call and loads neither torch nor the library; it relays rank 0's line (the children share its
+    stdout, the other ranks print nothing there) and exits with the first non-zero status of a rank, after ending the
+    others.  ZKHIP_BENCH_BACKEND=gloo lets the ranks share fewer GPUs than ranks (a rehearsal of the multi-rank path)."""
+    import signal
+    import socket
+    import subprocess
+    backend = os.environ.get("ZKHIP_BENCH_BACKEND", "nccl")
+    if backend == "nccl":
+        have = visible_devices()
+        if n > have:
+            print(f"bench.py: --gpus {n} but {have} GPU(s) are visible; one rank per GPU over RCCL needs {n} "
+                  f"(ZKHIP_BENCH_BACKEND=gloo rehearses the multi-rank path on fewer)", file=sys.stderr)
+            return 2
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), ZKHIP_BENCH_SELF_LAUNCHED="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, "-u", os.path.abspath(__file__)] + list(argv), env=env,
+                                      stdout=None if r == 0 else sys.stderr))
+    deadline = time.monotonic() + LAUNCH_LIMIT_SECONDS
+    status = 0
+    live = list(procs)
+    while live and not status:
+        time.sleep(0.2)
+        for p in list(live):
+            rc = p.poll()
+            if rc is None:
+                continue
+            live.remove(p)
+            if rc != 0:
+                status = rc if rc > 0 else 128 - rc
+                print(f"bench.py: rank {procs.index(p)} ended with status {rc}", file=sys.stderr)
+        if time.monotonic() > deadline and live:
+            status = 124
+            print(f"bench.py: ranks still running after {LAUNCH_LIMIT_SECONDS} s", file=sys.stderr)
+    for p in live:                                  # a rank failed or the limit passed: end the others, by their own PIDs
+        p.send_signal(signal.SIGTERM)
+    for p in live:
+        try:
+            p.wait(timeout=20)
+        except subprocess.TimeoutExpired:
+            p.kill()
+            p.wait()
+    return status
+
+
+if __name__ == "__main__" and "WORLD_SIZE" not in os.environ and requested_gpus(sys.argv[1:]) > 1:
+    sys.exit(launch_ranks(requested_gpus(sys.argv[1:]), sys.argv[1:]))
+
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
@@ -193,6 +270,11 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        # --gpus N > 1 without a launcher's environment never gets here (launch_ranks above); what is left is a launcher
+        # whose world size contradicts the flag
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
+        sys.exit(2)
     # the replay is a child process with 166 GB of columns of its own: it runs before this process touches the GPU
     replay = None
     if not args.skip_extras and not args.skip_replay and world == 1:
@@ -204,12 +286,18 @@ def main():
     backend = os.environ.get("ZKHIP_BENCH_BACKEND", "nccl")
     device_index = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
     torch.cuda.set_device(device_index)
+    ranks_seen = None
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if backend == "nccl":
+            if local_rank >= torch.cuda.device_count():
+                print(f"bench.py: rank {rank} has no GPU of its own ({torch.cuda.device_count()} visible)", file=sys.stderr)
+                sys.exit(2)
             dist.init_process_group("nccl", device_id=torch.device("cuda", device_index))
         else:
             dist.init_process_group(backend)
+        world = dist.get_world_size()                 # what the line reports is what the process group holds
+        ranks_seen = gather_rank_ids(rank, device_index)
 
     ctx = zk.Context(device_index)
     stream = torch.cuda.Stream()
@@ -296,6 +384,16 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed, msm_ms, ntt_ms = (float(x) for x in t.cpu())
 
+    # ---- extra measurements outside the timed steps (rank-local) ---------------------------------------
+    extra = {"ranks_seen": ranks_seen,
+             "launcher": "self" if os.environ.get("ZKHIP_BENCH_SELF_LAUNCHED") else ("external" if world > 1 else None),
+             "backend": backend if world > 1 else None,
+             "preheat": {"steps": preheat_steps, "seconds": PREHEAT_SECONDS,
+                         "what": "untimed steps before the warm-up steps, until the chip holds its steady clocks"},
+             "cold_start": {"ms_per_step": cold_ms, "steps": cold_n,
+                            "what": "the same step timed right after set-up (one step run before), before the preheat: the chip "
+                                    "has not reached its steady clocks yet"},
+             "msm_phases_us": extra_phases}
     # With several ranks some extras below are collective (split evaluate_h, sharded proof, split MSM): a rank that fails or
     # hangs inside one would leave the others waiting until the collective library aborts the job, and the measured line
     # would be lost with it.  Every rank therefore arms a timer: when it fires, rank 0 prints the line of the timed steps
@@ -306,22 +404,18 @@ def main():
             try:
                 if rank == 0:
                     finish(args, ctx, dist, world, rank, device_index, bid, scalars, n, en, elapsed, msm_ms, ntt_ms, acc_us,
-                           acc_launches, ntt_us, {"extras": f"abandoned after {EXTRAS_LIMIT_SECONDS} s: a rank failed or hung in a "
-                                                  "multi-rank extra measurement; the timed steps are complete"}, None, minimal=True)
+                           acc_launches, ntt_us, dict(extra, extras=f"abandoned after {EXTRAS_LIMIT_SECONDS} s: a rank failed or hung in "
+                                                       "a multi-rank extra measurement; the timed steps are complete; exit status 3"),
+                           None, minimal=True)
                     sys.stdout.flush()
+                else:
+                    time.sleep(5)                     # rank 0 gets its line out before the launcher sees a rank end
             finally:
-                os._exit(0)
+                os._exit(3)                           # a hung job is a failed job: the partial line is out, the status says so
         watchdog = threading.Timer(EXTRAS_LIMIT_SECONDS, abandon_extras)
         watchdog.daemon = True
         watchdog.start()
 
-    # ---- extra measurements outside the timed steps (rank-local) ---------------------------------------
-    extra = {"preheat": {"steps": preheat_steps, "seconds": PREHEAT_SECONDS,
-                         "what": "untimed steps before the warm-up steps, until the chip holds its steady clocks"},
-             "cold_start": {"ms_per_step": cold_ms, "steps": cold_n,
-                            "what": "the same step timed right after set-up (one step run before), before the preheat: the chip "
-                                    "has not reached its steady clocks yet"},
-             "msm_phases_us": extra_phases}
     if not args.skip_extras:
         measure_extras(ctx, dom, bid, stream, gen, n, en, extra)
     evalh = None
@@ -343,6 +437,15 @@ def main():
         extra["replay_supercircuit_shape"] = replay
     finish(args, ctx, dist, world, rank, device_index, bid, scalars, n, en, elapsed, msm_ms, ntt_ms, acc_us, acc_launches, ntt_us,
            extra, evalh, watchdog=watchdog)
+
+
+def gather_rank_ids(rank, device_index):
+    """[{rank, device, pci_bus}] of every rank, gathered over the process group (device tensors: RCCL moves nothing else)"""
+    props = torch.cuda.get_device_properties(device_index)
+    mine = torch.tensor([rank, device_index, int(getattr(props, "pci_bus_id", -1)), os.getpid()], dtype=torch.int64, device="cuda")
+    got = [torch.empty_like(mine) for _ in range(dist.get_world_size())]
+    dist.all_gather(got, mine)
+    return [dict(zip(("rank", "device", "pci_bus", "pid"), (int(v) for v in g.cpu()))) for g in got]
 
 
 def measure_create_proof(ctx, bid, dist_=None):

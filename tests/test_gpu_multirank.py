@@ -214,11 +214,12 @@ def _prover_worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 4])
+@pytest.mark.parametrize("world", [2, 3, 4])
 def test_ranks_create_the_same_proof_as_one(world):
     """create_proof with the commitments column-sharded and the quotient numerator coset-sharded: the bytes equal the
     single-rank proof and pass the verifier model.  Two ranks: extended domains 4n and 8n, whole cosets per rank.  Four
-    ranks: 4n (one coset each) and 2n (two ranks share a coset by row ranges).  Each rank's peak of resident column data
+    ranks: 4n (one coset each) and 2n (two ranks share a coset by row ranges).  Three ranks: the third owns no coset, keeps
+    no extended vector (key generation included) and only joins the collectives.  Each rank's peak of resident column data
     (key generation + proof) shrinks with the share of the extended domain it holds."""
     mpctx = mp.get_context("spawn")
     q = mpctx.Queue()
@@ -237,7 +238,8 @@ def test_ranks_create_the_same_proof_as_one(world):
     assert all(p.exitcode == 0 for p in procs)
     assert [r[0] for r in results] == [True, True], [r[4] for r in results]
     for ok, peak_sharded, peak_whole, e, _ in results:
-        share = max(1.0 / world, 1.0 / (1 << e))          # the part of the extended domain one rank holds
+        owners = 1 << (world.bit_length() - 1)             # the largest power of two within the world size
+        share = max(1.0 / owners, 1.0 / (1 << e))         # the part of the extended domain rank 0 holds
         # the 2^k-sized polynomials (coefficient and Lagrange forms) stay whole on every rank: they come on top of the
         # rank's share of the extended vectors, and weigh most where the extended domain is only 2n
         assert peak_sharded < peak_whole, (peak_sharded, peak_whole, share)

@@ -279,3 +279,66 @@ def test_rng_batched_draws_equal_single_draws():
     assert b.fr_many(7) + [b.fr()] + b.fr_many(32) == seq
     assert a.fr() == b.fr()
     assert len(prover.OsFieldRng().fr_many(5)) == 5 and all(0 <= v < prover.P for v in prover.OsFieldRng().fr_many(5))
+
+
+def test_keygen_polys_of_a_rank_without_cosets_makes_no_empty_device_call():
+    """world sizes that are no power of two leave ranks that own no coset (`sharding.coset_partition`): their key keeps
+    the 2^k-sized forms and no extended vector, and never asks the device for a zero-sized block or an empty coset list
+    (which the library rejects -- on that rank alone, while the owners wait in the next collective)."""
+    import numpy as np
+    from zkevm_circuits_amd import keygen, sharding
+
+    parts = sharding.coset_partition(12, 10, 3)
+    assert parts[2] is None and parts[0] is not None and parts[1] is not None
+
+    class FakeCtx:
+        def __init__(self):
+            self.next, self.live = 0x1000, {}
+
+        def alloc(self, nbytes):
+            assert nbytes > 0, "zero-sized device block requested"
+            self.next += 0x100000
+            self.live[self.next] = nbytes
+            return self.next
+
+        def upload(self, arr, dptr=None):
+            return dptr if dptr is not None else self.alloc(np.asarray(arr).nbytes)
+
+        def free(self, p):
+            assert p in self.live, "freed a block that was never allocated"
+            del self.live[p]
+
+        def sync(self):
+            pass
+
+        def poly_lincomb_dev(self, *a):
+            pass
+
+    class FakeDom:
+        n, extended_len = 1 << 10, 1 << 12
+
+        def lagrange_to_coeff_dev(self, *a):
+            pass
+
+        def permutation_sigma_dev(self, *a):
+            pass
+
+        def coeff_to_extended_dev(self, *a):
+            raise AssertionError("a sharded key never forms a whole extended vector")
+
+        def coeff_to_cosets_dev(self, d_poly, cosets, d_out):
+            assert len(cosets) > 0, "empty coset list sent to the device"
+
+    n = FakeDom.n
+    fixed = [np.zeros((n, 4), dtype=np.uint64) for _ in range(2)]
+    for cosets in ([], [1, 3]):
+        ctx = FakeCtx()
+        asm = keygen.Assembly(n, 2)
+        pk = keygen.keygen_polys(ctx, FakeDom(), fixed, asm, 5, cosets)
+        assert pk.cosets == cosets
+        if not cosets:
+            assert pk.fixed_cosets == [0, 0] and pk.permutation_cosets == [0, 0] and (pk.l0, pk.l_last, pk.l_active_row) == (0, 0, 0)
+        assert 0 not in pk.pointers() and sorted(pk.pointers()) == sorted(ctx.live)
+        for p in pk.pointers():
+            ctx.free(p)
+        assert not ctx.live

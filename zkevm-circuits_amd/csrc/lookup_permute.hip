@@ -437,8 +437,8 @@ constexpr uint32_t LP_MAX_BATCH = 64;   // lookups per sequence of launches (abo
 
 static size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 
-// one chunk of at most LP_MAX_BATCH lookups
-static int lookup_permute_chunk(zkhip_ctx* ctx, uint32_t m, uint32_t count, const uint64_t* const* d_inputs,
+// one chunk of at most LP_MAX_BATCH lookups; `first` = index of the chunk's first lookup in the caller's batch (for messages)
+static int lookup_permute_chunk(zkhip_ctx* ctx, uint32_t first, uint32_t m, uint32_t count, const uint64_t* const* d_inputs,
                                 const uint64_t* const* d_tables, uint64_t* const* d_out_a, uint64_t* const* d_out_s) {
     hipStream_t st = ctx->stream;
     const uint32_t segs = 2 * count, ntiles = (m + RS_TILE - 1) / RS_TILE;
@@ -531,7 +531,8 @@ static int lookup_permute_chunk(zkhip_ctx* ctx, uint32_t m, uint32_t count, cons
     ZK_CHECK(ctx, !h_status[0], "lookup_permute: internal error, a column is not sorted after the exact sort");
     for (uint32_t l = 0; l < count; l++)
         if (h_status[1 + l])
-            return set_error(ctx, ZKHIP_ERR_CONSTRAINT, "lookup_permute: an input value of lookup %u does not occur in its table", l);
+            return set_error(ctx, ZKHIP_ERR_CONSTRAINT, "lookup_permute: an input value of lookup %u does not occur in its table",
+                             first + l);
     return ZKHIP_OK;
 }
 
@@ -555,7 +556,7 @@ extern "C" int zkhip_lookup_permute_batch_dev(zkhip_domain* dom, uint32_t count,
     TimedRegion tr(ctx, "lookup_permute");
     for (uint32_t first = 0; first < count; first += LP_MAX_BATCH) {
         const uint32_t c = std::min(LP_MAX_BATCH, count - first);
-        int rc = lookup_permute_chunk(ctx, usable_rows, c, d_compressed_inputs + first, d_compressed_tables + first,
+        int rc = lookup_permute_chunk(ctx, first, usable_rows, c, d_compressed_inputs + first, d_compressed_tables + first,
                                       d_permuted_inputs + first, d_permuted_tables + first);
         if (rc) return rc;
     }

@@ -790,7 +790,9 @@ static uint32_t env_u32(const char* name, uint32_t dflt) {
     return v && *v ? (uint32_t)atoi(v) : dflt;
 }
 // experiments: force the slot length (0 = planned per MSM) / items folded per lane in a merge pre-level
-static const uint32_t FORCE_L = env_u32("ZKHIP_SLOT_L", 0);
+// a forced slot length (measurements only) of 1 is raised to 2: the kernels divide by the slot length with a 32-bit
+// reciprocal, (2^32 + D - 1) / D, which does not fit for D = 1
+static const uint32_t FORCE_L = env_u32("ZKHIP_SLOT_L", 0) == 1 ? 2 : env_u32("ZKHIP_SLOT_L", 0);
 
 // Buffers of one in-flight MSM.  A workspace is bound to a stream; several workspaces let the latency-bound tail of
 // one MSM (merge, reduce, host fold) overlap the accumulate phase of the next.
@@ -1312,6 +1314,12 @@ static int msm_pipeline(zkhip_ctx* ctx, MsmState& stt, const MsmTables& tb, cons
     for (int i = 0; i < MsmState::N_STREAMS; i++) ZK_HIP(ctx, hipStreamWaitEvent(stt.batch_streams[i], stt.ev_in, 0));
     // software pipeline: phase1(j), phase2(j - 1), phase3(j - 1 - MSM_TAIL_LAG)
     int rc;
+    // a failed step leaves work of earlier members queued on the batch's streams: it is waited for before the error
+    // goes back, so that the caller may free the columns and the context's stream never runs beside leftovers
+    auto drained = [&](int status) {
+        for (int i = 0; i < MsmState::N_STREAMS; i++) (void)hipStreamSynchronize(stt.batch_streams[i]);
+        return status;
+    };
     const size_t lag3 = 1 + lag;
     for (size_t j = 0; j < batch + lag3; j++) {
         if (j < batch) {
@@ -1324,15 +1332,15 @@ static int msm_pipeline(zkhip_ctx* ctx, MsmState& stt, const MsmTables& tb, cons
                 TimedRegion tr(ctx, timed ? "msm_accumulate" : nullptr, ws.acc());
                 rc = msm_accumulate(ctx, ws, tb);
             }
-            if (rc) return rc;
+            if (rc) return drained(rc);
         }
         if (j >= 1 && j - 1 < batch) {
             rc = msm_phase2(ctx, *pipe[(j - 1) % depth], tb, timed);
-            if (rc) return rc;
+            if (rc) return drained(rc);
         }
         if (j >= lag3 && j - lag3 < batch) {
             rc = msm_phase3(ctx, *pipe[(j - lag3) % depth], out + 12 * (j - lag3));
-            if (rc) return rc;
+            if (rc) return drained(rc);
         }
     }
     for (int i = 0; i < MsmState::N_STREAMS; i++) {

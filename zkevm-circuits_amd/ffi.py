@@ -161,6 +161,7 @@ class Context:
         # internal streams join it at the end of each call; overlapped uploads start behind it).
         self._pool = {}
         self._pooled_bytes = 0
+        self._upload_window = False       # overlapped copies issued since the last fence
 
     POOL_CAP_BYTES = 4 << 30
 
@@ -217,6 +218,11 @@ class Context:
         return addr
 
     def free(self, dptr: int):
+        if self._upload_window:
+            # Copies on the transfer stream are ordered behind the compute stream only at the first copy after a fence.  A
+            # block freed now may be handed out again and become the target of a later copy of the same window, which
+            # would not wait for the kernels that still read the block: the window is closed first.
+            self.upload_fence()
         size = self._sizes.pop(dptr, None)
         if size is None:                              # not one of alloc()'s blocks
             self._ck(self._l.zkhip_dev_free(self.h, C.c_void_p(dptr)))
@@ -229,11 +235,13 @@ class Context:
             self._ck(self._l.zkhip_dev_free(self.h, C.c_void_p(dptr)))
 
     def mem_info(self):
-        """(free, total) bytes of device memory; blocks waiting in the pool count as free (alloc gives them back to the
-        device when a request needs the room)"""
+        """(free, total) bytes of device memory.  Blocks waiting in the pool (at most POOL_CAP_BYTES) are NOT counted as
+        free: `alloc` returns them to the device when one of its own requests needs the room, but the library's internal
+        buffers (transform scratch, MSM workspaces, the evaluate_h program) are allocated past the pool, so a caller that
+        sizes its working set from this figure must not be promised the pooled bytes."""
         free, total = C.c_size_t(), C.c_size_t()
         self._ck(self._l.zkhip_mem_info(self.h, C.byref(free), C.byref(total)))
-        return free.value + self._pooled_bytes, total.value
+        return free.value, total.value
 
     def reset_peak(self):
         self.peak_allocated_bytes = self.allocated_bytes
@@ -273,10 +281,12 @@ class Context:
         if arr.dtype != np.uint64 or not arr.flags.c_contiguous or not self.is_pinned(arr):
             raise ValueError("upload_overlapped takes a contiguous uint64 array in page-locked memory (host_zeros)")
         self._ck(self._l.zkhip_upload_overlapped(self.h, C.c_void_p(dptr), _p(arr), C.c_size_t(arr.nbytes)))
+        self._upload_window = True
 
     def upload_fence(self):
         """the calls that follow see every overlapped copy issued so far"""
         self._ck(self._l.zkhip_upload_fence(self.h))
+        self._upload_window = False
 
     def host_zeros(self, shape) -> np.ndarray:
         """a zeroed uint64 array in page-locked host memory (freed with the context): witness columns built in such

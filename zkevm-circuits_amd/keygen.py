@@ -67,20 +67,27 @@ class ProvingKeyPolys:
         self.cosets = None     # None: the "coset" vectors are whole extended vectors; a list: compact layout of these cosets
 
     def pointers(self):
-        return (self.fixed_polys + self.fixed_cosets + self.permutations + self.permutation_polys + self.permutation_cosets
-                + [self.l0, self.l_last, self.l_active_row])
+        """every device block the key owns (a rank that evaluates no coset holds no extended vectors: those entries are 0)"""
+        every = (self.fixed_polys + self.fixed_cosets + self.permutations + self.permutation_polys + self.permutation_cosets
+                 + [self.l0, self.l_last, self.l_active_row])
+        return [p for p in every if p]
 
 
 def keygen_polys(ctx, dom, fixed_values, assembly: Assembly | None, blinding_factors: int, cosets=None) -> ProvingKeyPolys:
     """fixed_values: list of (n, 4) Montgomery arrays (Lagrange basis).  Returns device-resident key polynomials; the
     caller frees `pointers()`.  cosets: a rank of a multi-GPU prover that evaluates only these cosets of the extended
     domain keeps the key's extended vectors (fixed_cosets, permutation_cosets, l0, l_last, l_active_row) in the compact
-    layout of those cosets -- n * len(cosets) rows, straight from the coefficients, never forming the whole vector."""
+    layout of those cosets -- n * len(cosets) rows, straight from the coefficients, never forming the whole vector; an
+    empty list (a rank that owns no coset) leaves those entries 0."""
     n, en = dom.n, dom.extended_len
     pk = ProvingKeyPolys()
     pk.cosets = list(cosets) if cosets is not None else None
 
     def extend(d_poly):
+        if pk.cosets is not None and not pk.cosets:
+            # a rank beyond the owners of the partition (world sizes that are no power of two) evaluates no row of the
+            # quotient: it keeps the 2^k-sized forms, which the replicated phases read, and no extended vector at all
+            return 0
         if pk.cosets is None:
             d_coset = ctx.alloc(en * 32)
             dom.coeff_to_extended_dev(d_poly, d_coset)

@@ -314,12 +314,16 @@ def save_proving_key(ctx, dom, pk: ProvingKey, path: str, layout: str = "v3") ->
     formats.write_proving_key_raw(path, raw, layout)
 
 
-def load_proving_key(ctx, dom, cs: ConstraintSystem, path: str) -> ProvingKey:
+def load_proving_key(ctx, dom, cs: ConstraintSystem, path: str, num_selectors: int = 0) -> ProvingKey:
     """`ProvingKey::read::<_, Circuit>(_, SerdeFormat::RawBytes)` (/root/reference/zkevm-circuits/benches/benchmark_list/main.rs:
     486-501): as upstream, the constraint system comes from the circuit (`cs`), the file supplies commitments and
-    polynomials, which are uploaded as they are.  The result proves like a key from `keygen`."""
+    polynomials, which are uploaded as they are.  The result proves like a key from `keygen`.
+    num_selectors: the circuit's selector count.  A key written upstream carries that many packed selector bit vectors
+    after the permutation commitments (the constraint system here has its selectors as fixed columns already, so it cannot
+    say how many the circuit declared); `save_proving_key` writes none.  Reading keys the reference wrote is unpinned:
+    the container layouts restate published halo2 and no such file exists to check them against."""
     from . import formats
-    raw = formats.read_proving_key_raw(path, len(cs.permutation_columns))
+    raw = formats.read_proving_key_raw(path, len(cs.permutation_columns), num_selectors)
     if raw.vk.k != dom.k:
         raise ValueError(f"the key is for k = {raw.vk.k}, the domain has k = {dom.k}")
     raw.check(dom.extended_k)
