@@ -215,6 +215,33 @@ def cpu_baseline(steps_hint):
             "evaluate_h_s_at_2p21_rows_extrapolated": t_evalh * (1 << LOG_EXT) / en_e}
 
 
+def ntt_product_count(k, log_ext):
+    """Field products `ntt_tile_kernel` executes for one coeff_to_extended 2^k -> 2^log_ext, as csrc/ntt.hip runs it:
+    passes of radix 2^r (the fewest passes of radix <= 2^8, as even as possible); in a pass the butterflies of stage 0
+    have the twiddle 1 and take no product, half of stage 1's likewise; the first log_ext - k stages of the first pass
+    see a zero partner (the padding is never materialised) and are copies; every pass but the last multiplies each
+    element once more on store (the twiddle the next pass would apply on load, one lookup in a data-sized table); two
+    thirds of the inputs take the zeta^(i mod 3) scaling."""
+    en = 1 << log_ext
+    npass = (log_ext + 7) // 8
+    left, radices = log_ext, []
+    for p in range(npass):
+        r = (left + (npass - p) - 1) // (npass - p)
+        radices.append(r)
+        left -= r
+    butterflies = 0.0
+    for p, r in enumerate(radices):
+        zskip = min(log_ext - k, r) if p == 0 else 0
+        for s in range(r):
+            if s < zskip:
+                continue
+            butterflies += (en / 2) * (0.0 if s == 0 else 0.5 if s == 1 else 1.0)
+    boundary = (npass - 1) * float(en)
+    scaling = 2.0 * (1 << k) / 3
+    return {"radices": radices, "butterfly": butterflies, "boundary": boundary, "zeta_scaling": scaling,
+            "total": butterflies + boundary + scaling}
+
+
 def bench_cs():
     return synthetic.synthetic_cs(num_advice=64, num_fixed=16, num_instance=1, num_gate_polys=256, max_degree=5,
                                   rotations=(-2, -1, 0, 1), num_lookups=16, lookup_width=3, num_perm_cols=8)
@@ -627,7 +654,17 @@ def measure_evalh(ctx, dom, stream, gen, evalh_k):
     bytes_alg = 32.0 * kdom.extended_len * (c_read + 1)
     prog = ctx.evaluate_h_last_stats()
     mads = prog["multiplications"] * MADS_PER_MUL * float(kdom.extended_len)
-    return {"program": prog, "valu_mads": mads, "valu_frac": mads / (k_us * 1e-6) / VALU_MAD_PEAK if k_us else 0.0,"k": evalh_k, "extended_k": kdom.extended_k, "seconds": ev_s, "algorithmic_GB": bytes_alg / 1e9,
+    counters = None
+    e = (load_profile_json("r03_pmc_valu.json") or {}).get("kernels", {}).get("evalh_interp_kernel")
+    if e and evalh_k == K:                       # the profiled run (tools/evalh_bench.py) is this configuration at k = 19
+        insts = e["counters_per_launch"].get("SQ_INSTS_VALU")
+        counters = {"file": "profiles/r03_pmc_valu.json", "avg_us_in_that_run": e["avg_us"], "SQ_INSTS_VALU_per_launch": insts,
+                    "valu_issue_frac": e["valu_issue_frac"],
+                    "multiply_add_share_of_valu_insts": mads / (insts * 64.0) if insts else None,
+                    "mad_frac_from_counters": mads / (e["avg_us"] * 1e-6) / VALU_MAD_PEAK,
+                    "hbm_bytes_per_launch": e.get("hbm_bytes_per_launch")}
+    return {"program": prog, "valu_mads": mads, "valu_frac": mads / (k_us * 1e-6) / VALU_MAD_PEAK if k_us else 0.0, "counters": counters,
+            "traffic": e.get("hbm_bytes_per_launch") if e and evalh_k == K else None, "k": evalh_k, "extended_k": kdom.extended_k, "seconds": ev_s, "algorithmic_GB": bytes_alg / 1e9,
             "GBps": bytes_alg / ev_s / 1e9, "frac_of_hbm_peak": bytes_alg / ev_s / 1e9 / HBM_PEAK,
             "calculations": n_calc, "kernel_ms": k_us / 1e3, "columns_read": c_read}
 
@@ -698,7 +735,8 @@ def finish(args, ctx, dist, world, rank, local_rank, bid, scalars, n, en, elapse
         ms_per_step = elapsed * 1e3 / args.steps
         msm_mpts = world * n / (msm_ms * 1e-3) / 1e6
         ntt_bytes = 32.0 * (n + en)
-        ntt_mads = (en / 2 * LOG_EXT + 2 * en * 2 + 2 * n / 3) * MADS_PER_MUL
+        ntt_products = ntt_product_count(K, LOG_EXT)
+        ntt_mads = ntt_products["total"] * MADS_PER_MUL
         W = 16
         adds = float(n) * W                                    # mixed additions of one accumulate launch
         alg_mads, own_mads = adds * ALG_MADS_PER_MADD, adds * MADS_PER_MADD
@@ -711,6 +749,25 @@ def finish(args, ctx, dist, world, rank, local_rank, bid, scalars, n, en, elapse
             mad_peak_measured = max(r["t_lane_ops_per_s"] for r in rows) * 1e12 if rows else None
         pmc = load_profile_json("pmc_traffic.json") or {}      # tools/collect_pmc.sh + tools/pmc_to_json.py (profiles/)
         acc_pmc, ntt_pmc = pmc.get("accumulate_kernel"), pmc.get("ntt_tile_kernel")
+        # instruction counters of the same kernels (tools/collect_pmc_valu.sh + tools/pmc_valu_to_json.py): an earlier
+        # profiling run of this command on another box, so each entry carries the duration of ITS run; the fractions
+        # quoted from it are counter / that duration / peak, the live fractions use this run's own durations
+        valu_pmc = (load_profile_json("r03_pmc_valu.json") or {}).get("kernels", {})
+
+        def counter_view(kernel, own_mads_per_launch):
+            e = valu_pmc.get(kernel)
+            if not e:
+                return None
+            insts = e["counters_per_launch"].get("SQ_INSTS_VALU")
+            out = {"file": "profiles/r03_pmc_valu.json", "avg_us_in_that_run": e["avg_us"], "SQ_INSTS_VALU_per_launch": insts,
+                   "valu_issue_frac": e["valu_issue_frac"],
+                   "valu_issue_frac_is": "SQ_INSTS_VALU / (1024 SIMDs x avg_us x 2.4 GHz / 4): share of the chip's quarter-rate "
+                                         "issue slots that held a vector instruction",
+                   "lds_bank_conflict_share_of_lds_cycles": e.get("lds_bank_conflict_share_of_lds_cycles")}
+            if insts and own_mads_per_launch:
+                out["multiply_add_share_of_valu_insts"] = own_mads_per_launch / (insts * 64.0)
+                out["mad_frac_from_counters"] = own_mads_per_launch / (e["avg_us"] * 1e-6) / VALU_MAD_PEAK
+            return out
         standin = extra.get("create_proof_k19") or {}
         replay = extra.get("replay_supercircuit_shape") or {}
         line = {
@@ -744,7 +801,8 @@ def finish(args, ctx, dist, world, rank, local_rank, bid, scalars, n, en, elapse
                          # HBM bytes per launch from separate rocprofv3 --pmc passes over this command's timed region
                          "traffic": acc_pmc["bytes_per_launch"] if acc_pmc else None,
                          "traffic_detail": acc_pmc,
-                         "algorithmic_bytes": adds * 64 + adds * 4},
+                         "algorithmic_bytes": adds * 64 + adds * 4,
+                         "counters": counter_view("accumulate_kernel", own_mads)},
             "roofline_ntt": {"bound": "hbm", "kernel": "ntt_tile_kernel (3 passes)", "achieved": ntt_bytes / (ntt_us * 1e-6) / 1e9 if ntt_us else 0.0,
                              "peak": HBM_PEAK, "unit": "GB/s", "frac": (ntt_bytes / (ntt_us * 1e-6) / 1e9 / HBM_PEAK) if ntt_us else 0.0,
                              "avg_launch_us": ntt_us,
@@ -753,7 +811,9 @@ def finish(args, ctx, dist, world, rank, local_rank, bid, scalars, n, en, elapse
                              "algorithmic_bytes": ntt_bytes,
                              # the transform is multiplier-bound, not HBM-bound: (M/2) log2 M butterfly products, two
                              # twiddle products per element between passes, the zeta scaling of 2/3 of the inputs
-                             "valu_mads": ntt_mads, "valu_frac": (ntt_mads / (ntt_us * 1e-6) / VALU_MAD_PEAK) if ntt_us else 0.0},
+                             "valu_mads": ntt_mads, "valu_frac": (ntt_mads / (ntt_us * 1e-6) / VALU_MAD_PEAK) if ntt_us else 0.0,
+                             "products": ntt_products,
+                             "counters": counter_view("ntt_tile_kernel", ntt_mads / len(ntt_products["radices"]))},
             "evaluate_h": evalh, "cpu_baseline": cpu, "msm_base_split_ok": split_ok,
         }
         line.update(extra)
