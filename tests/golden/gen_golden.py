@@ -73,6 +73,13 @@ def gen_reference_kats():
             {"source": "/root/reference/poseidon/src/hash.rs:921-950", "msg": ["1", "2", "3", "0"], "cap": "32",
              "expected": "066397f309d55f6caf6419cbb4120f5ada8e54254061b4b448359de388ab5526"},
         ],
+        # the whole state after one permutation of (0, 1, 2): all three lanes, where the hash KATs above pin lane 0 only
+        "poseidon_permutation_full_state": [
+            {"source": "/root/reference/poseidon/src/poseidon/septidon/tests.rs:58-61", "state": ["0", "1", "2"],
+             "expected": ["115cc0f5e7d690413df64c6b9662e9cf2a3617f2743245519e19607a4417189a",
+                          "0fca49b798923ab0239de1c9e7a4a9a2210312b6a2f616d18b5a87f9b628ae29",
+                          "0e7ae82e40091e63cbd4f16a6d16310b3729d4b6e138fcf54110e2867045a30c"]},
+        ],
         "fr_bytes": {
             "source": "/root/reference/zkevm-circuits/src/util.rs:832-882",
             "from_uniform_bytes_one_le64": "01" + "00" * 63,
@@ -92,6 +99,9 @@ def gen_reference_kats():
     for kat in out["poseidon_hash_msg"]:
         got = bn.poseidon_hash_msg([int(x, 16) for x in kat["msg"]], int(kat["cap"], 16))
         assert got == int(kat["expected"], 16), "poseidon msg KAT mismatch"
+    for kat in out["poseidon_permutation_full_state"]:
+        got = bn.poseidon_permute([int(x, 16) for x in kat["state"]])
+        assert got == [int(x, 16) for x in kat["expected"]], "poseidon full-state KAT mismatch"
     assert bn.Fr.from_uniform_bytes(bytes.fromhex(out["fr_bytes"]["from_uniform_bytes_one_le64"])) == 1
     mx = int.from_bytes(bytes.fromhex(out["fr_bytes"]["max_value_le32"]), "little")
     assert mx < P and bn.Fr.to_repr(mx) == bytes.fromhex(out["fr_bytes"]["max_value_le32"])

@@ -28,6 +28,36 @@ def test_library_exports_every_declared_symbol():
     assert b"gfx950" in lib.zkhip_version()
 
 
+def test_rust_sys_crate_declares_exactly_the_header():
+    """rust/zkhip-sys/src/lib.rs (source only: no Rust toolchain here) declares one `pub fn` per function of the header,
+    no more and no fewer, and its three #[repr(C)] structs list the header's fields in the header's order."""
+    rs = open(os.path.join(ROOT, "rust", "zkhip-sys", "src", "lib.rs")).read()
+    rs_names = sorted(set(re.findall(r"pub fn (zkhip_[a-z0-9_]+)\s*\(", rs)))
+    assert rs_names == declared_symbols()
+    shim = open(os.path.join(ROOT, "rust", "zkhip", "src", "lib.rs")).read()
+    used = set(re.findall(r"\b(zkhip_[a-z0-9_]+)\s*\(", shim))
+    assert used <= set(rs_names) and {"zkhip_msm", "zkhip_ntt", "zkhip_evaluate_h", "zkhip_coeff_to_extended"} <= used
+    header = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "zkhip.h")).read(), flags=re.S)
+
+    def c_fields(struct):
+        end = header.index("} " + struct + ";")
+        body = header[header.rindex("typedef struct {", 0, end) + len("typedef struct {"):end]
+        out = []
+        for decl in body.split(";"):
+            decl = decl.strip()
+            if not decl:
+                continue
+            for part in decl.split(","):
+                out.append(re.findall(r"([A-Za-z_0-9]+)\s*(?:\[\d+\])?\s*$", part.strip())[0])
+        return out
+
+    def rs_fields(struct):
+        body = re.search(r"pub struct " + struct + r" \{(.*?)\n\}", rs, flags=re.S).group(1)
+        return re.findall(r"pub ([a-z_0-9]+):", body)
+    for struct in ("zkhip_graph", "zkhip_lookup", "zkhip_evalh_desc"):
+        assert rs_fields(struct) == c_fields(struct), struct
+
+
 def test_struct_layout_matches_header():
     # sizes computed from the C declarations (LP64): catches a drifted ctypes mirror
     assert C.sizeof(ffi.Graph) == 48

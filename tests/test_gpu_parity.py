@@ -46,24 +46,31 @@ def test_lazy_arithmetic_matches_packed_on_the_device(ctx):
 
 
 def test_poseidon_kat_through_device_fr(ctx):
-    """The reference's Poseidon known answer (/root/reference/poseidon/src/hash.rs:903-918) recomputed with every
-    field operation running on the device."""
+    """The reference's Poseidon known answers recomputed with every field operation running on the device: the hash of
+    (1, 2) (/root/reference/poseidon/src/hash.rs:903-918, lane 0 of the permutation) and the whole state after one
+    permutation of (0, 1, 2) (/root/reference/poseidon/src/poseidon/septidon/tests.rs:58-61, all three lanes)."""
     k = golden("reference_kats.json")
     rounds = [[int(c, 16) for c in r] for r in k["poseidon_params"]["round_constants"]]
     mds = [[fr_arr([int(c, 16)]) for c in r] for r in k["poseidon_params"]["mds"]]
-    kat = k["poseidon_hash_with_domain"][0]
-    st = fr_arr([int(kat["domain"], 16)] + [int(x, 16) for x in kat["inputs"]])
     mul = lambda x, y: ctx.field_binop(0, 2, x, y)   # noqa: E731
     add = lambda x, y: ctx.field_binop(0, 0, x, y)   # noqa: E731
-    for rnd, rcs in enumerate(rounds):
-        st = add(st, fr_arr(rcs))
-        ns = 3 if (rnd < 4 or rnd >= 61) else 1
-        x = st[:ns]
-        x2 = mul(x, x)
-        st = np.concatenate([mul(mul(x2, x2), x), st[ns:]])
-        st = np.array([add(add(mul(mds[i][0], st[0:1]), mul(mds[i][1], st[1:2])), mul(mds[i][2], st[2:3]))[0]
-                       for i in range(3)], dtype=np.uint64)
-    assert fr_ints(st)[0] == int(kat["expected"], 16)
+
+    def permute(state):
+        st = fr_arr(state)
+        for rnd, rcs in enumerate(rounds):
+            st = add(st, fr_arr(rcs))
+            ns = 3 if (rnd < 4 or rnd >= 61) else 1
+            x = st[:ns]
+            x2 = mul(x, x)
+            st = np.concatenate([mul(mul(x2, x2), x), st[ns:]])
+            st = np.array([add(add(mul(mds[i][0], st[0:1]), mul(mds[i][1], st[1:2])), mul(mds[i][2], st[2:3]))[0]
+                           for i in range(3)], dtype=np.uint64)
+        return fr_ints(st)
+
+    kat = k["poseidon_hash_with_domain"][0]
+    assert permute([int(kat["domain"], 16)] + [int(x, 16) for x in kat["inputs"]])[0] == int(kat["expected"], 16)
+    for kat in k["poseidon_permutation_full_state"]:
+        assert permute([int(x, 16) for x in kat["state"]]) == [int(x, 16) for x in kat["expected"]]
 
 
 def test_timing_levels_bracket_the_named_stages_only(ctx, co):

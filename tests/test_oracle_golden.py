@@ -80,6 +80,11 @@ def test_poseidon_kats_from_reference(co):
         assert _poseidon_c(co, [dom, inp[0], inp[1]], rounds, mds)[0] == exp
     for kat in k["poseidon_hash_msg"]:
         assert bn.poseidon_hash_msg([int(x, 16) for x in kat["msg"]], int(kat["cap"], 16)) == int(kat["expected"], 16)
+    # all three lanes of one permutation (/root/reference/poseidon/src/poseidon/septidon/tests.rs:58-61)
+    for kat in k["poseidon_permutation_full_state"]:
+        st, exp = [int(x, 16) for x in kat["state"]], [int(x, 16) for x in kat["expected"]]
+        assert bn.poseidon_permute(st) == exp
+        assert _poseidon_c(co, st, rounds, mds) == exp
 
 
 def test_fr_byte_conventions(co):
