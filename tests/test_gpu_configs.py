@@ -52,6 +52,71 @@ def test_aggregation_size_msm_known_answer(ctx):
     ctx.release_bases(bid)
 
 
+def _weighted_sum_of_montgomery_limbs(sc):
+    """sum_i value_i * (i + 1) mod P for (n, 4) uint64 Montgomery limbs, vectorised: sixteen 16-bit chunks per element,
+    blocks of 2^20 rows (a block's chunk sum stays below 2^16 * 2^25 * 2^20 = 2^61), divided by R at the end"""
+    n = len(sc)
+    total = 0
+    step = 1 << 20
+    for b0 in range(0, n, step):
+        w = np.arange(b0 + 1, min(b0 + step, n) + 1, dtype=np.uint64)
+        blk = sc[b0:b0 + step]
+        for j in range(4):
+            for c in range(4):
+                chunk = (blk[:, j] >> np.uint64(16 * c)) & np.uint64(0xFFFF)
+                total += int(np.dot(chunk, w)) << (64 * j + 16 * c)
+    return total * pow(1 << 256, -1, P) % P
+
+
+@pytest.mark.parametrize("log_n", [24, 25])
+def test_aggregation_degree_msm_known_answer(ctx, log_n):
+    """2^24 and 2^25 bases (i+1)G -- the reference's standard aggregation degree is 25
+    (/root/reference/prover/src/constants.rs:33-36, /root/reference/aggregate-zkevm/src/main.rs:203,213) -- uniform and
+    witness-like scalars against one scalar multiplication.  At 2^25 the window tables of one base set take 32 GiB."""
+    n = 1 << log_n
+    rng = np.random.default_rng(log_n)
+    t0 = time.perf_counter()
+    bid = ctx.register_bases(ctx.g1_multiples(n))
+    t_reg = time.perf_counter() - t0
+    to_mont = lambda c: ctx.field_binop(0, 2, c, np.repeat(fr_arr([(1 << 256) % P]), len(c), axis=0))
+    for name in ("uniform", "witness"):
+        sc = rand_fr(rng, n) if name == "uniform" else witness_like(rng, n, to_mont)
+        k = _weighted_sum_of_montgomery_limbs(sc)
+        d_sc = ctx.upload(sc)
+        got = ctx.msm_range_dev(bid, 0, d_sc, n)
+        ctx.sync()
+        t0 = time.perf_counter()
+        got2 = ctx.msm_range_dev(bid, 0, d_sc, n)
+        ctx.sync()
+        dt = time.perf_counter() - t0
+        ctx.free(d_sc)
+        assert affine_pt(ctx.g1_to_affine(got)) == bn.g1_mul(bn.G1_GENERATOR, k), name
+        assert np.array_equal(ctx.g1_to_affine(got), ctx.g1_to_affine(got2))
+        print(f"2^{log_n} MSM, {name} scalars: {dt * 1e3:.2f} ms = {n / dt / 1e6:.0f} Mpts/s (tables built in {t_reg:.2f} s)")
+    ctx.release_bases(bid)
+
+
+def test_aggregation_degree_coset_extension_matches_oracle(ctx, co):
+    """2^24 -> 2^25 (quotient degree 2, the aggregation circuit's extension at k = 24): the whole output bit for bit against
+    the C oracle's coeff_to_extended, and extended_to_coeff back to the coefficients"""
+    k = 24
+    d, od = zk.Domain(ctx, 3, k), co.Domain(3, k, threads=16)
+    assert d.extended_k == 25
+    rng = np.random.default_rng(2425)
+    a = rand_fr(rng, d.n)
+    d_a, d_e = ctx.upload(a), ctx.alloc(d.extended_len * 32)
+    d.coeff_to_extended_dev(d_a, d_e)
+    ext = ctx.download(d_e, (d.extended_len, 4))
+    assert np.array_equal(ext, od.coeff_to_extended(a))
+    d_back = ctx.alloc(d.n * d.quotient_poly_degree * 32)
+    d.extended_to_coeff_dev(d_e, d_back)
+    back = ctx.download(d_back, (d.n * d.quotient_poly_degree, 4))
+    assert np.array_equal(back[:d.n], a) and not back[d.n:].any()
+    for p in (d_a, d_e, d_back):
+        ctx.free(p)
+    d.close()
+
+
 def test_aggregation_size_coset_extension(ctx, co):
     """2^22 -> 2^23 (quotient degree 2): sampled outputs against big-int Horner, inversion, linearity"""
     check_coset_extension_properties(ctx, co, 22, 3, 23)

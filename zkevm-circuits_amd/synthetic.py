@@ -9,6 +9,8 @@ permutation columns.
 """
 from __future__ import annotations
 
+import json
+import os
 import random
 
 import numpy as np
@@ -68,12 +70,19 @@ def synthetic_cs(num_advice=8, num_fixed=4, num_instance=1, num_gate_polys=16, m
     return cs
 
 
-def satisfied_cs(units, degree9=False, extra_gates=0):
+def satisfied_cs(units, degree9=False, extra_gates=0, lookup_copies=1, perm_units=None):
     """A constraint system that `satisfied_witness` satisfies, for proofs that a verifier can check: `units` copies side
     by side of five advice columns a, b, c, s, d with the gates q (a b - c), a challenge multiple of it,
     q_acc (s(+1) - s - c) and q_prev (d - a(-1) - b), one lookup of (q a, q b) in a fixed table of squares per unit, three
     permutation columns per unit plus the shared instance column; with degree9 one gate polynomial of degree nine
-    (extended domain 8n)."""
+    (extended domain 8n).
+    lookup_copies: how often a unit declares its lookup (an int, or one count per unit): halo2 does not merge equal lookup
+    arguments, so every copy costs the prover a compression, a sort, a grand product and three commitments -- the way to
+    give a stand-in the lookup count of a real circuit without more columns.  perm_units: only the first that many units
+    put their columns into the permutation argument (None: all), for circuits with few equality-enabled columns."""
+    copies = [lookup_copies] * units if isinstance(lookup_copies, int) else list(lookup_copies)
+    assert len(copies) == units
+    perm_units = units if perm_units is None else min(perm_units, units)
     q, q_acc, q_prev = Fixed(0), Fixed(1), Fixed(4)
     cs = ConstraintSystem(num_fixed_columns=5, num_advice_columns=5 * units, num_instance_columns=1, num_challenges=1)
     for u in range(units):
@@ -98,8 +107,10 @@ def satisfied_cs(units, degree9=False, extra_gates=0):
         cs.gates.append(polys)
         cs.gates.append([Product(q_acc, Sub(Sub(Advice(5 * u + 3, 1), s), c)),
                          Product(q_prev, Sub(Sub(d, Advice(5 * u, -1)), b))])
-        cs.lookups.append(Lookup([Product(q, a), Product(q, b)], [Fixed(2), Fixed(3)]))
-        cs.permutation_columns += [(ANY_ADVICE, 5 * u + 3), (ANY_ADVICE, 5 * u), (ANY_ADVICE, 5 * u + 2)]
+        for _ in range(copies[u]):
+            cs.lookups.append(Lookup([Product(q, a), Product(q, b)], [Fixed(2), Fixed(3)]))
+        if u < perm_units:
+            cs.permutation_columns += [(ANY_ADVICE, 5 * u + 3), (ANY_ADVICE, 5 * u), (ANY_ADVICE, 5 * u + 2)]
     cs.permutation_columns.append((ANY_INSTANCE, 0))
     return cs
 
@@ -114,7 +125,11 @@ def satisfied_witness(cs, n, seed, units, active_rows=500, as_arrays=False, zero
     advice, public = [], []
     from .keygen import Assembly
     asm = Assembly(n, len(cs.permutation_columns))       # argument columns: (s, a, c) per unit, then the instance
-    inst_col = 3 * units
+    perm_units = sum(1 for kind, _ in cs.permutation_columns[:3 * units] if kind == ANY_ADVICE) // 3
+    perm_units = min(perm_units, (len(cs.permutation_columns) - 1) // 3)
+    ic = next(i for i, (kind, _) in enumerate(cs.permutation_columns) if kind == ANY_INSTANCE)
+    perm_units = min(perm_units, ic // 3)
+    inst_col = 3 * perm_units
     for u in range(units):
         a = [int(v) for v in rng.integers(0, 11, size=m)] + [0] * (usable - m)
         a[0], a[3], a[7] = 2, 8, 3
@@ -127,6 +142,8 @@ def satisfied_witness(cs, n, seed, units, active_rows=500, as_arrays=False, zero
         s += [0] * (usable - len(s))
         d = [0] + [a[i - 1] + b[i] for i in range(1, m)] + [0] * (usable - m)
         advice += [a, b, c, s, d]
+        if u >= perm_units:
+            continue
         public += [5 + u, s[m]]
         asm.copy(3 * u, 0, inst_col, 2 * u)
         asm.copy(3 * u, m, inst_col, 2 * u + 1)
@@ -156,7 +173,7 @@ def satisfied_witness(cs, n, seed, units, active_rows=500, as_arrays=False, zero
 KECCAK_ROTATIONS = tuple(range(12)) + tuple(12 * (i + 1) for i in range(17)) + (-12,)
 
 
-def standin_cs(units=52, lanes=8, wide_lookups=8, lookup_width=10, extra_gates=0):
+def standin_cs(units=52, lanes=8, wide_lookups=8, lookup_width=10, extra_gates=0, lookup_copies=1, perm_units=None):
     """A satisfiable stand-in for the reference's SuperCircuit that carries its hard features together, on top of
     `satisfied_cs(units, degree9=True, extra_gates)`:
       * `lanes` keccak-like advice columns w, each queried at the 30 rotations of KECCAK_ROTATIONS (so that
@@ -168,7 +185,7 @@ def standin_cs(units=52, lanes=8, wide_lookups=8, lookup_width=10, extra_gates=0
         (/root/reference/zkevm-circuits/src/core_circuit.rs:153-154, /root/reference/zkevm-circuits/src/util.rs:63-67).
     Column order: the units' 5 * units advice columns, per lane (w, t, u), the table columns, per wide lookup its input
     columns, the two second-phase columns.  Fixed: the 5 of satisfied_cs, then q_k, q_w, q_2."""
-    cs = satisfied_cs(units, degree9=True, extra_gates=extra_gates)
+    cs = satisfied_cs(units, degree9=True, extra_gates=extra_gates, lookup_copies=lookup_copies, perm_units=perm_units)
     base_adv = cs.num_advice_columns
     q_k, q_w, q_2 = Fixed(5), Fixed(6), Fixed(7)
     cs.num_fixed_columns = 8
@@ -205,8 +222,54 @@ def standin_cs(units=52, lanes=8, wide_lookups=8, lookup_width=10, extra_gates=0
     cs.challenge_phase = [0, 0, 0]
     cs.permutation_columns += [(ANY_ADVICE, lane_cols[0][0])] if lanes else []
     cs.permutation_columns.append((ANY_ADVICE, r1))
-    cs._standin = dict(units=units, lanes=lane_cols, table=table_cols, wide=wide_inputs, second=(r1, r2), x=x)
+    cs._standin = dict(units=units, lanes=lane_cols, table=table_cols, wide=wide_inputs, second=(r1, r2), x=x,
+                       perm_units=units if perm_units is None else min(perm_units, units))
     return cs
+
+
+CENSUS_PATH = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "supercircuit_census.json")
+
+
+def supercircuit_shape(feature="standard"):
+    """(A, F, L, P, ..) of the reference's SuperCircuit from the committed static census of its sources
+    (tests/golden/supercircuit_census.json, written by tools/supercircuit_census.py with a file:line per counted call):
+    advice / lookup counts are the middle of the census bracket (the keccak circuit allocates its cell columns and their
+    lookups at run time), the permutation columns its equality-enabled sites plus the instance column and the Poseidon
+    chip's state columns, rotations from the execution gadgets' NUM_ROW and the keccak round layout."""
+    with open(CENSUS_PATH) as f:
+        c = json.load(f)
+    sh, ex = c["shape"][feature], c["execution_gadgets"]
+    mid = lambda pair: (pair[0] + pair[1]) // 2                                     # noqa: E731
+    return {"feature": feature, "advice": mid(sh["advice_with_keccak_cell_columns"]), "advice_second_phase": sh["advice_second_phase"],
+            "fixed": sh["fixed_counted"], "instance": sh["instance"], "lookups": mid(sh["lookups_with_keccak_cell_lookups"]),
+            "create_gate_calls": sh["gates_counted"], "permutation_columns": sh["enable_equality_sites"] + 1 + 10,
+            "degree": 9, "challenges": 3, "max_rotation": 204 if feature == "standard" else 1,
+            "min_rotation": -ex["max_NUM_ROW"], "widest_lookup": 10,
+            "source": "tests/golden/supercircuit_census.json (tools/supercircuit_census.py over the reference's Rust sources)"}
+
+
+def supercircuit_standin(feature="standard", extra_gates=None):
+    """`standin_cs` sized from `supercircuit_shape(feature)`: units, lookup copies and permutation units are solved so
+    that the advice, lookup and permutation column counts land on the census figures (within one unit's five columns).
+    Returns (constraint system, shape dictionary with both the census target and what the stand-in has)."""
+    shape = supercircuit_shape(feature)
+    standard = feature == "standard"
+    lanes = 8 if standard else 0
+    wide, width = (8, 10) if standard else (3, 8)
+    other = 3 * lanes + width + wide * width + 2
+    units = max(1, round((shape["advice"] - other) / 5))
+    unit_lookups = max(units, shape["lookups"] - wide)
+    copies = [unit_lookups // units + (1 if u < unit_lookups % units else 0) for u in range(units)]
+    perm_units = max(1, (shape["permutation_columns"] - 1 - (2 if lanes else 1)) // 3)
+    if extra_gates is None:
+        extra_gates = 38 if standard else 4
+    cs = standin_cs(units=units, lanes=lanes, wide_lookups=wide, lookup_width=width, extra_gates=extra_gates,
+                    lookup_copies=copies, perm_units=perm_units)
+    built = {"advice": cs.num_advice_columns, "fixed": cs.num_fixed_columns, "lookups": len(cs.lookups),
+             "permutation_columns": len(cs.permutation_columns), "gate_polynomials": sum(len(g) for g in cs.gates),
+             "degree": cs.degree(), "blinding_factors": cs.blinding_factors(), "challenges": cs.num_challenges,
+             "units": units, "lanes": lanes, "wide_lookups": wide, "lookup_width": width, "perm_units": perm_units}
+    return cs, {"census": shape, "standin": built}
 
 
 def standin_witness(cs, n, seed, active_rows=3000, zeros=None):
@@ -223,7 +286,8 @@ def standin_witness(cs, n, seed, active_rows=3000, zeros=None):
     usable = n - (cs.blinding_factors() + 1)
     m = min(usable - 210, active_rows)
     assert m > 300, "not enough rows for the +204 rotation"
-    base_cs = satisfied_cs(units, degree9=True)
+    perm_units = info.get("perm_units", units)
+    base_cs = satisfied_cs(units, degree9=True, perm_units=perm_units)
     base_cs_bf = cs.blinding_factors()
     # the units' columns: satisfied_witness sizes its rows from the constraint system's blinding factors, so hand it ours
     shim = ConstraintSystem()
@@ -262,9 +326,9 @@ def standin_witness(cs, n, seed, active_rows=3000, zeros=None):
     fixed.append([1] * m + [0] * (n - m))                                   # q_w
     fixed.append([1] * m + [0] * (n - m))                                   # q_2
     asm = Assembly(n, len(cs.permutation_columns))
-    inst_col = 3 * units
+    inst_col = 3 * perm_units
     public = instance[0]
-    for u in range(units):                                                  # the copy constraints of satisfied_witness
+    for u in range(perm_units):                                             # the copy constraints of satisfied_witness
         asm.copy(3 * u, 0, inst_col, 2 * u)
         asm.copy(3 * u, m, inst_col, 2 * u + 1)
         asm.copy(3 * u + 1, 1, 3 * u + 1, 4)
