@@ -477,15 +477,16 @@ def gather_rank_ids(rank, device_index):
 
 def measure_create_proof(ctx, bid, dist_=None):
     """One whole `create_proof` (zkevm_circuits_amd/prover.py) at k = 19 for the SuperCircuit STAND-IN of
-    `synthetic.standin_cs`: a satisfied circuit with the column counts estimated for the reference's SuperCircuit and its
-    hard features together -- 376 advice columns in two phases, three challenges, 60 lookups of which eight are ten columns
-    wide into advice tables, keccak-like rotations up to +204 (32 blinding factors), about 2200 gate polynomials of degree
-    up to nine (extended domain 2^22).  The SRS here is the benchmark's unstructured table, so this proof is timed, not
+    `synthetic.supercircuit_standin`: a satisfied circuit with the advice, lookup and permutation column counts that the
+    committed static census of the reference's sources gives for the SuperCircuit (tests/golden/supercircuit_census.json)
+    and its hard features together -- about 360 advice columns in two phases, three challenges, about 200 lookups of which
+    eight are ten columns wide into advice tables, keccak-like rotations up to +204 (32 blinding factors), about 2100 gate
+    polynomials of degree up to nine (extended domain 2^22).  The SRS here is the benchmark's unstructured table, so this proof is timed, not
     verified; tests/test_gpu_configs.py runs the same circuit over a structured SRS and verifies the bytes.  With several
     ranks the commitments are column-sharded and the quotient numerator coset-sharded; seconds = the slowest rank."""
     from zkevm_circuits_amd import prover
     k = K
-    cs = synthetic.standin_cs(units=52, lanes=8, wide_lookups=8, lookup_width=10, extra_gates=38)
+    cs, shape = synthetic.supercircuit_standin("standard")
     dom = zk.Domain(ctx, cs.degree(), k)
     params = prover.ParamsKZG.from_registered(ctx, dom, bid, bid)
     # the witness columns live in page-locked host memory (what the library asks of its caller): the upload is a DMA
@@ -519,7 +520,8 @@ def measure_create_proof(ctx, bid, dist_=None):
                       "lookups": len(cs.lookups), "widest_lookup": max(len(lk.input_expressions) for lk in cs.lookups),
                       "permutation_columns": len(cs.permutation_columns), "blinding_factors": cs.blinding_factors(),
                       "phases": len(cs.phases()), "challenges": cs.num_challenges,
-                      "gate_polynomials": sum(len(g) for g in cs.gates), "degree": cs.degree()},
+                      "gate_polynomials": sum(len(g) for g in cs.gates), "degree": cs.degree(),
+                      "census": shape["census"]},
             "note": "STAND-IN, not the SuperCircuit (which cannot be instantiated without the reference's Rust halo2 fork): wall "
                     "time of one proof (slowest rank) including the Python host side and the upload of the witness; with "
                     "several ranks only the commitments and the quotient numerator are sharded, the rest is replicated; timed "

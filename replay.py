@@ -16,9 +16,11 @@ columns, in upstream's phase order:
                     queries: rotation sets, quotient and linearisation polynomials, Kate divisions, two commitments
 
 Witness generation, transcript hashing and the RNG stay on the host in the reference and are not part of this number.
-The default shape is the estimate for the k = 19 SuperCircuit (standard feature set): about 380 advice and 60 fixed
-columns, one instance column, about 200 lookup arguments, 12 permutation columns, constraint degree 9 (extended
-domain 8n).  Prints one JSON line with per-phase seconds.
+The default shape is the k = 19 SuperCircuit's (standard feature set) as the committed static census of the reference's
+sources gives it (tests/golden/supercircuit_census.json via `synthetic.supercircuit_shape`: advice, fixed, lookup and
+permutation column counts, each with the file:line of the calls counted), constraint degree 9 (extended domain 8n); the
+number of gate polynomials (the census counts `create_gate` calls, not the polynomials each returns) stays an estimate.
+Prints one JSON line with per-phase seconds.
 """
 import argparse
 import json
@@ -62,12 +64,13 @@ class Phases:
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--k", type=int, default=19)
-    ap.add_argument("--advice", type=int, default=380)
-    ap.add_argument("--fixed", type=int, default=60)
-    ap.add_argument("--lookups", type=int, default=200)
+    census = synthetic.supercircuit_shape("standard")
+    ap.add_argument("--advice", type=int, default=census["advice"])
+    ap.add_argument("--fixed", type=int, default=census["fixed"])
+    ap.add_argument("--lookups", type=int, default=census["lookups"])
     ap.add_argument("--lookup-width", type=int, default=4)
-    ap.add_argument("--perm-cols", type=int, default=12)
-    ap.add_argument("--degree", type=int, default=9)
+    ap.add_argument("--perm-cols", type=int, default=census["permutation_columns"])
+    ap.add_argument("--degree", type=int, default=census["degree"])
     ap.add_argument("--gate-polys", type=int, default=3000)
     ap.add_argument("--reference-log", metavar="PATH",
                     help="also write the summary / Start / End lines the reference's benchmark prints "
@@ -299,7 +302,11 @@ def main():
                 "generation and transcript hashing are not included",
         "shape": {"k": k, "extended_k": ek, "advice": A, "fixed": F, "instance": I, "lookups": L,
                   "lookup_width": args.lookup_width, "permutation_columns": len(pcols), "permutation_sets": sets,
-                  "degree": d, "gate_polynomials": args.gate_polys},
+                  "degree": d, "gate_polynomials": args.gate_polys,
+                  "shape_source": "tests/golden/supercircuit_census.json (static census of the reference's sources, "
+                                  "tools/supercircuit_census.py) for every count left at its default; gate_polynomials is an "
+                                  "estimate (the census counts create_gate calls: "
+                                  f"{census['create_gate_calls']})"},
         "total_s": total, "phases_s": ph.t, "msm_count": n_msm, "msm_total_s": msm_s, "msm_ms_each": msm_s / n_msm * 1e3,
         "coset_ntt_count": A + I + 3 * L + sets, "evalh_kernel_ms": evalh_kernel_ms, "evalh_program": evalh_program, "eval_polynomial_count": n_queries,
         "shplonk": {"polynomials": len(shapes), "queries": n_queries, "poly_lincomb_calls": lincomb_n,

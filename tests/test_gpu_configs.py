@@ -172,19 +172,23 @@ def _prove_and_verify(ctx, co, k, cs, seed, active_rows, label):
 
 
 def test_fast_test_shape_proof_verifies(ctx, co):
-    """the fast_test SuperCircuit's shape (no keccak, no fixed-table circuit): k = 15, extended domain 2^18, 234 advice
-    columns in two phases, 43 lookups of which three are eight columns wide, three challenges"""
-    cs = synthetic.standin_cs(units=40, lanes=0, wide_lookups=3, lookup_width=8, extra_gates=4)
-    assert cs.degree() == 9 and cs.num_advice_columns == 234 and len(cs.lookups) == 43
+    """the fast_test SuperCircuit's shape as the static census of the reference's sources gives it (no keccak, no
+    fixed-table circuit; tests/golden/supercircuit_census.json): k = 15, extended domain 2^18, about 212 advice columns in two
+    phases, 92 lookups of which three are eight columns wide, three challenges"""
+    cs, shape = synthetic.supercircuit_standin("fast_test")
+    assert cs.degree() == 9 and abs(cs.num_advice_columns - shape["census"]["advice"]) <= 5
+    assert len(cs.lookups) == shape["census"]["lookups"]
     _prove_and_verify(ctx, co, 15, cs, 15, 2000, "fast_test shape")
 
 
 def test_supercircuit_standin_proof_verifies(ctx, co):
-    """k = 19, extended domain 2^22: 52 units + 8 keccak-like lanes (rotations 0..11, 12..204 in steps of 12, -12, hence 32
-    blinding factors and a last rotation of -33 in the permutation argument) + 8 ten-column lookups into advice tables +
-    two second-phase columns and three challenges, 2000 extra gate polynomials of degree up to nine"""
-    cs = synthetic.standin_cs(units=52, lanes=8, wide_lookups=8, lookup_width=10, extra_gates=38)
-    assert cs.degree() == 9 and cs.blinding_factors() == 32 and cs.num_advice_columns == 376 and len(cs.lookups) == 60
+    """k = 19, extended domain 2^22, the standard SuperCircuit's counts from the static census (about 360 advice columns, 199
+    lookups, a dozen permutation columns): units + 8 keccak-like lanes (rotations 0..11, 12..204 in steps of 12, -12, hence
+    32 blinding factors and a last rotation of -33 in the permutation argument) + 8 ten-column lookups into advice tables
+    + two second-phase columns and three challenges, about 1900 extra gate polynomials of degree up to nine"""
+    cs, shape = synthetic.supercircuit_standin("standard")
+    assert cs.degree() == 9 and cs.blinding_factors() == 32 and abs(cs.num_advice_columns - shape["census"]["advice"]) <= 5
+    assert len(cs.lookups) == shape["census"]["lookups"] and len(cs.permutation_columns) <= shape["census"]["permutation_columns"]
     assert sum(len(g) for g in cs.gates) > 2000
     _prove_and_verify(ctx, co, 19, cs, 19, 3000, "SuperCircuit stand-in")
 

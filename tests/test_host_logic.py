@@ -1,9 +1,13 @@
 """CPU suite, part 2: host logic — Expression -> GraphEvaluator lowering, ConstraintSystem quantities, the wire
 format, and the multi-GPU partition helpers."""
+import os
 import random
+import re
 
 import numpy as np
 import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 import bn254 as bn
 import halo2_model as hm
@@ -236,8 +240,10 @@ def test_standin_witness_satisfies_its_constraint_system():
     from zkevm_circuits_amd.synthetic import fr_from_limbs_rows
     k = 10
     n = 1 << k
-    cs = synthetic.standin_cs(units=3, lanes=2, wide_lookups=2, lookup_width=8, extra_gates=3)
+    # lookup copies and a permutation argument over the first two units only, as `supercircuit_standin` sizes them
+    cs = synthetic.standin_cs(units=3, lanes=2, wide_lookups=2, lookup_width=8, extra_gates=3, lookup_copies=[3, 2, 2], perm_units=2)
     assert cs.degree() == 9 and cs.blinding_factors() == 32 and cs.num_challenges == 3
+    assert len(cs.lookups) == 7 + 2 and len(cs.permutation_columns) == 3 * 2 + 1 + 2
     assert [len(c) for _, c, _ in cs.phases()] == [cs.num_advice_columns - 2, 2]
     rots = {r for g in cs.gates for p in g for (t, _, r) in _queries(p) if t == "advice"}
     assert {204, -12, 11} <= rots
@@ -342,3 +348,28 @@ def test_keygen_polys_of_a_rank_without_cosets_makes_no_empty_device_call():
         for p in pk.pointers():
             ctx.free(p)
         assert not ctx.live
+
+
+def test_supercircuit_census_is_current_and_sizes_the_standins():
+    """tests/golden/supercircuit_census.json is what tools/supercircuit_census.py writes from the reference's sources (read
+    as text; skipped where the reference tree is absent), and the stand-ins built from it land on its counts"""
+    import json
+    import subprocess
+    import sys
+    committed = json.load(open(os.path.join(ROOT, "tests", "golden", "supercircuit_census.json")))
+    if os.path.isdir("/root/reference/zkevm-circuits/src"):
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "supercircuit_census.py"), "/root/reference"],
+                             capture_output=True, text=True, check=True)
+        assert json.loads(out.stdout) == committed
+    assert committed["execution_gadgets"]["gadgets"] == 78
+    # every counted site carries its file:line
+    for sub in committed["subcircuits"].values():
+        assert all(re.fullmatch(r"[\w/.-]+\.rs:\d+", e["at"]) for e in sub["sites"])
+    for feature in ("standard", "fast_test"):
+        cs, shape = synthetic.supercircuit_standin(feature)
+        census = shape["census"]
+        assert abs(cs.num_advice_columns - census["advice"]) <= 5 and len(cs.lookups) == census["lookups"]
+        assert cs.degree() == census["degree"] and cs.num_challenges == census["challenges"]
+        assert len(cs.permutation_columns) <= census["permutation_columns"]
+    std = synthetic.supercircuit_shape("standard")
+    assert 340 <= std["advice"] <= 380 and 170 <= std["lookups"] <= 230 and std["max_rotation"] == 204
