@@ -141,6 +141,14 @@ int zkhip_lagrange_to_coeff_dev(zkhip_domain* dom, uint64_t* d_a, size_t batch);
 int zkhip_coeff_to_lagrange_dev(zkhip_domain* dom, uint64_t* d_a, size_t batch);
 int zkhip_coeff_to_extended_dev(zkhip_domain* dom, const uint64_t* d_coeff, uint64_t* d_out, size_t batch);
 int zkhip_extended_to_coeff_dev(zkhip_domain* dom, uint64_t* d_ext /* clobbered */, uint64_t* d_out, size_t batch);
+/* coeff_to_extended with the result split by the parity of the extended row: per member the 2^(ext_k-1) even-indexed rows
+ * first, then the odd-indexed ones.  Each half is the compact layout (see the coset subsets below) of the even / the odd
+ * cosets, in ascending order, so zkhip_evaluate_h reads a half through desc.cosets = {0, 2, ..} or {1, 3, ..}.  No
+ * reference counterpart: upstream keeps one layout because it evaluates every term on every row. */
+int zkhip_coeff_to_extended_split_dev(zkhip_domain* dom, const uint64_t* d_coeff, uint64_t* d_out, size_t batch);
+/* Values of a polynomial of degree < 2^(ext_k-1) on the even-indexed rows of the extended domain -> its values on the
+ * odd-indexed rows (one inverse and one forward transform of half the extended size).  batch members back to back. */
+int zkhip_extend_half_dev(zkhip_domain* dom, const uint64_t* d_even, uint64_t* d_odd, size_t batch);
 int zkhip_divide_by_vanishing_poly_dev(zkhip_domain* dom, uint64_t* d_ext, size_t batch);
 
 /* ------------------------------------------------------------------ evaluate_h --------------------
@@ -214,12 +222,21 @@ typedef struct {
      * extended domain, or the compact layout of `cosets`); every column is still given whole, `out` has row_count rows.
      * More GPUs than cosets share a coset this way without exchanging neighbouring rows (no reference counterpart). */
     uint32_t row_first, row_count;
+    /* Which terms of h are evaluated (no reference counterpart): h = sum_i y^(N-1-i) term_i over the gate polynomials and
+     * the permutation / lookup identities in upstream's order.  ZKHIP_TERMS_LOW keeps the terms whose degree as a polynomial
+     * in the columns is at most term_degree_max, ZKHIP_TERMS_HIGH the others; every kept term keeps its power of y, so the
+     * two results add up to the ZKHIP_TERMS_ALL result.  A sum of terms of degree <= d is determined by its values on
+     * d * 2^k points: with d = 2^(e-1) the low part is evaluated on the even-indexed half of the extended domain only
+     * (the compact layout of the even cosets) and extended to the other half by zkhip_extend_half_dev. */
+    uint32_t term_select;
+    uint32_t term_degree_max;
 } zkhip_evalh_desc;
+enum { ZKHIP_TERMS_ALL = 0, ZKHIP_TERMS_LOW = 1, ZKHIP_TERMS_HIGH = 2 };
 
 /* out: 2^ext_k x 4 (host or device per desc->mem) = numerator of the quotient on the extended coset (2^k * num_cosets rows
  * with a coset list, row_count rows with a row window). */
 int zkhip_evaluate_h(zkhip_domain* dom, const zkhip_evalh_desc* desc, uint64_t* out);
-/* Size of the fused program the last zkhip_evaluate_h call on this context ran per extended row: out[0] instructions,
+/* Size of the fused program the last zkhip_evaluate_h (or zkhip_evaluate_h_prepare) call on this context ran (built) per extended row: out[0] instructions,
  * out[1] field multiplications, out[2] column reads, out[3] value slots (for throughput accounting; no reference
  * counterpart). */
 int zkhip_evaluate_h_last_stats(zkhip_ctx* ctx, uint64_t out[4]);

@@ -20,6 +20,9 @@ pub const ZKHIP_FORM_COEFF: u32 = 0;
 pub const ZKHIP_FORM_EXTENDED: u32 = 1;
 pub const ZKHIP_BASIS_EXTENDED: u32 = 0;
 pub const ZKHIP_BASIS_LAGRANGE: u32 = 1;
+pub const ZKHIP_TERMS_ALL: u32 = 0;
+pub const ZKHIP_TERMS_LOW: u32 = 1;
+pub const ZKHIP_TERMS_HIGH: u32 = 2;
 
 #[repr(C)]
 pub struct zkhip_ctx {
@@ -88,6 +91,8 @@ pub struct zkhip_evalh_desc {
     pub basis: u32,
     pub row_first: u32,
     pub row_count: u32,
+    pub term_select: u32,
+    pub term_degree_max: u32,
 }
 
 extern "C" {
@@ -148,6 +153,8 @@ extern "C" {
     pub fn zkhip_coeff_to_extended_dev(dom: *mut zkhip_domain, d_coeff: *const u64, d_out: *mut u64, batch: usize) -> c_int;
     pub fn zkhip_extended_to_coeff_dev(dom: *mut zkhip_domain, d_ext: *mut u64, d_out: *mut u64, batch: usize) -> c_int;
     pub fn zkhip_divide_by_vanishing_poly_dev(dom: *mut zkhip_domain, d_ext: *mut u64, batch: usize) -> c_int;
+    pub fn zkhip_coeff_to_extended_split_dev(dom: *mut zkhip_domain, d_coeff: *const u64, d_out: *mut u64, batch: usize) -> c_int;
+    pub fn zkhip_extend_half_dev(dom: *mut zkhip_domain, d_even: *const u64, d_odd: *mut u64, batch: usize) -> c_int;
 
     // ---- plonk::evaluation::Evaluator::evaluate_h
     pub fn zkhip_evaluate_h(dom: *mut zkhip_domain, desc: *const zkhip_evalh_desc, out: *mut u64) -> c_int;

@@ -405,6 +405,8 @@ impl<'a> EvaluateH<'a> {
             basis: ZKHIP_BASIS_EXTENDED,
             row_first: 0,
             row_count: 0,
+            term_select: ZKHIP_TERMS_ALL,
+            term_degree_max: 0,
         }
     }
 

@@ -62,7 +62,20 @@ def test_struct_layout_matches_header():
     # sizes computed from the C declarations (LP64): catches a drifted ctypes mirror
     assert C.sizeof(ffi.Graph) == 48
     assert C.sizeof(ffi.Lookup) == 48 + 24
-    assert C.sizeof(ffi.EvalhDesc) == 6 * 4 + 4 * 8 + 4 * 32 + 3 * 8 + 8 + 8 + 8 + 8 + 3 * 8 + 8 + 8 + 8 + 8 + 8 + 8 + 8
+    assert C.sizeof(ffi.EvalhDesc) == 6 * 4 + 4 * 8 + 4 * 32 + 3 * 8 + 8 + 8 + 8 + 8 + 3 * 8 + 8 + 8 + 8 + 8 + 8 + 8 + 8 + 8
+    # and what the C compiler makes of the header itself
+    import shutil
+    import subprocess
+    import tempfile
+    if shutil.which("gcc"):
+        with tempfile.TemporaryDirectory() as tmp:
+            src = os.path.join(tmp, "sz.c")
+            with open(src, "w") as f:
+                f.write('#include <stdio.h>\n#include "%s"\nint main(void) { printf("%%zu %%zu %%zu\\n", sizeof(zkhip_graph), '
+                        'sizeof(zkhip_lookup), sizeof(zkhip_evalh_desc)); return 0; }\n' % os.path.join(ROOT, "include", "zkhip.h"))
+            subprocess.check_call(["gcc", src, "-o", os.path.join(tmp, "sz")])
+            sizes = [int(v) for v in subprocess.check_output([os.path.join(tmp, "sz")]).split()]
+        assert sizes == [C.sizeof(ffi.Graph), C.sizeof(ffi.Lookup), C.sizeof(ffi.EvalhDesc)]
 
 
 def test_code_object_targets_gfx950():

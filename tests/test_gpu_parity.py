@@ -386,6 +386,134 @@ def test_evaluate_h_vs_oracle(ctx, co, k, kw):
     d.close()
 
 
+_SPLIT_SHAPES = [
+    (7, dict()),
+    (8, dict(num_advice=12, num_gate_polys=40, num_lookups=3, num_perm_cols=7)),
+    (8, dict(num_advice=24, num_fixed=6, num_gate_polys=120, max_degree=9, num_lookups=4, lookup_width=3, num_perm_cols=9,
+             rotations=(-5, -2, -1, 0, 1, 3))),
+    (7, dict(num_advice=6, num_gate_polys=12, max_degree=3, num_lookups=1, num_perm_cols=2)),      # extended domain 2n
+    (6, dict(num_lookups=0, num_perm_cols=0)),
+]
+
+
+@pytest.mark.parametrize("k,kw", _SPLIT_SHAPES)
+def test_evaluate_h_low_and_high_degree_terms_add_up(ctx, co, k, kw):
+    """desc.term_select: the terms of degree <= bound and the others, each with its own power of y, add up to h as the
+    oracle computes it, for every bound (a bound of 0 or of the constraint degree leaves one side empty)"""
+    cs = synthetic.synthetic_cs(**kw)
+    d, od = zk.Domain(ctx, cs.degree(), k), co.Domain(cs.degree(), k, threads=8)
+    rng = np.random.default_rng(500 + k)
+    call, coeff, ext = _random_call(cs, rng, d.n, d.extended_len, od)
+    call.advice, call.instance, call.lookups = ext["advice"], ext["instance"], ext["lookups"]
+    exp = od.evaluate_h(call.build(ffi.MEM_HOST, ffi.FORM_EXTENDED))
+    sizes = {}
+    for bound in (0, 1, 2, 3, 4, 6, cs.degree()):
+        parts = []
+        for sel in (ffi.TERMS_LOW, ffi.TERMS_HIGH):
+            call.terms = (sel, bound)
+            parts.append(d.evaluate_h(call.build(ffi.MEM_HOST, ffi.FORM_EXTENDED)))
+            sizes[(bound, sel)] = ctx.evaluate_h_last_stats()["multiplications"]
+        assert np.array_equal(co.field_binop(0, 0, parts[0], parts[1]), exp), bound
+        if bound == 0:
+            assert not parts[0].any() and np.array_equal(parts[1], exp)
+        if bound == cs.degree():
+            assert not parts[1].any() and np.array_equal(parts[0], exp)
+    call.terms = None
+    assert np.array_equal(d.evaluate_h(call.build(ffi.MEM_HOST, ffi.FORM_EXTENDED)), exp)
+    assert sizes[(0, ffi.TERMS_LOW)] == 0 and sizes[(cs.degree(), ffi.TERMS_HIGH)] == 0
+    d.close()
+
+
+def test_split_extension_layout_and_half_domain_extension(ctx, co):
+    """coeff_to_extended_split_dev = coeff_to_extended with the even-indexed rows first, then the odd-indexed ones;
+    extend_half_dev carries the values of a polynomial of degree < 2^(extended_k - 1) from the even to the odd rows"""
+    for k, j in ((5, 3), (6, 4), (7, 5), (8, 9), (11, 9)):
+        d, od = zk.Domain(ctx, j, k), co.Domain(j, k, threads=8)
+        en, half = d.extended_len, d.extended_len // 2
+        rng = np.random.default_rng(k * 10 + j)
+        a, b = rand_fr(rng, d.n), rand_fr(rng, d.n)
+        ea, eb = od.coeff_to_extended(a), od.coeff_to_extended(b)
+        d_in = ctx.upload(np.concatenate([a, b]))
+        d_out = ctx.alloc(2 * en * 32)
+        d.coeff_to_extended_split_dev(d_in, d_out, 2)
+        got = ctx.download(d_out, (2, en, 4))
+        for g, e in ((got[0], ea), (got[1], eb)):
+            assert np.array_equal(g[:half], e[0::2]) and np.array_equal(g[half:], e[1::2])
+        # degree < n <= en / 2: one polynomial; and, from four cosets on, a product of two (degree < 2n <= en / 2)
+        d_odd = ctx.alloc(2 * half * 32)
+        d_even = ctx.upload(np.concatenate([ea[0::2], eb[0::2]]))
+        d.extend_half_dev(d_even, d_odd, 2)
+        odd = ctx.download(d_odd, (2, half, 4))
+        assert np.array_equal(odd[0], ea[1::2]) and np.array_equal(odd[1], eb[1::2])
+        if en >= 4 * d.n:
+            prod = co.field_binop(0, 2, ea, eb)
+            d_pe = ctx.upload(prod[0::2])
+            d.extend_half_dev(d_pe, d_odd)
+            assert np.array_equal(ctx.download(d_odd, (half, 4)), prod[1::2])
+            ctx.free(d_pe)
+        for p in (d_in, d_out, d_odd, d_even):
+            ctx.free(p)
+        d.close()
+
+
+@pytest.mark.parametrize("k,kw", _SPLIT_SHAPES)
+def test_evaluate_h_with_low_degree_terms_on_half_the_domain(ctx, co, k, kw):
+    """`evalh_host.evaluate_h_split`: every column a genuine polynomial of degree < n in the parity-split layout, the terms of
+    degree <= m / 2 evaluated on the even-indexed rows only and extended; h equals the oracle's whole-domain evaluation bit for
+    bit, and so do the quotient's coefficients"""
+    cs = synthetic.synthetic_cs(**kw)
+    d, od = zk.Domain(ctx, cs.degree(), k), co.Domain(cs.degree(), k, threads=8)
+    n, en = d.n, d.extended_len
+    rng = np.random.default_rng(900 + k)
+    names = (["fixed"] * cs.num_fixed_columns + ["advice"] * cs.num_advice_columns + ["instance"] * cs.num_instance_columns
+             + ["l"] * 3 + ["lookup"] * (3 * len(cs.lookups)) + ["sigma"] * len(cs.permutation_columns)
+             + ["z"] * cs.num_permutation_sets())
+    coeffs = [rand_fr(rng, n) for _ in names]
+    d_coeff = ctx.upload(np.concatenate(coeffs))
+    d_nat, d_split = ctx.alloc(len(names) * en * 32), ctx.alloc(len(names) * en * 32)
+    d.coeff_to_extended_dev(d_coeff, d_nat, len(names))
+    d.coeff_to_extended_split_dev(d_coeff, d_split, len(names))
+
+    def fill(call, base):
+        it = iter(base + i * en * 32 for i in range(len(names)))
+        take = lambda cnt: [next(it) for _ in range(cnt)]                               # noqa: E731
+        call.fixed, call.advice, call.instance = take(cs.num_fixed_columns), take(cs.num_advice_columns), take(cs.num_instance_columns)
+        call.l0, call.l_last, call.l_active = take(3)
+        call.lookups = [tuple(take(3)) for _ in cs.lookups]
+        call.perm_sigma, call.perm_z = take(len(cs.permutation_columns)), take(cs.num_permutation_sets())
+    call = evalh_host.EvalhCall(cs)
+    call.challenges = rand_fr(rng, cs.num_challenges)
+    call.y, call.beta, call.gamma, call.theta = (rand_fr(rng, 1)[0] for _ in range(4))
+    # the oracle on host copies of the natural layout
+    nat = ctx.download(d_nat, (len(names), en, 4))
+    host = evalh_host.EvalhCall(cs)
+    host.challenges, host.y, host.beta, host.gamma, host.theta = call.challenges, call.y, call.beta, call.gamma, call.theta
+    it = iter(nat)
+    take = lambda cnt: [next(it) for _ in range(cnt)]                                   # noqa: E731
+    host.fixed, host.advice, host.instance = take(cs.num_fixed_columns), take(cs.num_advice_columns), take(cs.num_instance_columns)
+    host.l0, host.l_last, host.l_active = take(3)
+    host.lookups = [tuple(take(3)) for _ in cs.lookups]
+    host.perm_sigma, host.perm_z = take(len(cs.permutation_columns)), take(cs.num_permutation_sets())
+    exp = od.evaluate_h(host.build(ffi.MEM_HOST, ffi.FORM_EXTENDED))
+    d_h = ctx.alloc(en * 32)
+    fill(call, d_nat)
+    d.evaluate_h(call.build(ffi.MEM_DEVICE, ffi.FORM_EXTENDED), d_h)
+    assert np.array_equal(ctx.download(d_h, (en, 4)), exp)
+    ctx.upload(np.zeros((en, 4), dtype=np.uint64), d_h)
+    fill(call, d_split)
+    evalh_host.evaluate_h_split(ctx, d, call, d_h)
+    assert np.array_equal(ctx.download(d_h, (en, 4)), exp)
+    gain = evalh_host.split_gain(d, cs, call.ev)
+    assert gain[0] + gain[1] >= gain[2] * 0.9 and gain[0] <= gain[2] and gain[1] <= gain[2]
+    d.divide_by_vanishing_poly_dev(d_h)
+    d_q = ctx.alloc(n * d.quotient_poly_degree * 32)
+    d.extended_to_coeff_dev(d_h, d_q)
+    assert np.array_equal(ctx.download(d_q, (n * d.quotient_poly_degree, 4)), od.extended_to_coeff(od.divide_by_vanishing_poly(exp)))
+    for p in (d_coeff, d_nat, d_split, d_h, d_q):
+        ctx.free(p)
+    d.close()
+
+
 def test_evaluate_h_program_is_built_once_per_shape(ctx, co):
     """The fused program is kept per constraint-system shape (upstream: `ProvingKey::ev`): a second call with other
     columns, challenges and another extended size reuses it, a different shape builds its own, and every result still

@@ -14,6 +14,8 @@ struct zkhip_domain {
     void* d_xpoints = nullptr;             // zeta * extended_omega^idx per extended row (built on first use by evaluate_h)
     std::map<uint32_t, void*> d_coset_powers;   // coset j -> (zeta * extended_omega^j)^i for i < 2^k (built on first use)
     zkhip::NttPlan *plan_fwd = nullptr, *plan_inv = nullptr, *plan_ext_fwd = nullptr, *plan_ext_inv = nullptr;
+    // transforms over the even-indexed half of the extended domain, zeta * <extended_omega^2> (built on first use)
+    zkhip::NttPlan *plan_half_fwd = nullptr, *plan_half_inv = nullptr;
 };
 
 namespace zkhip {
@@ -32,5 +34,6 @@ int domain_coeff_to_cosets(zkhip_domain* dom, const fe* d_coeff, size_t batch, c
 // x[q * num + s] = zeta * extended_omega^(q * 2^e + j[s])
 int domain_coset_xpoints(zkhip_domain* dom, const CosetList& cl, fe* d_x);
 // coeff (2^k per member, stride 2^k) -> extended coset (2^extended_k per member); tmp0/tmp1: batch * 2^extended_k each
-int domain_coeff_to_extended(zkhip_domain* dom, const fe* d_coeff, fe* d_out, size_t batch, fe* tmp0, fe* tmp1);
+int domain_coeff_to_extended(zkhip_domain* dom, const fe* d_coeff, fe* d_out, size_t batch, fe* tmp0, fe* tmp1,
+                             bool split = false);
 }  // namespace zkhip

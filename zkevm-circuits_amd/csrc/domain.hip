@@ -9,9 +9,10 @@ namespace zkhip {
 
 static void to_fe(fe& o, const uint64_t v[4]) { memcpy(o.l, v, 32); }
 
-int domain_coeff_to_extended(zkhip_domain* dom, const fe* d_coeff, fe* d_out, size_t batch, fe* tmp0, fe* tmp1) {
+int domain_coeff_to_extended(zkhip_domain* dom, const fe* d_coeff, fe* d_out, size_t batch, fe* tmp0, fe* tmp1, bool split) {
     NttFuse fuse;
     fuse.pre_mode = 1;
+    fuse.split_out = split ? 1 : 0;
     to_fe(fuse.pre[0], HFR.r);
     to_fe(fuse.pre[1], dom->g_coset);
     to_fe(fuse.pre[2], dom->g_coset_inv);
@@ -75,6 +76,15 @@ __global__ void __launch_bounds__(256) coset_xpoints_kernel(fe* x, size_t rows, 
     fe om = load_fe(om_lo + (idx & ((1u << h) - 1)));
     if (idx >> h) om = Fr::mul(om, load_fe(om_hi + (idx >> h)));
     store_fe(x + c, Fr::mul(om, zeta));
+}
+
+// a[m] *= s * w^m with w^m = lo[m mod 2^h] * hi[m >> h]: moves the coefficients of P(zeta X) to those of P(zeta w X)
+__global__ void __launch_bounds__(256) scale_by_powers_kernel(fe* a, size_t n, fe s, const fe* om_lo, const fe* om_hi, uint32_t h) {
+    const size_t m = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= n) return;
+    fe f = Fr::mul(s, load_fe(om_lo + (m & (((size_t)1 << h) - 1))));
+    if (m >> h) f = Fr::mul(f, load_fe(om_hi + (m >> h)));
+    store_fe(a + m, Fr::mul(load_fe(a + m), f));
 }
 
 int coset_list_check(zkhip_domain* dom, const uint32_t* cosets, uint32_t num, CosetList* out) {
@@ -309,6 +319,59 @@ int zkhip_coeff_to_extended_dev(zkhip_domain* dom, const uint64_t* d_coeff, uint
     int rc = scratch2(dom, batch, dom->extended_k, &t0, &t1);
     if (rc) return rc;
     return domain_coeff_to_extended(dom, (const fe*)d_coeff, (fe*)d_out, batch, t0, t1);
+}
+
+int zkhip_coeff_to_extended_split_dev(zkhip_domain* dom, const uint64_t* d_coeff, uint64_t* d_out, size_t batch) {
+    if (!dom) return ZKHIP_ERR_INVALID;
+    zkhip_ctx* ctx = dom->ctx;
+    ZK_CHECK(ctx, d_coeff && d_out && batch >= 1, "coeff_to_extended_split: null pointer or empty batch");
+    ZK_CHECK(ctx, (const void*)d_coeff != (const void*)d_out, "coeff_to_extended_split: in and out must differ");
+    ZK_CHECK(ctx, dom->extended_k > dom->k, "coeff_to_extended_split: the extended domain has a single coset");
+    ZK_HIP(ctx, hipSetDevice(ctx->device));
+    fe *t0, *t1;
+    int rc = scratch2(dom, batch, dom->extended_k, &t0, &t1);
+    if (rc) return rc;
+    return domain_coeff_to_extended(dom, (const fe*)d_coeff, (fe*)d_out, batch, t0, t1, true);
+}
+
+int zkhip_extend_half_dev(zkhip_domain* dom, const uint64_t* d_even, uint64_t* d_odd, size_t batch) {
+    if (!dom) return ZKHIP_ERR_INVALID;
+    zkhip_ctx* ctx = dom->ctx;
+    ZK_CHECK(ctx, d_even && d_odd && batch >= 1, "extend_half: null pointer or empty batch");
+    ZK_CHECK(ctx, (const void*)d_even != (const void*)d_odd, "extend_half: in and out must differ");
+    ZK_CHECK(ctx, dom->extended_k > dom->k, "extend_half: the extended domain has a single coset");
+    ZK_HIP(ctx, hipSetDevice(ctx->device));
+    const uint32_t hk = dom->extended_k - 1;
+    const size_t hn = (size_t)1 << hk;
+    int rc = ZKHIP_OK;
+    if (!dom->plan_half_fwd) {
+        uint64_t w[4], wi[4];
+        h_mul(HFR, w, dom->extended_omega, dom->extended_omega);
+        h_mul(HFR, wi, dom->extended_omega_inv, dom->extended_omega_inv);
+        if ((rc = zkhip_internal_get_plan(ctx, hk, w, &dom->plan_half_fwd))) return rc;
+        if ((rc = zkhip_internal_get_plan(ctx, hk, wi, &dom->plan_half_inv))) return rc;
+    }
+    // d_odd = inverse transform of the values on zeta <w^2> (the coefficients of P(zeta X), not yet divided by their
+    // count); coefficient m times w^m / count; forward transform: P on zeta w <w^2>, the odd-indexed points
+    rc = ensure_scratch(ctx, 2 * batch * hn * 32);
+    if (rc) return rc;
+    fe* t0 = (fe*)ctx->scratch;
+    fe* t1 = t0 + batch * hn;
+    NttFuse none;
+    rc = ntt_run(ctx, dom->plan_half_inv, (const fe*)d_even, hn, (uint32_t)hn, (fe*)d_odd, hn, (uint32_t)hn, batch, none, t0, t1);
+    if (rc) return rc;
+    uint64_t cnt[4], inv[4];
+    h_from_u64(HFR, cnt, (uint64_t)hn);
+    h_inv(HFR, inv, cnt);
+    fe s;
+    memcpy(s.l, inv, 32);
+    for (size_t b = 0; b < batch; b++) {
+        hipLaunchKernelGGL(scale_by_powers_kernel, dim3((unsigned)((hn + 255) / 256)), dim3(256), 0, ctx->stream,
+                           (fe*)d_odd + b * hn, hn, s, (const fe*)dom->plan_ext_fwd->d_lo, (const fe*)dom->plan_ext_fwd->d_hi,
+                           dom->plan_ext_fwd->h);
+    }
+    ZK_HIP(ctx, hipGetLastError());
+    return ntt_run(ctx, dom->plan_half_fwd, (const fe*)d_odd, hn, (uint32_t)hn, (fe*)d_odd, hn, (uint32_t)hn, batch, none, t0, t1);
 }
 
 int zkhip_extended_to_coeff_dev(zkhip_domain* dom, uint64_t* d_ext, uint64_t* d_out, size_t batch) {

@@ -528,6 +528,10 @@ struct Builder {
     // The running-value register holds H while the gates are lowered, afterwards (or when no gate term is outside a
     // group) the partial sum of the one group that is open: a value in the register costs no slot.
     bool grouping = false;
+    // which terms are issued (zkhip_evalh_desc::term_select): a term that is not kept still takes its number, so that every
+    // kept term keeps its power of y and the low and the high program add up to the whole
+    uint32_t term_select = 0, term_degree_max = 0;
+    bool keep(uint32_t degree) const { return term_select == 0 || (term_select == 1) == (degree <= term_degree_max); }
     std::vector<std::pair<const char*, size_t>> marks;   // section boundaries (instruction index), for the debug print
     void mark(const char* name) { marks.push_back({name, words.size() / IW}); }
     uint32_t n_terms = 0, sc_y0 = 0;
@@ -746,6 +750,33 @@ struct Lowering {
         }
     }
 
+    // degree of every calculation as a polynomial in the columns (constants, challenges and the running value: 0)
+    std::vector<uint32_t> deg;
+    uint32_t vs_degree(const VS& v) const {
+        if (v.kind == 1) return v.a < deg.size() ? deg[v.a] : 0;
+        return (v.kind >= 2 && v.kind <= 4) ? 1 : 0;
+    }
+    void compute_degrees() {
+        deg.assign(calcs.size(), 0);
+        for (size_t t = 0; t < calcs.size(); t++) {
+            const Calc& c = calcs[t];
+            switch (c.op) {
+                case 0: case 1: deg[t] = std::max(vs_degree(c.src[0]), vs_degree(c.src[1])); break;
+                case 2: deg[t] = vs_degree(c.src[0]) + vs_degree(c.src[1]); break;
+                case 3: deg[t] = 2 * vs_degree(c.src[0]); break;
+                case 6: {
+                    uint32_t d = vs_degree(c.start);
+                    const uint32_t f = vs_degree(c.factor);
+                    for (const VS& p : c.parts) d = std::max(d + f, vs_degree(p));
+                    deg[t] = d;
+                    break;
+                }
+                default: deg[t] = vs_degree(c.src[0]); break;
+            }
+        }
+    }
+    bool whole_skipped = false;   // a gates graph that is one term of h, and that term is not kept
+
     // iterative post-order: make calculation `t_root` available
     bool schedule(uint32_t t_root) {
         struct Frame { uint32_t t; uint32_t stage; };
@@ -793,6 +824,10 @@ struct Lowering {
                 while (st.back().stage - 1 < root_order.size()) {
                     const uint32_t j = root_order[st.back().stage - 1];
                     const RootPart& rp = root_parts[j];
+                    if (!b.keep(vs_degree(c.parts[j]))) {      // the term keeps its number and nothing of it is issued
+                        st.back().stage++;                        // (groups are formed among the kept parts only)
+                        continue;
+                    }
                     if (rp.group < 0) {
                         if (dep(c.parts[j])) { pushed = true; break; }
                         uint32_t pw;
@@ -878,7 +913,7 @@ struct Lowering {
         std::vector<Cand> cand;
         for (size_t j = 0; j < np; j++) {
             const VS& v = c.parts[j];
-            if (v.kind != 1 || v.a >= calcs.size() || uses[v.a] != 1) continue;
+            if (v.kind != 1 || v.a >= calcs.size() || uses[v.a] != 1 || !b.keep(vs_degree(v))) continue;
             const Calc& m = calcs[v.a];
             if (m.op != 2 || vs_key(m.src[0]) == vs_key(m.src[1])) continue;
             cand.push_back({j, {m.src[0], m.src[1]}});
@@ -909,7 +944,7 @@ struct Lowering {
         }
         root_term0 = b.reserve_terms((uint32_t)np);
         for (size_t j = 0; j < np; j++)
-            if (root_parts[j].group < 0) b.chain_reserved = true;   // the register carries the chain of those parts
+            if (root_parts[j].group < 0 && b.keep(vs_degree(c.parts[j]))) b.chain_reserved = true;   // the register carries the chain of those parts
         std::vector<std::vector<uint32_t>> members(group_left.size());
         for (size_t j = 0; j < np; j++)
             if (root_parts[j].group >= 0) members[root_parts[j].group].push_back((uint32_t)j);
@@ -936,6 +971,12 @@ struct Lowering {
         done.assign(calcs.size(), 0);
         root = (uint32_t)calcs.size() - 1;
         terms_root = is_gates && b.grouping && calcs[root].op == 6 && calcs[root].start.kind == 10 && calcs[root].factor.kind == 9;
+        compute_degrees();
+        if (is_gates && b.grouping && !terms_root && !b.keep(deg[root])) {
+            whole_skipped = true;
+            result = W_ZERO;
+            return true;
+        }
         if (!schedule(root)) return false;
         result = val[root];
         return true;
@@ -1125,6 +1166,9 @@ static int build_program(zkhip_ctx* ctx, const zkhip_evalh_desc* desc, bool lagr
     // ZKHIP_EVALH_CHAIN: the terms as upstream's chain h = h * y + term (measurements and differential tests)
     static const bool chain = getenv("ZKHIP_EVALH_CHAIN") != nullptr;
     b.grouping = !chain;
+    b.term_select = lagrange ? 0 : desc->term_select;
+    b.term_degree_max = desc->term_degree_max;
+    ZK_CHECK(ctx, !b.term_select || b.grouping, "evaluate_h: a term selection needs the grouped form (ZKHIP_EVALH_CHAIN is set)");
     b.sc_y0 = sc_perm0 + (desc->num_perm_sets ? desc->num_perm_columns : 0);
     // ---- 1. custom gates -----------------------------------------------------------------------------
     if (desc->custom_gates) {
@@ -1133,7 +1177,10 @@ static int build_program(zkhip_ctx* ctx, const zkhip_evalh_desc* desc, bool lagr
         uint32_t res;
         if (!lw.run(res)) return set_error(ctx, ZKHIP_ERR_INVALID, "evaluate_h: %s", lw.err.c_str());
         if (b.grouping) {
-            if (!lw.terms_root) b.fold(res);           // the value of the graph is the first term
+            if (!lw.terms_root) {                      // the value of the graph is the first term
+                const uint32_t i0 = b.reserve_terms(1);
+                if (!lw.whole_skipped) b.fold_at(i0, res);
+            }
             b.chain_reserved = false;                  // the groups that follow may use the register
         } else if (res != W_ACC) {
             b.emit(0, DST_ACC_V, res);                 // a gates graph whose value is not the running Horner
@@ -1152,7 +1199,11 @@ static int build_program(zkhip_ctx* ctx, const zkhip_evalh_desc* desc, bool lagr
     };
     std::vector<Term> by_factor[3];            // 0: l_0, 1: l_last, 2: l_active
     const uint32_t l_cols[3] = {c_l0, c_last, c_active};
-    auto term = [&](int f, std::function<int(uint32_t&)> make) { by_factor[f].push_back({b.reserve_terms(1), std::move(make)}); };
+    // degree: of the whole term as a polynomial in the columns, its l_0 / l_last / l_active factor included
+    auto term = [&](int f, uint32_t degree, std::function<int(uint32_t&)> make) {
+        const uint32_t idx = b.reserve_terms(1);
+        if (b.keep(degree)) by_factor[f].push_back({idx, std::move(make)});
+    };
     std::vector<uint32_t> pcol(desc->num_perm_sets ? desc->num_perm_columns : 0);
     if (desc->num_perm_sets) {
         const uint32_t c_x = L.c_x, c_z0 = L.c_z0, c_sigma0 = L.c_sigma0;
@@ -1166,23 +1217,24 @@ static int build_program(zkhip_ctx* ctx, const zkhip_evalh_desc* desc, bool lagr
         const int32_t last_rot = -((int32_t)desc->blinding_factors + 1);
         const uint32_t nsets = desc->num_perm_sets;
         // l_0(X) * (1 - z_0(X))
-        term(0, [&b, ONE, c_z0](uint32_t& e) { e = b.sub(ONE, b.col(c_z0, 0)); return (int)ZKHIP_OK; });
+        term(0, 2, [&b, ONE, c_z0](uint32_t& e) { e = b.sub(ONE, b.col(c_z0, 0)); return (int)ZKHIP_OK; });
         // l_last(X) * (z_l(X)^2 - z_l(X))
-        term(1, [&b, c_z0, nsets](uint32_t& e) {
+        term(1, 3, [&b, c_z0, nsets](uint32_t& e) {
             const uint32_t zl = b.col(c_z0 + nsets - 1, 0);
             e = b.mul_sub(zl, zl, zl);
             return (int)ZKHIP_OK;
         });
         // l_0(X) * (z_i(X) - z_{i-1}(omega^last X))
         for (uint32_t s = 1; s < nsets; s++)
-            term(0, [&b, c_z0, s, last_rot](uint32_t& e) {
+            term(0, 2, [&b, c_z0, s, last_rot](uint32_t& e) {
                 e = b.sub(b.col(c_z0 + s, 0), b.col(c_z0 + s - 1, last_rot));
                 return (int)ZKHIP_OK;
             });
         // l_active(X) * (z_i(omega X) prod (p + beta s_j + gamma) - z_i(X) prod (p + delta^j beta X + gamma));
         // current_delta of column c on row idx = beta * zeta * extended_omega^idx * delta^c = (beta * delta^c) * X[idx]
         for (uint32_t s = 0; s < nsets; s++)
-            term(2, [&b, &pcol, desc, s, c_z0, c_x, c_sigma0, sc_perm0, BETA, GAMMA](uint32_t& e) {
+            term(2, 2 + std::min(desc->perm_chunk_len, desc->num_perm_columns - s * desc->perm_chunk_len),
+                 [&b, &pcol, desc, s, c_z0, c_x, c_sigma0, sc_perm0, BETA, GAMMA](uint32_t& e) {
                 const uint32_t c0 = s * desc->perm_chunk_len, c1 = std::min(c0 + desc->perm_chunk_len, desc->num_perm_columns);
                 uint32_t left = b.col(c_z0 + s, 1), right = b.col(c_z0 + s, 0);
                 for (uint32_t c = c0; c < c1; c++) {
@@ -1198,15 +1250,22 @@ static int build_program(zkhip_ctx* ctx, const zkhip_evalh_desc* desc, bool lagr
         const zkhip_graph* g = &desc->lookups[i].graph;
         const uint32_t c_z = L.c_lk0 + 3 * i, c_a = c_z + 1, c_s = c_z + 2;
         // l_0(X) * (1 - z(X))
-        term(0, [&b, ONE, c_z](uint32_t& e) { e = b.sub(ONE, b.col(c_z, 0)); return (int)ZKHIP_OK; });
+        term(0, 2, [&b, ONE, c_z](uint32_t& e) { e = b.sub(ONE, b.col(c_z, 0)); return (int)ZKHIP_OK; });
         // l_last(X) * (z(X)^2 - z(X))
-        term(1, [&b, c_z](uint32_t& e) {
+        term(1, 3, [&b, c_z](uint32_t& e) {
             const uint32_t Z = b.col(c_z, 0);
             e = b.mul_sub(Z, Z, Z);
             return (int)ZKHIP_OK;
         });
         // l_active(X) * (z(omega X) (a'(X) + beta) (s'(X) + gamma) - z(X) * table_value)
-        term(2, [&b, ctx, g, desc, c_z, c_a, c_s, BETA, GAMMA](uint32_t& e) {
+        uint32_t table_degree = 0;     // of (a_compressed + beta) (s_compressed + gamma), the graph's value
+        {
+            Lowering probe(b, g, desc, false);
+            if (!parse_graph(g, probe.calcs, probe.err)) return set_error(ctx, ZKHIP_ERR_INVALID, "evaluate_h: %s", probe.err.c_str());
+            probe.compute_degrees();
+            if (!probe.calcs.empty()) table_degree = probe.deg.back();
+        }
+        term(2, 1 + std::max<uint32_t>(3, 1 + table_degree), [&b, ctx, g, desc, c_z, c_a, c_s, BETA, GAMMA](uint32_t& e) {
             Lowering lw(b, g, desc, false);
             uint32_t table_value;
             if (!lw.run(table_value)) return set_error(ctx, ZKHIP_ERR_INVALID, "evaluate_h: %s", lw.err.c_str());
@@ -1215,9 +1274,9 @@ static int build_program(zkhip_ctx* ctx, const zkhip_evalh_desc* desc, bool lagr
             return (int)ZKHIP_OK;
         });
         // l_0(X) * (a'(X) - s'(X))
-        term(0, [&b, c_a, c_s](uint32_t& e) { e = b.sub(b.col(c_a, 0), b.col(c_s, 0)); return (int)ZKHIP_OK; });
+        term(0, 2, [&b, c_a, c_s](uint32_t& e) { e = b.sub(b.col(c_a, 0), b.col(c_s, 0)); return (int)ZKHIP_OK; });
         // l_active(X) * (a'(X) - s'(X)) * (a'(X) - a'(omega^-1 X))
-        term(2, [&b, c_a, c_s](uint32_t& e) {
+        term(2, 3, [&b, c_a, c_s](uint32_t& e) {
             const uint32_t A = b.col(c_a, 0);
             e = b.mul(b.sub(A, b.col(c_s, 0)), b.sub(A, b.col(c_a, -1)));
             return (int)ZKHIP_OK;
@@ -1345,6 +1404,7 @@ static int get_program(zkhip_ctx* ctx, const zkhip_evalh_desc* desc, bool lagran
     const bool do_fuse = !(env_fuse && *env_fuse == '0');
     ShapeHash sh;
     sh.word(((uint64_t)desc->basis << 32) | lds_budget | ((uint64_t)do_fuse << 31));
+    if (desc->basis != ZKHIP_BASIS_LAGRANGE) sh.word(((uint64_t)desc->term_select << 32) | (desc->term_select ? desc->term_degree_max : 0));
     sh.word(((uint64_t)desc->num_fixed << 32) | desc->num_advice);
     sh.word(((uint64_t)desc->num_instance << 32) | desc->num_challenges);
     sh.word(desc->custom_gates ? 1 : 0);
@@ -1376,6 +1436,7 @@ static int get_program(zkhip_ctx* ctx, const zkhip_evalh_desc* desc, bool lagran
 // what every use of a descriptor's shape fields checks before the program is built or looked up
 static int check_shape(zkhip_ctx* ctx, const zkhip_evalh_desc* desc) {
     ZK_CHECK(ctx, desc->basis <= 1, "evaluate_h: basis %u", desc->basis);
+    ZK_CHECK(ctx, desc->term_select <= 2, "evaluate_h: term_select %u", desc->term_select);
     ZK_CHECK(ctx, !desc->num_lookups || desc->lookups, "evaluate_h: lookups missing");
     if (desc->num_perm_sets) {
         ZK_CHECK(ctx, desc->perm_chunk_len >= 1, "evaluate_h: perm_chunk_len = 0");
@@ -1412,7 +1473,9 @@ extern "C" int zkhip_evaluate_h_prepare(zkhip_domain* dom, const zkhip_evalh_des
     int rc = check_shape(ctx, desc);
     if (rc) return rc;
     std::shared_ptr<EvalhProgram> prog;
-    return get_program(ctx, desc, desc->basis == ZKHIP_BASIS_LAGRANGE, prog);
+    rc = get_program(ctx, desc, desc->basis == ZKHIP_BASIS_LAGRANGE, prog);
+    if (!rc) memcpy(ctx->evalh_stats, prog->stats, sizeof ctx->evalh_stats);   // zkhip_evaluate_h_last_stats: of this program
+    return rc;
 }
 
 extern "C" int zkhip_evaluate_h(zkhip_domain* dom, const zkhip_evalh_desc* desc, uint64_t* out) {

@@ -26,6 +26,9 @@ struct NttFuse {
     uint32_t post_mode = 0;   // 1: output multiplied by post[0]; 2: output i multiplied by post[i % 3]
     fe pre[3];
     fe post[3];
+    // 1: the output goes out split by the parity of its index: element i of the N results is stored at
+    // (i & 1) * N/2 + (i >> 1), i.e. the even-indexed results first, then the odd-indexed ones (needs n_out = N)
+    uint32_t split_out = 0;
 };
 
 int ntt_plan_create(zkhip_ctx* ctx, uint32_t log_n, const uint64_t omega[4], NttPlan** out);

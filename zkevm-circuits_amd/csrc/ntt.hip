@@ -45,6 +45,7 @@ struct NttPassArgs {
     uint32_t post_mode;  // 0 none, 1: multiply output by post[0], 2: multiply output i by post[i % 3]
     fe pre[3];
     fe post[3];
+    uint32_t split_out;   // last pass: result i is stored at (i & 1) * N/2 + (i >> 1)
     size_t in_stride, out_stride;   // elements between consecutive batch members
 };
 
@@ -131,7 +132,7 @@ __global__ void __launch_bounds__(NTT_THREADS) ntt_pass_kernel(const NttPassArgs
             fe v = x[(bitrev(q, a.r) << a.logJ) + c];
             if (a.post_mode == 1) v = Fr::mul(v, a.post[0]);
             else if (a.post_mode == 2) v = Fr::mul(v, a.post[oi % 3]);
-            store_fe(out + oi, v);
+            store_fe(out + (a.split_out ? ((oi & 1) << (a.logN - 1)) + (oi >> 1) : oi), v);
         }
     }
 }
@@ -169,6 +170,7 @@ struct NttTileArgs {
     uint32_t r_next;              // radix of the next pass (for the twiddle applied on store)
     const fe* b0;                 // non-null: single-lookup twiddles of this pass boundary, indexed by t * (j mod Ns)
     uint32_t zskip;               // first pass of a zero-padded transform: n_in = N >> zskip (0 otherwise)
+    uint32_t split_out;           // last pass: result i is stored at (i & 1) * N/2 + (i >> 1)
     uint32_t nrounds;
     uint32_t pb[TK_MAX_ROUNDS][TK_LOGE];   // round, local bit i -> tile-row bit
     uint32_t sb[TK_MAX_ROUNDS][TK_LOGE];   // the same bits sorted ascending
@@ -356,7 +358,7 @@ __global__ void __launch_bounds__(TK_THREADS) ntt_tile_kernel(const NttTileArgs 
             fw v = FrW::norm(lds_get(x, tile_at(q, cc, a.logJ)));
             if (a.post_mode == 1) v = NttW::mul(v, FrW::from_fe(a.post[0]));
             else if (a.post_mode == 2) v = NttW::mul(v, FrW::from_fe(a.post[oi % 3]));
-            store_fe(out + oi, FrW::to_fe(v));
+            store_fe(out + (a.split_out ? ((oi & 1) << (a.logN - 1)) + (oi >> 1) : oi), FrW::to_fe(v));
         }
         return;
     }
@@ -507,6 +509,7 @@ int ntt_run(zkhip_ctx* ctx, const NttPlan* plan, const fe* src, size_t src_strid
     const size_t N = (size_t)1 << L;
     const uint32_t npass = (uint32_t)plan->radix.size();
     ZK_CHECK(ctx, batch >= 1 && batch <= 65535, "ntt: batch %zu outside [1, 65535]", batch);
+    ZK_CHECK(ctx, !fuse.split_out || (n_out == N && L >= 1 && src != dst), "ntt: the split output needs all N results, out of place");
     // ping-pong so that the last pass writes dst and no pass runs in place
     // sequence of buffers: src -> b1 -> b2 -> ... -> dst
     std::vector<fe*> bufs(npass + 1);
@@ -552,6 +555,7 @@ int ntt_run(zkhip_ctx* ctx, const NttPlan* plan, const fe* src, size_t src_strid
                 h_mul(HFR, (uint64_t*)a.post[q].l, (const uint64_t*)fuse.post[q].l, k32);
             }
             a.last = (p == npass - 1);
+            a.split_out = (a.last && fuse.split_out) ? 1 : 0;
             a.zskip = 0;
             if (p == 0 && n_in < N && n_in > 0 && (n_in & (n_in - 1)) == 0) {
                 uint32_t z = 0;
@@ -600,6 +604,7 @@ int ntt_run(zkhip_ctx* ctx, const NttPlan* plan, const fe* src, size_t src_strid
         a.post_mode = (p == npass - 1) ? fuse.post_mode : 0;
         memcpy(a.pre, fuse.pre, sizeof a.pre);
         memcpy(a.post, fuse.post, sizeof a.post);
+        a.split_out = (p == npass - 1 && fuse.split_out) ? 1 : 0;
         const uint32_t tile = 1u << (a.r + logJ);
         const size_t lds = ((size_t)tile + (1u << a.r) / 2 + 1) * sizeof(fe);
         dim3 grid((uint32_t)(N >> (a.r + logJ)), (uint32_t)batch);

@@ -41,6 +41,7 @@ class EvalhCall:
         self.rows = None         # (first, count): evaluate only this window of the rows (columns stay whole)
         self.graph = None        # with basis = BASIS_LAGRANGE: the graph evaluated over the 2^k rows of the circuit
         self.basis = ffi.BASIS_EXTENDED
+        self.terms = None        # (TERMS_LOW | TERMS_HIGH, degree bound): evaluate only the terms of h on one side of it
 
     def build(self, mem=ffi.MEM_HOST, form=ffi.FORM_EXTENDED):
         cs, ev = self.cs, self.ev
@@ -96,14 +97,19 @@ class EvalhCall:
             d.num_cosets, d.cosets = len(cl), C.c_void_p(cl.ctypes.data)
         if self.rows is not None:
             d.row_first, d.row_count = self.rows
+        if self.terms is not None:
+            d.term_select, d.term_degree_max = self.terms
         self._keep = b
         return d
 
 
-def prepare(dom, cs: ConstraintSystem, ev: Evaluator):
+def prepare(dom, cs: ConstraintSystem, ev: Evaluator, terms=None):
     """Key-generation step: has the device library build (and keep) the evaluate_h program of this constraint system, as
-    upstream builds `ProvingKey::ev`.  No column data is needed: the descriptor carries counts and graphs only."""
+    upstream builds `ProvingKey::ev`.  No column data is needed: the descriptor carries counts and graphs only.
+    terms: the (selection, degree bound) of `EvalhCall.terms`; returns the program's size (instructions,
+    multiplications, column reads, value slots per row)."""
     call = EvalhCall(cs, ev)
+    call.terms = terms
     call.fixed, call.advice, call.instance = [0] * cs.num_fixed_columns, [0] * cs.num_advice_columns, [0] * cs.num_instance_columns
     call.challenges = np.zeros((cs.num_challenges, 4), dtype=np.uint64)
     call.y = call.beta = call.gamma = call.theta = np.zeros(4, dtype=np.uint64)
@@ -112,6 +118,70 @@ def prepare(dom, cs: ConstraintSystem, ev: Evaluator):
     call.perm_sigma = [0] * len(cs.permutation_columns)
     call.perm_z = [0] * cs.num_permutation_sets()
     dom.evaluate_h_prepare(call.build(ffi.MEM_DEVICE, ffi.FORM_EXTENDED))
+    return dom.ctx.evaluate_h_last_stats()
+
+
+# ---- low-degree terms on half the extended domain ---------------------------------------------------------------------
+# h = sum_i y^(N-1-i) term_i.  A term of degree d in the columns (each a polynomial of degree < n = 2^k) has degree at most
+# d (n - 1); the sum L of the terms with d <= m / 2 (m = 2^e cosets make up the extended domain) is therefore determined by
+# its values on m n / 2 points.  The even-indexed extended rows are such a set -- the coset zeta <extended_omega^2> -- so L
+# is evaluated there only and carried to the odd-indexed rows by one inverse and one forward transform of half the
+# extended size (`Domain.extend_half_dev`); the other terms run on every row as before.  Every column must be in the
+# parity-split layout (`Domain.coeff_to_extended_split_dev`: even-indexed rows, then odd-indexed rows): a half is then the
+# compact layout of the even / the odd cosets, which `zkhip_evaluate_h` reads through its coset list.
+def split_gain(dom, cs: ConstraintSystem, ev: Evaluator):
+    """(low, high, all) multiplications per row of the three programs, built and cached as `prepare` does.  The split
+    evaluates low + 2 * high per pair of rows where the whole program costs 2 * all."""
+    m = 1 << (dom.extended_k - dom.k)
+    if m < 2:
+        return None
+    whole = prepare(dom, cs, ev)
+    low = prepare(dom, cs, ev, (ffi.TERMS_LOW, m // 2))
+    high = prepare(dom, cs, ev, (ffi.TERMS_HIGH, m // 2))
+    return low["multiplications"], high["multiplications"], whole["multiplications"]
+
+
+def shifted(call: EvalhCall, offset: int) -> EvalhCall:
+    """a copy of a device-memory call with `offset` bytes added to every extended-vector pointer"""
+    import copy
+    c = copy.copy(call)
+    mv = lambda ps: [p + offset for p in ps]                                        # noqa: E731
+    c.fixed, c.advice, c.instance = mv(call.fixed), mv(call.advice), mv(call.instance)
+    c.l0, c.l_last, c.l_active = call.l0 + offset, call.l_last + offset, call.l_active + offset
+    c.lookups = [tuple(p + offset for p in t) for t in call.lookups]
+    c.perm_sigma, c.perm_z = mv(call.perm_sigma), mv(call.perm_z)
+    return c
+
+
+def evaluate_h_split(ctx, dom, call: EvalhCall, d_h: int):
+    """`Evaluator::evaluate_h` over device columns in the parity-split layout (extended form), with the terms of degree
+    <= m / 2 evaluated on the even-indexed rows only.  Writes the 2^extended_k values of h, in extended order, to d_h."""
+    m = 1 << (dom.extended_k - dom.k)
+    half = dom.extended_len // 2
+    even, odd = list(range(0, m, 2)), list(range(1, m, 2))
+    bound = m // 2
+    one = np.array([fr_to_mont_limbs(1)] * 2, dtype=np.uint64)
+    bufs = [ctx.alloc(half * 32) for _ in range(4)]
+    d_low_even, d_low_odd, d_high_even, d_high_odd = bufs
+    try:
+        lo = shifted(call, 0)
+        lo.cosets, lo.terms = even, (ffi.TERMS_LOW, bound)
+        dom.evaluate_h(lo.build(ffi.MEM_DEVICE, ffi.FORM_EXTENDED), d_low_even)
+        dom.extend_half_dev(d_low_even, d_low_odd)
+        hi = shifted(call, 0)
+        hi.cosets, hi.terms = even, (ffi.TERMS_HIGH, bound)
+        dom.evaluate_h(hi.build(ffi.MEM_DEVICE, ffi.FORM_EXTENDED), d_high_even)
+        hi = shifted(call, half * 32)
+        hi.cosets, hi.terms = odd, (ffi.TERMS_HIGH, bound)
+        dom.evaluate_h(hi.build(ffi.MEM_DEVICE, ffi.FORM_EXTENDED), d_high_odd)
+        ctx.poly_lincomb_dev([d_low_even, d_high_even], [half, half], one, half, d_high_even)
+        ctx.poly_lincomb_dev([d_low_odd, d_high_odd], [half, half], one, half, d_high_odd)
+        dom.cosets_to_extended_dev(d_high_even, even, d_h)
+        dom.cosets_to_extended_dev(d_high_odd, odd, d_h)
+        ctx.sync()
+    finally:
+        for p in bufs:
+            ctx.free(p)
 
 
 def compress_graph(expressions):

@@ -29,6 +29,7 @@ EXPORTS = [
     "zkhip_divide_by_vanishing_poly",
     "zkhip_lagrange_to_coeff_dev", "zkhip_coeff_to_lagrange_dev", "zkhip_coeff_to_extended_dev",
     "zkhip_extended_to_coeff_dev", "zkhip_divide_by_vanishing_poly_dev",
+    "zkhip_coeff_to_extended_split_dev", "zkhip_extend_half_dev",
     "zkhip_evaluate_h", "zkhip_evaluate_h_last_stats", "zkhip_evaluate_h_cache_stats", "zkhip_evaluate_h_prepare",
     "zkhip_coeff_to_cosets_dev", "zkhip_extended_to_cosets_dev", "zkhip_cosets_to_extended_dev",
     "zkhip_batch_invert_dev", "zkhip_prefix_product_dev", "zkhip_prefix_product_noalloc_dev", "zkhip_permutation_product_dev", "zkhip_lookup_product_dev",
@@ -86,12 +87,14 @@ class EvalhDesc(C.Structure):
                 ("num_perm_sets", C.c_uint32), ("perm_product_cosets", C.POINTER(C.c_void_p)),
                 ("perm_chunk_len", C.c_uint32), ("blinding_factors", C.c_uint32),
                 ("num_cosets", C.c_uint32), ("cosets", C.c_void_p), ("basis", C.c_uint32),
-                ("row_first", C.c_uint32), ("row_count", C.c_uint32)]
+                ("row_first", C.c_uint32), ("row_count", C.c_uint32),
+                ("term_select", C.c_uint32), ("term_degree_max", C.c_uint32)]
 
 
 MEM_HOST, MEM_DEVICE = 0, 1
 FORM_COEFF, FORM_EXTENDED = 0, 1
 BASIS_EXTENDED, BASIS_LAGRANGE = 0, 1
+TERMS_ALL, TERMS_LOW, TERMS_HIGH = 0, 1, 2
 
 
 def _p(a):
@@ -568,6 +571,16 @@ class Domain:
     def coeff_to_extended_dev(self, d_coeff: int, d_out: int, batch: int = 1):
         self.ctx._ck(self._l.zkhip_coeff_to_extended_dev(self.h, C.c_void_p(d_coeff), C.c_void_p(d_out),
                                                          C.c_size_t(batch)))
+
+    def coeff_to_extended_split_dev(self, d_coeff: int, d_out: int, batch: int = 1):
+        """coeff_to_extended with each result split by row parity: even-indexed extended rows, then the odd-indexed ones
+        (the compact layouts of the even and of the odd cosets)"""
+        self.ctx._ck(self._l.zkhip_coeff_to_extended_split_dev(self.h, C.c_void_p(d_coeff), C.c_void_p(d_out),
+                                                               C.c_size_t(batch)))
+
+    def extend_half_dev(self, d_even: int, d_odd: int, batch: int = 1):
+        """values of a polynomial of degree < 2^(extended_k - 1) on the even-indexed extended rows -> on the odd-indexed"""
+        self.ctx._ck(self._l.zkhip_extend_half_dev(self.h, C.c_void_p(d_even), C.c_void_p(d_odd), C.c_size_t(batch)))
 
     def extended_to_coeff_dev(self, d_ext: int, d_out: int, batch: int = 1):
         self.ctx._ck(self._l.zkhip_extended_to_coeff_dev(self.h, C.c_void_p(d_ext), C.c_void_p(d_out),
