@@ -97,12 +97,24 @@ def test_bounded_footprint_gives_the_same_proof(ctx, setup):
     cosets need does) gives the same bytes as all cosets at once; the OS-entropy RNG gives a verifying proof"""
     k, cs, dom, params, pk, vk, advice, instance = setup
     proof = _prove(ctx, setup, advice, instance)
+    # coset groups need a key whose extended vectors are in extended order; a key with the vectors split by row parity
+    # (low-degree terms on half the domain) holds every coset at once and says so.  The bytes are the same either way.
+    _, _, fixed, asm = _witness(cs, dom.n, 7)
+    keys = {flag: prover.keygen(ctx, dom, params, cs, fixed, asm, low_degree_split=flag) for flag in (False, True)}
+    assert keys[True].polys.split and not keys[False].polys.split
+    assert prover.create_proof(ctx, dom, params, keys[True], advice, instance, prover.FieldRng(1), prover.Blake2bWrite()) == proof
+    assert prover.create_proof(ctx, dom, params, keys[False], advice, instance, prover.FieldRng(1), prover.Blake2bWrite()) == proof
     for groups in (2, 4):
-        got = prover.create_proof(ctx, dom, params, pk, advice, instance, prover.FieldRng(1), prover.Blake2bWrite(),
+        got = prover.create_proof(ctx, dom, params, keys[False], advice, instance, prover.FieldRng(1), prover.Blake2bWrite(),
                                   coset_groups=groups)
         assert got == proof, groups
     with pytest.raises(ValueError):
-        prover.create_proof(ctx, dom, params, pk, advice, instance, prover.FieldRng(1), prover.Blake2bWrite(), coset_groups=3)
+        prover.create_proof(ctx, dom, params, keys[False], advice, instance, prover.FieldRng(1), prover.Blake2bWrite(), coset_groups=3)
+    with pytest.raises(ValueError):
+        prover.create_proof(ctx, dom, params, keys[True], advice, instance, prover.FieldRng(1), prover.Blake2bWrite(), coset_groups=2)
+    for key in keys.values():
+        for p in key.pointers():
+            ctx.free(p)
     fresh = prover.create_proof(ctx, dom, params, pk, advice, instance, prover.OsFieldRng(), prover.Blake2bWrite())
     assert fresh != proof
     vm.verify_proof(cs, k, vk, instance, fresh, TAU)

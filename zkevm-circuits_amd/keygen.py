@@ -65,6 +65,7 @@ class ProvingKeyPolys:
         self.permutations, self.permutation_polys, self.permutation_cosets = [], [], []
         self.l0 = self.l_last = self.l_active_row = 0
         self.cosets = None     # None: the "coset" vectors are whole extended vectors; a list: compact layout of these cosets
+        self.split = False     # whole extended vectors stored split by row parity (even-indexed rows, then odd-indexed)
 
     def pointers(self):
         """every device block the key owns (a rank that evaluates no coset holds no extended vectors: those entries are 0)"""
@@ -73,15 +74,18 @@ class ProvingKeyPolys:
         return [p for p in every if p]
 
 
-def keygen_polys(ctx, dom, fixed_values, assembly: Assembly | None, blinding_factors: int, cosets=None) -> ProvingKeyPolys:
+def keygen_polys(ctx, dom, fixed_values, assembly: Assembly | None, blinding_factors: int, cosets=None,
+                 split: bool = False) -> ProvingKeyPolys:
     """fixed_values: list of (n, 4) Montgomery arrays (Lagrange basis).  Returns device-resident key polynomials; the
     caller frees `pointers()`.  cosets: a rank of a multi-GPU prover that evaluates only these cosets of the extended
     domain keeps the key's extended vectors (fixed_cosets, permutation_cosets, l0, l_last, l_active_row) in the compact
     layout of those cosets -- n * len(cosets) rows, straight from the coefficients, never forming the whole vector; an
-    empty list (a rank that owns no coset) leaves those entries 0."""
+    empty list (a rank that owns no coset) leaves those entries 0.  split (whole vectors only): the extended vectors are
+    stored split by row parity, the layout `evalh_host.evaluate_h_split` reads."""
     n, en = dom.n, dom.extended_len
     pk = ProvingKeyPolys()
     pk.cosets = list(cosets) if cosets is not None else None
+    pk.split = bool(split) and cosets is None
 
     def extend(d_poly):
         if pk.cosets is not None and not pk.cosets:
@@ -90,7 +94,10 @@ def keygen_polys(ctx, dom, fixed_values, assembly: Assembly | None, blinding_fac
             return 0
         if pk.cosets is None:
             d_coset = ctx.alloc(en * 32)
-            dom.coeff_to_extended_dev(d_poly, d_coset)
+            if pk.split:
+                dom.coeff_to_extended_split_dev(d_poly, d_coset)
+            else:
+                dom.coeff_to_extended_dev(d_poly, d_coset)
         else:
             d_coset = ctx.alloc(n * len(pk.cosets) * 32)
             dom.coeff_to_cosets_dev(d_poly, pk.cosets, d_coset)

@@ -241,16 +241,24 @@ class ProvingKey:
         self.fixed_commitments, self.permutation_commitments = [], []      # (x, y) integers
         self.transcript_repr = 0
         self.ev = None                        # plonk.Evaluator, built once per key as upstream's `ProvingKey::ev`
+        self.split_programs = None            # multiplications per row of the low / high / whole evaluate_h programs
 
     def pointers(self):
         return self.polys.pointers() + self.fixed_values
 
 
-def keygen(ctx, dom, params: ParamsKZG, cs: ConstraintSystem, fixed, assembly, dist=None) -> ProvingKey:
+SPLIT_MIN_LOW_SHARE = 0.08      # the half-domain evaluation is used when the low-degree terms hold this share of the products
+
+
+def keygen(ctx, dom, params: ParamsKZG, cs: ConstraintSystem, fixed, assembly, dist=None, low_degree_split=None) -> ProvingKey:
     """`keygen_vk` + `keygen_pk` for assigned fixed columns (lists of n canonical integers) and copy constraints.
     dist: an initialised torch.distributed module with one rank per GPU; every rank then keeps the key's extended vectors
     only on the cosets it evaluates in `create_proof(..., dist=dist)` (1 / world of them up to 2^e ranks), and such a key
-    proves only with the same process group."""
+    proves only with the same process group.
+    low_degree_split (single GPU): evaluate the terms of the quotient numerator whose degree is at most half the number of
+    cosets on the even-indexed half of the extended domain only (`evalh_host.evaluate_h_split`); the key's extended vectors
+    are then stored split by row parity.  None decides from the constraint system: on when those terms hold at least
+    SPLIT_MIN_LOW_SHARE of the program's multiplications.  The proof bytes do not depend on it."""
     n = dom.n
     if n < cs.minimum_rows():
         raise ValueError("not enough rows available")
@@ -265,7 +273,18 @@ def keygen(ctx, dom, params: ParamsKZG, cs: ConstraintSystem, fixed, assembly, d
     if dist is not None and dist.is_initialized() and dist.get_world_size() > 1:
         part = sharding.coset_partition(dom.extended_k, dom.k, dist.get_world_size())[dist.get_rank()]
         own = part[0] if part is not None else []
-    pk.polys = kg.keygen_polys(ctx, dom, fixed_limbs, assembly if cs.permutation_columns else None, cs.blinding_factors(), own)
+    split = False
+    if own is None and dom.extended_k > dom.k and low_degree_split is not False:
+        low, high, whole = evalh_host.split_gain(dom, cs, pk.ev)
+        pk.split_programs = {"low": low, "high": high, "whole": whole}
+        # the split evaluation holds every extended coset at once (no coset groups): it is chosen by itself only where
+        # the key's and the proof's extended vectors and the transform scratch of a batch fit the free memory
+        vectors = (cs.num_fixed_columns + len(cs.permutation_columns) + 3 + cs.num_advice_columns + cs.num_instance_columns
+                   + 3 * len(cs.lookups) + cs.num_permutation_sets() + 3 * 64 + 4)
+        fits = vectors * dom.extended_len * 32 <= 0.8 * ctx.mem_info()[0]
+        split = True if low_degree_split else (fits and whole > 0 and low >= SPLIT_MIN_LOW_SHARE * whole)
+    pk.polys = kg.keygen_polys(ctx, dom, fixed_limbs, assembly if cs.permutation_columns else None, cs.blinding_factors(), own,
+                               split=split)
     pk.fixed_values = [ctx.upload(a) for a in fixed_limbs]
     if pk.fixed_values:
         pk.fixed_commitments = [affine_ints(j) for j in params.commit_lagrange(pk.fixed_values)]
@@ -303,14 +322,29 @@ def save_proving_key(ctx, dom, pk: ProvingKey, path: str, layout: str = "v3") ->
         raise ValueError("a key generated for a multi-GPU partition holds only its rank's cosets")
     n, en = dom.n, dom.extended_len
     get = lambda ptrs, rows: [ctx.download(p, (rows, 4)) for p in ptrs]
+    if pk.polys.split:
+        # the file holds extended vectors in extended order: undo the split by row parity on the way out
+        m = en // n
+        d_tmp = ctx.alloc(en * 32)
+
+        def natural(p):
+            dom.cosets_to_extended_dev(p, list(range(0, m, 2)), d_tmp)
+            dom.cosets_to_extended_dev(p + en * 16, list(range(1, m, 2)), d_tmp)
+            return ctx.download(d_tmp, (en, 4))
+        ext = lambda ptrs: [natural(p) for p in ptrs]
+    else:
+        natural = lambda p: ctx.download(p, (en, 4))
+        ext = lambda ptrs: get(ptrs, en)
     vk = formats.VerifyingKeyRaw(dom.k, [_point_limbs(c) for c in pk.fixed_commitments] or np.zeros((0, 8), np.uint64),
                                  [_point_limbs(c) for c in pk.permutation_commitments] or np.zeros((0, 8), np.uint64))
     raw = formats.ProvingKeyRaw(
-        vk, l0=ctx.download(pk.polys.l0, (en, 4)), l_last=ctx.download(pk.polys.l_last, (en, 4)),
-        l_active_row=ctx.download(pk.polys.l_active_row, (en, 4)), fixed_values=get(pk.fixed_values, n),
-        fixed_polys=get(pk.polys.fixed_polys, n), fixed_cosets=get(pk.polys.fixed_cosets, en),
+        vk, l0=natural(pk.polys.l0), l_last=natural(pk.polys.l_last),
+        l_active_row=natural(pk.polys.l_active_row), fixed_values=get(pk.fixed_values, n),
+        fixed_polys=get(pk.polys.fixed_polys, n), fixed_cosets=ext(pk.polys.fixed_cosets),
         permutations=get(pk.polys.permutations, n), permutation_polys=get(pk.polys.permutation_polys, n),
-        permutation_cosets=get(pk.polys.permutation_cosets, en))
+        permutation_cosets=ext(pk.polys.permutation_cosets))
+    if pk.polys.split:
+        ctx.free(d_tmp)
     formats.write_proving_key_raw(path, raw, layout)
 
 
@@ -423,6 +457,11 @@ def create_proof(ctx, dom, params: ParamsKZG, pk: ProvingKey, advice, instance, 
         # coefficient (`early_coeff`, moved over the Lagrange form when the quotient phase starts) and extended.
         BATCH = 64
         sharded = dist is not None and dist.is_initialized() and dist.get_world_size() > 1
+        split = bool(pk.polys.split)       # extended vectors split by row parity: low-degree terms on half the domain
+        if split and (sharded or coset_groups not in (None, 1)):
+            raise ValueError("the proving key stores its extended vectors split by row parity (keygen(..., low_degree_split)): "
+                             "it proves on one GPU with every coset resident")
+        to_extended = dom.coeff_to_extended_split_dev if split else dom.coeff_to_extended_dev
         early_ext = early_coeff = None
         early_done = set()
         if (not sharded and coset_groups in (None, 1) and pk.polys.cosets is None and n_adv
@@ -444,7 +483,7 @@ def create_proof(ctx, dom, params: ParamsKZG, pk: ProvingKey, advice, instance, 
                 c0, cnt = cols[i], j - i + 1
                 ctx.copy_dev(early_coeff + c0 * n * 32, adv[c0], cnt * n * 32)
                 dom.lagrange_to_coeff_dev(early_coeff + c0 * n * 32, cnt)
-                dom.coeff_to_extended_dev(early_coeff + c0 * n * 32, early_ext + c0 * en * 32, cnt)
+                to_extended(early_coeff + c0 * n * 32, early_ext + c0 * en * 32, cnt)
                 early_done.update(cols[i:j + 1])
                 i = j + 1
 
@@ -619,8 +658,8 @@ def create_proof(ctx, dom, params: ParamsKZG, pk: ProvingKey, advice, instance, 
             # (what the ranks of the multi-GPU split do side by side), which holds 1 / groups of the cosets at a time.
             free_bytes = ctx.mem_info()[0]
             m = en // n
-            if early_ext is not None:
-                coset_groups = 1                   # the block of all extended cosets is already there
+            if early_ext is not None or split:
+                coset_groups = 1                   # the block of all extended cosets is already there (or has to be)
             if coset_groups is None:
                 coset_groups = 1
                 while coset_groups < m and (en // coset_groups) * 32 * (total + 3 * BATCH) > 0.85 * free_bytes:
@@ -631,10 +670,13 @@ def create_proof(ctx, dom, params: ParamsKZG, pk: ProvingKey, advice, instance, 
         if not sharded and coset_groups == 1:
             ext_block = early_ext if early_ext is not None else alloc(en * max(total, 1))
             for s0, cnt in runs(todo):
-                dom.coeff_to_extended_dev(slot[s0], ext_block + s0 * en * 32, cnt)
+                to_extended(slot[s0], ext_block + s0 * en * 32, cnt)
             fill(lambda p: ext_block + (p - block) // (n * 32) * en * 32, lambda p: p)
             mark("quotient_evaluate_h")
-            dom.evaluate_h(call.build(ffi.MEM_DEVICE, ffi.FORM_EXTENDED), d_h)
+            if split:
+                evalh_host.evaluate_h_split(ctx, dom, call, d_h)
+            else:
+                dom.evaluate_h(call.build(ffi.MEM_DEVICE, ffi.FORM_EXTENDED), d_h)
         elif not sharded:
             mark("quotient_evaluate_h")
             for g in range(coset_groups):
