@@ -516,6 +516,7 @@ def measure_create_proof(ctx, bid, dist_=None):
         seconds = float(t.cpu()[0])
     return {"seconds": seconds, "ranks": ranks, "keygen_seconds": keygen_seconds, "phases_s": phases, "proof_bytes": len(proof),
             "peak_device_GB_this_rank": (ctx.peak_allocated_bytes - resident0) / 1e9,
+            "evaluate_h_low_degree_split": {"used": bool(pk.polys.split), "multiplications_per_row": pk.split_programs},
             "shape": {"k": k, "extended_k": dom.extended_k, "advice": cs.num_advice_columns, "fixed": cs.num_fixed_columns,
                       "lookups": len(cs.lookups), "widest_lookup": max(len(lk.input_expressions) for lk in cs.lookups),
                       "permutation_columns": len(cs.permutation_columns), "blinding_factors": cs.blinding_factors(),

@@ -72,6 +72,7 @@ def main():
     ap.add_argument("--perm-cols", type=int, default=census["permutation_columns"])
     ap.add_argument("--degree", type=int, default=census["degree"])
     ap.add_argument("--gate-polys", type=int, default=3000)
+    ap.add_argument("--no-split", action="store_true", help="evaluate every term of the quotient numerator on every row")
     ap.add_argument("--reference-log", metavar="PATH",
                     help="also write the summary / Start / End lines the reference's benchmark prints "
                          "(zkevm-circuits/benches/benchmark_list/main.rs:44-52,68-71,236-245), with the replay's total as "
@@ -207,18 +208,32 @@ def main():
     ph.run("random_poly_commit_msm", lambda: ctx.msm_range_dev(bid, 0, colptr(advice, 0, n), n))
 
     # ---- 4. quotient ------------------------------------------------------------------------------------
+    # Low-degree terms on half the extended domain (zkevm_circuits_amd/evalh_host.py: evaluate_h_split), under the rule
+    # `prover.keygen` applies: on when the terms of degree <= (number of cosets) / 2 hold enough of the program's products.
+    # The extended vectors are then stored split by row parity (the key's would be, from key generation on).
+    from zkevm_circuits_amd import prover as _prover
+    split_programs = None
+    split = False
+    if not args.no_split and ek > k:
+        low, high, whole = evalh_host.split_gain(dom, cs, call.ev)
+        split_programs = {"low": low, "high": high, "whole": whole}
+        split = whole > 0 and low >= _prover.SPLIT_MIN_LOW_SHARE * whole
+    to_ext = dom.coeff_to_extended_split_dev if split else dom.coeff_to_extended_dev
+    if split:
+        evalh_host.warm_up_split(ctx, dom)          # as key generation does: twiddle tables of the half-size transforms
+
     # coefficient polynomials -> extended cosets (advice | instance | per lookup z, a', s' | perm z)
     def extend_all():
         o = 0
-        batched(lambda s, c: dom.coeff_to_extended_dev(colptr(advice, s, n), colptr(ext, o + s, en), c), A)
+        batched(lambda s, c: to_ext(colptr(advice, s, n), colptr(ext, o + s, en), c), A)
         o += A
-        dom.coeff_to_extended_dev(instance.data_ptr(), colptr(ext, o, en), I)
+        to_ext(instance.data_ptr(), colptr(ext, o, en), I)
         o += I
         for i in range(L):
-            dom.coeff_to_extended_dev(colptr(lk_z, i, n), colptr(ext, o + 3 * i, en), 1)
-            dom.coeff_to_extended_dev(colptr(lk_cols, 4 * i + 2, n), colptr(ext, o + 3 * i + 1, en), 2)
+            to_ext(colptr(lk_z, i, n), colptr(ext, o + 3 * i, en), 1)
+            to_ext(colptr(lk_cols, 4 * i + 2, n), colptr(ext, o + 3 * i + 1, en), 2)
         o += 3 * L
-        dom.coeff_to_extended_dev(perm_z.data_ptr(), colptr(ext, o, en), sets)
+        to_ext(perm_z.data_ptr(), colptr(ext, o, en), sets)
     ph.run("coeff_to_extended", extend_all)
 
     call.fixed = [colptr(fixed_ext, i, en) for i in range(F)]
@@ -236,9 +251,15 @@ def main():
     host_setup_s += time.perf_counter() - t0
     ctx.timing_enable(True)
     ctx.timing_reset()
-    ph.run("evaluate_h", lambda: dom.evaluate_h(desc, h.data_ptr()))
-    evalh_kernel_ms = ctx.timing_get("evalh")[0] / 1e3
-    evalh_program = ctx.evaluate_h_last_stats()
+    if split:
+        ph.run("evaluate_h", lambda: evalh_host.evaluate_h_split(ctx, dom, call, h.data_ptr()))
+        k_us, k_n = ctx.timing_get("evalh")
+        evalh_kernel_ms = k_us * k_n / 1e3                       # the three launches together
+        evalh_program = dict(ctx.evaluate_h_last_stats(), note="the last of three programs (high-degree terms); see split_programs")
+    else:
+        ph.run("evaluate_h", lambda: dom.evaluate_h(desc, h.data_ptr()))
+        evalh_kernel_ms = ctx.timing_get("evalh")[0] / 1e3
+        evalh_program = ctx.evaluate_h_last_stats()
     ctx.timing_enable(False)
     ph.run("divide_by_vanishing_poly", lambda: dom.divide_by_vanishing_poly_dev(h.data_ptr()))
     ph.run("extended_to_coeff", lambda: dom.extended_to_coeff_dev(h.data_ptr(), h_coeff.data_ptr()))
@@ -308,7 +329,10 @@ def main():
                                   "estimate (the census counts create_gate calls: "
                                   f"{census['create_gate_calls']})"},
         "total_s": total, "phases_s": ph.t, "msm_count": n_msm, "msm_total_s": msm_s, "msm_ms_each": msm_s / n_msm * 1e3,
-        "coset_ntt_count": A + I + 3 * L + sets, "evalh_kernel_ms": evalh_kernel_ms, "evalh_program": evalh_program, "eval_polynomial_count": n_queries,
+        "coset_ntt_count": A + I + 3 * L + sets, "evalh_kernel_ms": evalh_kernel_ms, "evalh_program": evalh_program,
+        "evaluate_h_low_degree_split": {"used": split, "multiplications_per_row": split_programs,
+                                        "what": "terms of degree <= cosets / 2 evaluated on the even-indexed rows only and "
+                                                "extended by two half-size transforms"}, "eval_polynomial_count": n_queries,
         "shplonk": {"polynomials": len(shapes), "queries": n_queries, "poly_lincomb_calls": lincomb_n,
                     "poly_lincomb_avg_us": lincomb_us, "kate_division_calls": kate_n, "kate_division_avg_us": kate_us},
         "host_program_build_s": host_setup_s,

@@ -141,6 +141,17 @@ def split_gain(dom, cs: ConstraintSystem, ev: Evaluator):
     return low["multiplications"], high["multiplications"], whole["multiplications"]
 
 
+def warm_up_split(ctx, dom):
+    """Key-generation step of the split evaluation: the transforms of half the extended size get their twiddle tables now
+    (built once per context and size), not inside the first proof."""
+    half = dom.extended_len // 2
+    d = ctx.alloc(2 * half * 32)
+    ctx.upload(np.zeros((1, 4), dtype=np.uint64), d)              # contents are irrelevant; any residues transform
+    dom.extend_half_dev(d, d + half * 32)
+    ctx.sync()
+    ctx.free(d)
+
+
 def shifted(call: EvalhCall, offset: int) -> EvalhCall:
     """a copy of a device-memory call with `offset` bytes added to every extended-vector pointer"""
     import copy

@@ -247,7 +247,8 @@ class ProvingKey:
         return self.polys.pointers() + self.fixed_values
 
 
-SPLIT_MIN_LOW_SHARE = 0.08      # the half-domain evaluation is used when the low-degree terms hold this share of the products
+SPLIT_MIN_LOW_SHARE = 0.15      # the half-domain evaluation is used when the low-degree terms hold this share of the products
+                                # (measured: a share of 0.13 at four cosets loses 2 %, 0.18 at eight gains 6.5 %, 0.35 gains 17 %)
 
 
 def keygen(ctx, dom, params: ParamsKZG, cs: ConstraintSystem, fixed, assembly, dist=None, low_degree_split=None) -> ProvingKey:
@@ -285,6 +286,8 @@ def keygen(ctx, dom, params: ParamsKZG, cs: ConstraintSystem, fixed, assembly, d
         split = True if low_degree_split else (fits and whole > 0 and low >= SPLIT_MIN_LOW_SHARE * whole)
     pk.polys = kg.keygen_polys(ctx, dom, fixed_limbs, assembly if cs.permutation_columns else None, cs.blinding_factors(), own,
                                split=split)
+    if split:
+        evalh_host.warm_up_split(ctx, dom)
     pk.fixed_values = [ctx.upload(a) for a in fixed_limbs]
     if pk.fixed_values:
         pk.fixed_commitments = [affine_ints(j) for j in params.commit_lagrange(pk.fixed_values)]
