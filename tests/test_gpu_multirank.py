@@ -247,3 +247,66 @@ def test_ranks_create_the_same_proof_as_one(world):
             assert peak_sharded < (share + 0.3) * peak_whole, (peak_sharded, peak_whole, share)
         print(f"world {world}, extended domain 2^{e} n: peak resident {peak_sharded / 1e6:.1f} MB per rank sharded, "
               f"{peak_whole / 1e6:.1f} MB single rank")
+
+
+def _rccl_worker(port, q):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for p in (root, os.path.join(root, "oracle"), os.path.join(root, "tests")):
+        sys.path.insert(0, p)
+    import torch
+    import zkhip_pkg
+    zk = zkhip_pkg.load()
+    from zkevm_circuits_amd import sharding
+    from util import rand_fr
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    try:
+        torch.cuda.set_device(0)
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+        ctx = zk.Context(0)
+        n, ncols = 1 << 10, 3
+        rng = np.random.default_rng(7)
+        bid = ctx.register_bases(ctx.g1_multiples(n))
+        d_cols = [ctx.upload(rand_fr(rng, n)) for _ in range(ncols)]
+        single = [ctx.msm_range_dev(bid, 0, d, n) for d in d_cols]
+        # the three exchanges of the prover over RCCL: device tensors in, device tensors out
+        allc = sharding.gather_commitments({c: single[c] for c in range(ncols)}, ncols, dist)
+        split = sharding.msm_base_split(n, lambda first, cnt: ctx.msm_range_dev(bid, first, d_cols[0] + 32 * first, cnt),
+                                        ctx.g1_sum_jacobian, dist, device=torch.device("cuda", 0))
+        piece = torch.arange(4 * 4 * n, dtype=torch.int64, device="cuda").reshape(-1, 4)
+        pieces = sharding.evaluate_h_by_cosets(12, 10, lambda cosets, first, count: piece, dist)
+        t = torch.ones(8, dtype=torch.int64, device="cuda")
+        dist.broadcast(t, src=0)
+        dist.barrier()
+        ok = (np.array_equal(allc, np.stack(single)) and np.array_equal(ctx.g1_to_affine(split), ctx.g1_to_affine(single[0]))
+              and len(pieces) == 1 and pieces[0][0] == [0, 1, 2, 3] and torch.equal(pieces[0][2], piece)
+              and pieces[0][2].is_cuda and dist.get_backend() == "nccl")
+        q.put(bool(ok))
+        ctx.close()
+    except Exception:
+        import traceback
+        q.put(f"failed:\n{traceback.format_exc()}")
+        raise
+    finally:
+        if dist.is_initialized():
+            dist.destroy_process_group()
+
+
+def test_rccl_backend_carries_the_exchanges_on_one_rank():
+    """The prover's exchanges (commitment table, partial sums of a split MSM, pieces of h, a broadcast) through the RCCL
+    backend itself, which needs one GPU per rank: a world of one rank on this GPU.  The library is initialised, the
+    collectives run on device tensors, and the results equal the local values."""
+    mpctx = mp.get_context("spawn")
+    q = mpctx.Queue()
+    p = mpctx.Process(target=_rccl_worker, args=(_free_port(), q))
+    p.start()
+    try:
+        result = q.get(timeout=240)
+    finally:
+        p.join(timeout=60)
+        if p.is_alive():
+            p.kill()
+    assert result is True, result
+    assert p.exitcode == 0

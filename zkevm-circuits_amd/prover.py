@@ -211,20 +211,24 @@ class ParamsKZG:
         self.ctx, self.k, self.n, self.g, self.g_lagrange = ctx, dom.k, dom.n, g, g_lagrange
         return self
 
-    def _commit(self, bid, d_polys, dist):
+    def _commit(self, bid, d_polys, dist, owners=None):
         d_polys = list(d_polys)
         if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
             return self.ctx.msm_batch_dev(bid, d_polys, self.n)
-        # columns are independent: rank r commits columns r, r + world, ..; the points are gathered in column order
-        mine = sharding.columns_for_rank(len(d_polys), dist.get_rank(), dist.get_world_size())
+        # columns are independent: every rank commits the columns it owns (contiguous blocks, `sharding.column_blocks`,
+        # unless the caller names the owner of every column: then only the owner needs to hold the column at all); the
+        # points are gathered in column order
+        if owners is None:
+            owners = sharding.block_owner(len(d_polys), dist.get_world_size())
+        mine = [c for c, r in enumerate(owners) if r == dist.get_rank()]
         local = self.ctx.msm_batch_dev(bid, [d_polys[c] for c in mine], self.n) if mine else []
         return sharding.gather_commitments(dict(zip(mine, local)), len(d_polys), dist)
 
-    def commit(self, d_polys, dist=None):
-        return self._commit(self.g, d_polys, dist)
+    def commit(self, d_polys, dist=None, owners=None):
+        return self._commit(self.g, d_polys, dist, owners)
 
-    def commit_lagrange(self, d_polys, dist=None):
-        return self._commit(self.g_lagrange, d_polys, dist)
+    def commit_lagrange(self, d_polys, dist=None, owners=None):
+        return self._commit(self.g_lagrange, d_polys, dist, owners)
 
     def close(self):
         self.ctx.release_bases(self.g)
@@ -391,10 +395,14 @@ def create_proof(ctx, dom, params: ParamsKZG, pk: ProvingKey, advice, instance, 
     synthesis per phase (only the phase's own columns are read from it); instance: per column at most that many
     canonical integers.  Writes the proof into `transcript` and returns its bytes.  timings: filled with the wall
     seconds of each phase (the device is synchronised at every phase boundary, only when given).
-    dist: an initialised torch.distributed module with one rank per GPU: every rank calls with the same arguments, the
-    commitments are computed column-sharded and the quotient numerator coset-sharded (zkevm_circuits_amd/sharding.py), the
-    rest is replicated; every rank returns the same bytes as a single-rank call.  A rank that raises (a lookup input
-    outside its table, say) does so on every rank alike, since all ranks hold the same witness.
+    dist: an initialised torch.distributed module with one rank per GPU: every rank calls with the same arguments.  Sharded
+    by column (contiguous blocks of columns per rank): the upload of the witness, every commitment, and -- by lookup -- the
+    compression, the permuted columns, the grand product and the coefficient forms of a lookup's three polynomials;
+    sharded by coset: the quotient numerator (zkevm_circuits_amd/sharding.py).  Exchanged: the uploaded advice columns and
+    the lookups' polynomials (one broadcast per owner and phase, 2^k-sized vectors), the commitments (96 bytes each), the
+    pieces of h.  Replicated: the transcript and the RNG (every rank draws every value, so the streams stay in step), the
+    permutation argument, the evaluations and the multi-open.  Every rank returns the same bytes as a single-rank call.
+    A lookup input outside its table raises on the lookup's owner; the other ranks then fail in the next collective.
     coset_groups (single rank): evaluate the quotient numerator in that many passes over disjoint coset groups, which
     bounds the resident extended data to 1 / coset_groups of the whole; None picks the smallest count that fits the free
     device memory (1 on a whole MI355X at the SuperCircuit's width).  The proof bytes do not depend on it."""
@@ -437,8 +445,11 @@ def create_proof(ctx, dom, params: ParamsKZG, pk: ProvingKey, advice, instance, 
         many = getattr(rng, "fr_many", None)
         return many(count) if many else [rng.fr() for _ in range(count)]
 
-    def blind_rows(d_col, first_row):
-        ctx.upload(fr_limbs(draws(n - first_row)), d_col + first_row * 32)
+    def blind_rows(d_col, first_row, own=True):
+        """the blinding rows of a column from the RNG; a rank that does not hold the column still draws them"""
+        vals = draws(n - first_row)
+        if own:
+            ctx.upload(fr_limbs(vals), d_col + first_row * 32)
 
     try:
         # ---- instances and advice ---------------------------------------------------------------------------
@@ -448,8 +459,32 @@ def create_proof(ctx, dom, params: ParamsKZG, pk: ProvingKey, advice, instance, 
         # those transforms run as batches: advice | instance | per lookup (z, a', s') | permutation z
         n_adv, n_inst, n_lk, sets = cs.num_advice_columns, len(instance), len(cs.lookups), cs.num_permutation_sets()
         total = n_adv + n_inst + 3 * n_lk + sets
-        block = alloc(n * max(total, 1))
+        sharded = dist is not None and dist.is_initialized() and dist.get_world_size() > 1
+        rank, world = (dist.get_rank(), dist.get_world_size()) if sharded else (0, 1)
+        if sharded:
+            # the block is a tensor of the collective library's framework, so that ranges of it can be broadcast
+            import torch
+            t_block = torch.empty((n * max(total, 1), 4), dtype=torch.int64, device="cuda")
+            torch.cuda.synchronize()
+            block = t_block.data_ptr()
+        else:
+            block = alloc(n * max(total, 1))
         slot = [block + i * n * 32 for i in range(total)]
+
+        def exchange(slots_by_owner):
+            """slots_by_owner[r]: the slots of the block that rank r has filled; afterwards every rank holds them all
+            (maximal runs of neighbouring slots travel as one broadcast each)"""
+            ctx.sync()
+            for r, owned_slots in enumerate(slots_by_owner):
+                owned_slots = sorted(owned_slots)
+                i = 0
+                while i < len(owned_slots):
+                    j = i
+                    while j + 1 < len(owned_slots) and owned_slots[j + 1] == owned_slots[j] + 1:
+                        j += 1
+                    dist.broadcast(t_block[owned_slots[i] * n:(owned_slots[j] + 1) * n], src=r)
+                    i = j + 1
+            torch.cuda.synchronize()
         adv, inst = slot[:n_adv], slot[n_adv:n_adv + n_inst]
         lk_slots = [slot[n_adv + n_inst + 3 * i:n_adv + n_inst + 3 * i + 3] for i in range(n_lk)]
         perm_z = slot[total - sets:]
@@ -459,7 +494,6 @@ def create_proof(ctx, dom, params: ParamsKZG, pk: ProvingKey, advice, instance, 
         # exists in three forms: Lagrange (where it was uploaded: lookups and the permutation argument read it),
         # coefficient (`early_coeff`, moved over the Lagrange form when the quotient phase starts) and extended.
         BATCH = 64
-        sharded = dist is not None and dist.is_initialized() and dist.get_world_size() > 1
         split = bool(pk.polys.split)       # extended vectors split by row parity: low-degree terms on half the domain
         if split and (sharded or coset_groups not in (None, 1)):
             raise ValueError("the proving key stores its extended vectors split by row parity (keygen(..., low_degree_split)): "
@@ -507,8 +541,24 @@ def create_proof(ctx, dom, params: ParamsKZG, pk: ProvingKey, advice, instance, 
                 if len(col) != usable or (isinstance(col, np.ndarray) and (col.dtype != np.uint64 or col.shape != (usable, 4))):
                     raise ValueError("an advice column holds the usable rows (integers, or (usable rows, 4) uint64 limbs)")
             points = []
-            if columns and all(isinstance(assigned[c], np.ndarray) and assigned[c].flags.c_contiguous
-                               and ctx.is_pinned(assigned[c]) for c in columns):
+            if sharded and columns:
+                # every rank uploads and commits its block of the phase's columns, then the blocks are exchanged (the
+                # lookups and the permutation argument read every column); the blinding rows are drawn by every rank
+                owner = sharding.block_owner(len(columns), world)
+                for c, r in zip(columns, owner):
+                    col, d = assigned[c], adv[c]
+                    blinding = draws(n - usable)
+                    if r != rank:
+                        continue
+                    if isinstance(col, np.ndarray):
+                        ctx.upload(col, d)
+                        ctx.upload(fr_limbs(blinding), d + usable * 32)
+                    else:
+                        ctx.upload(np.concatenate([fr_limbs(col), fr_limbs(blinding)]), d)
+                points.extend(params.commit_lagrange([adv[c] for c in columns], dist, owner))
+                exchange([[c for c, o in zip(columns, owner) if o == r] for r in range(world)])
+            elif columns and all(isinstance(assigned[c], np.ndarray) and assigned[c].flags.c_contiguous
+                                 and ctx.is_pinned(assigned[c]) for c in columns):
                 # page-locked columns: the copies of one group of columns run on the transfer stream while the group
                 # before it is committed, so that the link and the multiplier work side by side
                 GROUP = 32
@@ -556,25 +606,34 @@ def create_proof(ctx, dom, params: ParamsKZG, pk: ProvingKey, advice, instance, 
 
         # ---- lookups: compressed expressions, permuted columns ----------------------------------------------
         mark("lookup_permuted")
+        # With several ranks a lookup belongs to one of them (contiguous blocks of lookups): its owner compresses, sorts,
+        # blinds, multiplies up and commits; the other ranks only advance the RNG and receive the three polynomials in
+        # coefficient form before the quotient phase.
+        lk_owner = sharding.block_owner(n_lk, world) if sharded else [0] * n_lk
         lookups = []
-        for lk, (_, d_pa, d_ps) in zip(cs.lookups, lk_slots):
+        for lk, (_, d_pa, d_ps), o in zip(cs.lookups, lk_slots, lk_owner):
+            if o != rank:
+                lookups.append([0, 0, d_pa, d_ps, 0])
+                continue
             d_in, d_tb = alloc(n), alloc(n)
             for exprs, d_out in ((lk.input_expressions, d_in), (lk.table_expressions, d_tb)):
                 call = evalh_host.lookup_compress_call(cs, exprs, pk.fixed_values, adv, inst, ch_limbs, limb(theta))
                 dom.evaluate_h(call.build(ffi.MEM_DEVICE, ffi.FORM_EXTENDED), d_out)
             lookups.append([d_in, d_tb, d_pa, d_ps, 0])
+        mine = [lk for lk, o in zip(lookups, lk_owner) if o == rank]
         # the permuted columns of all lookups in one sequence of launches; blinding rows and blinds in upstream's order
-        if lookups:
-            dom.lookup_permute_batch_dev([lk[0] for lk in lookups], [lk[1] for lk in lookups], usable,
-                                         [lk[2] for lk in lookups], [lk[3] for lk in lookups])
-        for _, _, d_pa, d_ps, _ in lookups:
-            blind_rows(d_pa, usable)
-            blind_rows(d_ps, usable)
+        if mine:
+            dom.lookup_permute_batch_dev([lk[0] for lk in mine], [lk[1] for lk in mine], usable,
+                                         [lk[2] for lk in mine], [lk[3] for lk in mine])
+        for (_, _, d_pa, d_ps, _), o in zip(lookups, lk_owner):
+            blind_rows(d_pa, usable, o == rank)
+            blind_rows(d_ps, usable, o == rank)
             rng.fr(), rng.fr()
         # no challenge is squeezed between the lookups, so their commitments go out as one pipelined batch, written in
         # upstream's order (a' then s' of each lookup)
         if lookups:
-            for jac in params.commit_lagrange([p for lk in lookups for p in (lk[2], lk[3])], dist):
+            for jac in params.commit_lagrange([p for lk in lookups for p in (lk[2], lk[3])], dist,
+                                              [o for o in lk_owner for _ in range(2)]):
                 transcript.write_point(jac)
         beta = transcript.squeeze_challenge()
         gamma = transcript.squeeze_challenge()
@@ -599,13 +658,14 @@ def create_proof(ctx, dom, params: ParamsKZG, pk: ProvingKey, advice, instance, 
 
         # ---- lookup grand products --------------------------------------------------------------------------
         mark("lookup_product")
-        for lk, (d_z, _, _) in zip(lookups, lk_slots):
-            dom.lookup_product_dev(lk[0], lk[1], lk[2], lk[3], limb(beta), limb(gamma), d_z)
-            blind_rows(d_z, usable + 1)
+        for lk, (d_z, _, _), o in zip(lookups, lk_slots, lk_owner):
+            if o == rank:
+                dom.lookup_product_dev(lk[0], lk[1], lk[2], lk[3], limb(beta), limb(gamma), d_z)
+            blind_rows(d_z, usable + 1, o == rank)
             rng.fr()
             lk[4] = d_z
         if lookups:
-            for jac in params.commit_lagrange([lk[4] for lk in lookups], dist):
+            for jac in params.commit_lagrange([lk[4] for lk in lookups], dist, lk_owner):
                 transcript.write_point(jac)
 
         # ---- vanishing argument: random polynomial ----------------------------------------------------------
@@ -633,6 +693,14 @@ def create_proof(ctx, dom, params: ParamsKZG, pk: ProvingKey, advice, instance, 
                 i = j + 1
             return out
 
+        if sharded and n_lk:
+            # a lookup's polynomials go to coefficient form on its owner and reach the other ranks in that form
+            lk0 = n_adv + n_inst
+            mine_slots = [lk0 + 3 * i + j for i, o in enumerate(lk_owner) if o == rank for j in range(3)]
+            for s0, cnt in runs(mine_slots):
+                dom.lagrange_to_coeff_dev(slot[s0], cnt)
+            exchange([[lk0 + 3 * i + j for i, o in enumerate(lk_owner) if o == r for j in range(3)] for r in range(world)])
+            todo = [i for i in todo if not lk0 <= i < lk0 + 3 * n_lk]
         for s0, cnt in runs(todo):
             dom.lagrange_to_coeff_dev(slot[s0], cnt)
         for c0, cnt in runs(sorted(early_done)):                     # their coefficient form replaces the Lagrange form

@@ -36,27 +36,42 @@ def cosets_for_rank(extended_k: int, k: int, rank: int, world: int):
     return list(range(rank, m, world))
 
 
+def column_blocks(num_columns: int, world: int):
+    """Contiguous column ownership: [(first, count)] per rank, sizes differing by at most one.  The prover uses blocks
+    rather than the round-robin of `columns_for_rank` where the owners' results are polynomials that every rank needs
+    afterwards: a rank's columns are then one contiguous range of the polynomial block, i.e. one broadcast."""
+    return [base_range_for_rank(num_columns, r, world) for r in range(world)]
+
+
+def block_owner(num_columns: int, world: int):
+    """owner rank of every column under `column_blocks`"""
+    out = []
+    for r, (_, count) in enumerate(column_blocks(num_columns, world)):
+        out += [r] * count
+    return out
+
+
+def _on_group_device(t, dist):
+    """RCCL moves device memory only: the tensor goes to this rank's GPU under the nccl backend"""
+    return t.cuda() if dist.get_backend() == "nccl" else t
+
+
 def gather_commitments(local: dict, num_columns: int, dist=None):
-    """local: {column index: 12-limb Jacobian}.  Returns the (num_columns, 12) array in column order on every
-    rank (transcript order must not depend on the partition)."""
+    """local: {column index: 12-limb Jacobian} of the columns this rank committed, under any partition in which every
+    column has exactly one owner.  Returns the (num_columns, 12) array in column order on every rank (transcript order
+    must not depend on the partition): one all-reduce of the table in which every rank has filled in its own rows and
+    left the others zero (a sum of one value and zeros; the limbs travel as 32-bit halves in 64-bit lanes, so the sum
+    cannot wrap whatever the backend's integer type)."""
     out = np.zeros((num_columns, 12), dtype=np.uint64)
     for c, v in local.items():
         out[c] = v
-    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+    if dist is None or not dist.is_initialized():
         return out
     import torch
-    world = dist.get_world_size()
-    mine = torch.from_numpy(out.view(np.int64).copy())
-    if dist.get_backend() == "nccl":            # RCCL moves device memory only
-        mine = mine.cuda()
-    gathered = [torch.empty_like(mine) for _ in range(world)]
-    dist.all_gather(gathered, mine)
-    res = np.zeros_like(out)
-    for r, g in enumerate(gathered):
-        arr = g.cpu().numpy().view(np.uint64)
-        for c in columns_for_rank(num_columns, r, world):
-            res[c] = arr[c]
-    return res
+    halves = out.view(np.uint32).astype(np.int64)                  # (num_columns, 24), every entry below 2^32
+    t = _on_group_device(torch.from_numpy(halves), dist)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return np.ascontiguousarray(t.cpu().numpy().astype(np.uint32)).view(np.uint64).reshape(num_columns, 12)
 
 
 def msm_base_split(n: int, msm_range, fold, dist=None, device=None):
@@ -64,19 +79,17 @@ def msm_base_split(n: int, msm_range, fold, dist=None, device=None):
 
     msm_range(first, count) -> 12-limb Jacobian partial of this rank's range;
     fold(array of partials (G, 12)) -> 12-limb Jacobian sum.  Every rank returns the full result."""
-    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+    if dist is None or not dist.is_initialized():
         return fold(np.asarray(msm_range(0, n), dtype=np.uint64).reshape(1, 12))
     import torch
     rank, world = dist.get_rank(), dist.get_world_size()
     first, count = base_range_for_rank(n, rank, world)
     part = np.asarray(msm_range(first, count), dtype=np.uint64).reshape(12)
     t = torch.from_numpy(part.view(np.int64).copy())
-    if device is not None:
-        t = t.to(device)
-    gathered = [torch.empty_like(t) for _ in range(world)]
-    dist.all_gather(gathered, t)
-    parts = np.stack([g.cpu().numpy().view(np.uint64) for g in gathered])
-    return fold(parts)
+    t = t.to(device) if device is not None else _on_group_device(t, dist)
+    gathered = torch.empty((world, 12), dtype=torch.int64, device=t.device)
+    dist.all_gather(list(gathered.unbind(0)), t)
+    return fold(gathered.cpu().numpy().view(np.uint64))
 
 
 def coset_partition(extended_k: int, k: int, world: int):
@@ -116,7 +129,7 @@ def evaluate_h_by_cosets(extended_k: int, k: int, evaluate, dist=None):
     total), the only exchange this phase needs.  Ranks beyond the largest power of two own nothing and only take part in
     the collective."""
     e = extended_k - k
-    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+    if dist is None or not dist.is_initialized():
         cosets = list(range(1 << e))
         return [(cosets, 0, evaluate(cosets, 0, (1 << k) * len(cosets)))]
     import torch
