@@ -110,7 +110,19 @@ def collect_queries(cs):
     names = {3: "advice", 2: "fixed", 4: "instance"}     # Any::{Advice, Fixed, Instance} as the constraint system numbers them
     for kind, idx in cs.permutation_columns:
         add(names[kind], (idx, 0))
-    return out["advice"], out["fixed"], out["instance"]
+    # a constraint system that carries its own query lists (the order of the circuit's first query_* calls, as upstream's
+    # ConstraintSystem records it) is read in that order, like upstream's verifier reads `cs.advice_queries`
+    res = []
+    for kind in ("advice", "fixed", "instance"):
+        given = getattr(cs, kind + "_queries", None)
+        if given is not None:
+            given = [tuple(q) for q in given]
+            if len(set(given)) != len(given) or not set(out[kind]) <= set(given):
+                raise VerifyError(kind + "_queries does not list every query once")
+            res.append(given)
+        else:
+            res.append(out[kind])
+    return tuple(res)
 
 
 def eval_expression(e, ev, challenges):

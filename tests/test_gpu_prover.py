@@ -370,3 +370,40 @@ def test_two_phase_circuit(ctx, co):
         ctx.free(p)
     params.close()
     dom.close()
+
+
+def test_upstream_random_polynomial_and_query_order_modes(ctx, co):
+    """the restated byte-level rules: the random polynomial drawn from per-thread ChaCha20 streams (it depends on the thread
+    count, and the proof verifies for each), and a circuit's own query order (the evaluations move inside the proof, the
+    verifying key's digest changes with it, and the verifier reading the same lists accepts)"""
+    k = 7
+    cs = _circuit()
+    dom = zk.Domain(ctx, cs.degree(), k)
+    params = prover.ParamsKZG(ctx, dom, _srs(co, dom.n))
+    advice, instance, fixed, asm = _witness(cs, dom.n, 7)
+    pk = prover.keygen(ctx, dom, params, cs, fixed, asm)
+    vk = {"fixed_commitments": pk.fixed_commitments, "permutation_commitments": pk.permutation_commitments,
+          "transcript_repr": pk.transcript_repr}
+    proofs = {}
+    for threads in (None, 1, 3, 16):
+        proofs[threads] = prover.create_proof(ctx, dom, params, pk, advice, instance, prover.FieldRng(1), prover.Blake2bWrite(),
+                                              random_poly_threads=threads)
+        vm.verify_proof(cs, k, vk, instance, proofs[threads], TAU)
+    assert len(set(proofs.values())) == 4
+    # the circuit's own order of first queries: the derived order reversed
+    adv_q, fix_q, inst_q = prover.collect_queries(cs)
+    cs2 = _circuit()
+    cs2.advice_queries, cs2.fixed_queries = list(reversed(adv_q)), list(reversed(fix_q))
+    pk2 = prover.keygen(ctx, dom, params, cs2, fixed, asm)
+    assert pk2.fixed_commitments == pk.fixed_commitments and pk2.transcript_repr != pk.transcript_repr
+    vk2 = dict(vk, transcript_repr=pk2.transcript_repr)
+    proof2 = prover.create_proof(ctx, dom, params, pk2, advice, instance, prover.FieldRng(1), prover.Blake2bWrite())
+    assert proof2 != proofs[None] and len(proof2) == len(proofs[None])
+    vm.verify_proof(cs2, k, vk2, instance, proof2, TAU)
+    with pytest.raises(vm.VerifyError):
+        vm.verify_proof(cs, k, vk2, instance, proof2, TAU)          # read in the derived order, the evaluations do not fit
+    for key in (pk, pk2):
+        for p in key.pointers():
+            ctx.free(p)
+    params.close()
+    dom.close()

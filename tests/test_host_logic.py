@@ -373,3 +373,80 @@ def test_supercircuit_census_is_current_and_sizes_the_standins():
         assert len(cs.permutation_columns) <= census["permutation_columns"]
     std = synthetic.supercircuit_shape("standard")
     assert 340 <= std["advice"] <= 380 and 170 <= std["lookups"] <= 230 and std["max_rotation"] == 204
+
+
+def test_chacha20_keystream_and_per_thread_random_polynomial():
+    """the ChaCha20 block function against the all-zero-key known answer (block 0 of the original 64-bit-counter variant,
+    which `rand_chacha::ChaCha20Rng::from_seed([0; 32])` starts with), and upstream's chunking of the random polynomial:
+    threads (+ 1) streams seeded in order from the main RNG, so the polynomial depends on the thread count"""
+    from zkevm_circuits_amd import prover
+    w = prover.chacha20_blocks(bytes(32), 0, 3)
+    assert w[0].astype("<u4").tobytes().hex() == (
+        "76b8e0ada0f13d90405d6ae55386bd28bdd219b8a08ded1aa836efcc8b770dc7da41597c5157488d7724e03fb8d84a376a43b8f41518a11cc387b669b2ee6586")
+    # consecutive blocks are one stream: block 1 computed alone equals row 1 of a batch, and differs from block 0
+    assert np.array_equal(prover.chacha20_blocks(bytes(32), 1, 1)[0], w[1]) and not np.array_equal(w[0], w[1])
+    assert np.array_equal(prover.chacha20_blocks(bytes(32), (1 << 32) - 1, 2)[1], prover.chacha20_blocks(bytes(32), 1 << 32, 1)[0])
+    n = 64
+    polys = {t: prover.random_poly_per_thread_streams(prover.FieldRng(5), n, t) for t in (1, 3, 4)}
+    assert all(p.shape == (n, 4) for p in polys.values())
+    assert not np.array_equal(polys[1], polys[3]) and not np.array_equal(polys[3], polys[4])
+    # one thread: one stream seeded with the RNG's first 32 bytes, coefficient i = block i of it reduced mod r
+    seed = prover.FieldRng(5).fill_bytes(32)
+    blk = prover.chacha20_blocks(seed, 0, n)
+    want = [int.from_bytes(blk[i].astype("<u4").tobytes(), "little") % P for i in range(n)]
+    assert [prover.fr_from_mont_limbs(r) for r in polys[1]] == want
+    # three threads over 64 coefficients: chunks of 21, a fourth stream for the last coefficient; the main RNG has handed
+    # out four seeds afterwards
+    rng = prover.FieldRng(5)
+    prover.random_poly_per_thread_streams(rng, n, 3)
+    ref = prover.FieldRng(5)
+    seeds = [ref.fill_bytes(32) for _ in range(4)]
+    assert rng.fill_bytes(8) == ref.fill_bytes(8)
+    last = prover.chacha20_blocks(seeds[3], 0, 1)[0]
+    assert prover.fr_from_mont_limbs(polys[3][63]) == int.from_bytes(last.astype("<u4").tobytes(), "little") % P
+
+
+def test_pinned_verifying_key_text_and_query_lists():
+    """`transcript_repr` hashes the `{:?}` text of the pinned verifying key, which spells out the whole constraint system: the
+    text of a two-column circuit, its sensitivity to a gate and to the query order, and the explicit query lists"""
+    from zkevm_circuits_amd import prover
+    from zkevm_circuits_amd.plonk import Advice, ConstraintSystem, Fixed, Lookup, Product, Sum
+    cs = ConstraintSystem(num_fixed_columns=1, num_advice_columns=2, num_instance_columns=0)
+    cs.gates = [[Product(Fixed(0), Sum(Advice(0), Advice(1, 1)))]]
+    cs.lookups = [Lookup([Advice(1)], [Fixed(0)])]
+    cs.permutation_columns = [(plonk.ANY_ADVICE, 0)]
+    text = prover.pinned_vk_debug(cs, 3, 5, 7, [(1, 2)], [None])
+    q = "0x" + "0" * 63
+    assert text == (
+        'PinnedVerificationKey { base_modulus: "0x30644e72e131a029b85045b68181585d97816a916871ca8d3c208c16d87cfd47", '
+        'scalar_modulus: "0x30644e72e131a029b85045b68181585d2833e84879b9709143e1f593f0000001", '
+        f'domain: PinnedEvaluationDomain {{ k: 3, extended_k: 5, omega: {q}7 }}, cs: PinnedConstraintSystem {{ '
+        'num_fixed_columns: 1, num_advice_columns: 2, num_instance_columns: 0, num_selectors: 0, num_challenges: 0, '
+        'advice_column_phase: [0, 0], challenge_phase: [], gates: [Product(Fixed { query_index: 0, column_index: 0, rotation: '
+        'Rotation(0) }, Sum(Advice { query_index: 0, column_index: 0, rotation: Rotation(0), phase: Phase(0) }, Advice { '
+        'query_index: 1, column_index: 1, rotation: Rotation(1), phase: Phase(0) }))], advice_queries: [(Column { index: 0, '
+        'column_type: Advice }, Rotation(0)), (Column { index: 1, column_type: Advice }, Rotation(1)), (Column { index: 1, '
+        'column_type: Advice }, Rotation(0))], instance_queries: [], fixed_queries: [(Column { index: 0, column_type: Fixed }, '
+        'Rotation(0))], permutation: Argument { columns: [Column { index: 0, column_type: Advice }] }, lookups: [Argument { '
+        'input_expressions: [Advice { query_index: 2, column_index: 1, rotation: Rotation(0), phase: Phase(0) }], '
+        'table_expressions: [Fixed { query_index: 0, column_index: 0, rotation: Rotation(0) }] }], constants: [], '
+        f'minimum_degree: None }}, fixed_commitments: [({q}1, {q}2)], permutation: VerifyingKey {{ commitments: [Infinity] }} }}')
+    base = prover._vk_digest(cs, 3, 5, 7, [(1, 2)], [None])
+    other = ConstraintSystem(num_fixed_columns=1, num_advice_columns=2)
+    other.gates = [[Product(Fixed(0), Sum(Advice(0), Advice(1, -1)))]]
+    other.lookups, other.permutation_columns = cs.lookups, cs.permutation_columns
+    assert prover._vk_digest(other, 3, 5, 7, [(1, 2)], [None]) != base          # the digest binds the gates
+    assert prover._vk_digest(cs, 3, 5, 7, [(1, 3)], [None]) != base
+    # the circuit's own query order: (1, 0) first, as if it had enabled equality on column 1 before building its gate
+    cs2 = ConstraintSystem(num_fixed_columns=1, num_advice_columns=2)
+    cs2.gates, cs2.lookups, cs2.permutation_columns = cs.gates, cs.lookups, cs.permutation_columns
+    cs2.advice_queries = [(1, 0), (0, 0), (1, 1)]
+    assert prover.collect_queries(cs2)[0] == [(1, 0), (0, 0), (1, 1)]
+    assert prover.collect_queries(cs)[0] == [(0, 0), (1, 1), (1, 0)]
+    assert prover._vk_digest(cs2, 3, 5, 7, [(1, 2)], [None]) != base
+    import verifier_model as vm
+    assert vm.collect_queries(cs2)[0] == [(1, 0), (0, 0), (1, 1)] and vm.collect_queries(cs)[0] == [(0, 0), (1, 1), (1, 0)]
+    cs2.advice_queries = [(1, 0), (0, 0)]
+    cs2.__dict__.pop("_memo_cache", None)
+    with pytest.raises(ValueError):
+        prover.collect_queries(cs2)

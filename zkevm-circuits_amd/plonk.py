@@ -116,6 +116,15 @@ class ConstraintSystem:
     minimum_degree: int | None = None
     advice_column_phase: list | None = None            # phase of each advice column (None: all in the first phase)
     challenge_phase: list | None = None                # phase after which each challenge is squeezed (None: the first)
+    # Upstream's ConstraintSystem records every (column, rotation) query in the order of the circuit's first `query_*` /
+    # `enable_equality` call for it; that order decides the order of the evaluations in the proof.  A caller that mirrors a
+    # real circuit sets these lists ([(column index, rotation)]); left at None they are derived from the expressions in
+    # order of first appearance (gates, lookups, permutation columns), which is what a circuit gets that configures in
+    # that order.
+    advice_queries: list | None = None
+    fixed_queries: list | None = None
+    instance_queries: list | None = None
+    num_selectors: int = 0                             # selectors the circuit declared (they are fixed columns here already)
 
     def phases(self):
         """[(phase, its advice columns, its challenges)] in proving order"""

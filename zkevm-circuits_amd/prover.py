@@ -9,12 +9,24 @@ on the device: commitments (`zkhip_msm_batch_dev`), lookup compression and the p
 `coeff_to_extended`, `evaluate_h`, the division by the vanishing polynomial, evaluations at x and the SHPLONK multi-open.
 What stays on the host is what upstream does on single field elements: the transcript, the RNG and the bookkeeping.
 
-Differences from upstream that a byte-for-byte comparison would have to remove (none of them touches the device work):
-the verifying key's `transcript_repr` is a stand-in digest of its commitments (upstream hashes a debug print of the
-key), the random polynomial of the vanishing argument is drawn coefficient by coefficient from the one RNG (upstream
-draws it chunk-parallel from per-thread streams), and the order of the
-column queries follows first appearance in gates, lookups and permutation columns.  The compressed point encoding
-follows halo2curves 0.6.1 as published (little-endian x, sign of y in bit 6 and identity in bit 7 of the last byte).
+Where bytes, not field elements, are decided, upstream's rules are restated here; none of them can be pinned (the
+reference holds no proof bytes, no key file and no halo2 source), and none touches the device work:
+  * the verifying key's `transcript_repr` is upstream's: Blake2b-512, personalised "Halo2-Verify-Key", over the length and
+    the text of the `{:?}` rendering of the pinned verifying key -- moduli, domain, the whole constraint system (columns,
+    phases, gates, queries, permutation columns, lookups), the fixed and permutation commitments (`pinned_vk_debug`);
+    the rendering follows the derive(Debug) layout of halo2_proofs 0.3.0 as published, and a fork that adds or renames a
+    field changes every byte of it;
+  * the random polynomial of the vanishing argument: by default one draw of 2^k residues from the RNG (`rng.limbs`);
+    `create_proof(..., random_poly_threads=T)` draws it as upstream does, chunk-parallel from T (+1) ChaCha20 streams
+    each seeded with 32 bytes of the main RNG, element i of a chunk = `Fr::random` of that chunk's stream, so that the
+    polynomial depends on the thread count exactly as upstream's does;
+  * the order of the column queries: the lists `ConstraintSystem.{advice,fixed,instance}_queries` when the caller sets
+    them (a circuit's order of first `query_*` / `enable_equality` calls), else first appearance in gates, lookups and
+    permutation columns;
+  * compressed points follow halo2curves 0.6.1 as published (little-endian x, sign of y in bit 6 and identity in bit 7
+    of the last byte).
+What cannot be restated: the fork's own additions to these formats (its `create_proof` takes a seventh argument and a
+`tracing::Trace`; whether its key rendering differs from 0.3.0 is unknown).
 """
 from __future__ import annotations
 
@@ -132,6 +144,10 @@ class FieldRng:
         a[:, 3] &= np.uint64(0x0FFFFFFFFFFFFFFF)
         return a
 
+    def fill_bytes(self, count: int) -> bytes:
+        """`RngCore::fill_bytes`: the next `count` bytes of the stream"""
+        return self.g.bytes(count)
+
 
 class OsFieldRng:
     """The prover's RNG for real proofs: `Fr::random(OsRng)` as the reference draws it
@@ -147,6 +163,10 @@ class OsFieldRng:
         import secrets
         raw = secrets.token_bytes(64 * count)
         return [int.from_bytes(raw[64 * i:64 * i + 64], "little") % P for i in range(count)]
+
+    def fill_bytes(self, count: int) -> bytes:
+        import secrets
+        return secrets.token_bytes(count)
 
     def limbs(self, n: int) -> np.ndarray:
         import secrets
@@ -168,6 +188,21 @@ def collect_queries(cs: ConstraintSystem):
 
 
 def _collect_queries(cs: ConstraintSystem):
+    derived = _derive_queries(cs)
+    given = (cs.advice_queries, cs.fixed_queries, cs.instance_queries)
+    out = []
+    for name, have, want in zip(("advice", "fixed", "instance"), derived, given):
+        if want is None:
+            out.append(have)
+            continue
+        want = [tuple(q) for q in want]
+        if len(set(want)) != len(want) or not set(have) <= set(want):
+            raise ValueError(f"{name}_queries must list every (column, rotation) the expressions query, once")
+        out.append(want)
+    return tuple(out)
+
+
+def _derive_queries(cs: ConstraintSystem):
     out = {"advice": {}, "fixed": {}, "instance": {}}     # insertion-ordered sets
 
     def add(kind, q):
@@ -297,7 +332,8 @@ def keygen(ctx, dom, params: ParamsKZG, cs: ConstraintSystem, fixed, assembly, d
         pk.fixed_commitments = [affine_ints(j) for j in params.commit_lagrange(pk.fixed_values)]
     if pk.polys.permutations:
         pk.permutation_commitments = [affine_ints(j) for j in params.commit_lagrange(pk.polys.permutations)]
-    pk.transcript_repr = _vk_digest(dom.k, pk.fixed_commitments, pk.permutation_commitments)
+    pk.transcript_repr = _vk_digest(cs, dom.k, dom.extended_k, fr_from_mont_limbs(dom.constant(0)), pk.fixed_commitments,
+                                    pk.permutation_commitments)
     return pk
 
 
@@ -313,12 +349,127 @@ def _point_limbs(xy) -> np.ndarray:
     return np.array(words, dtype=np.uint64)
 
 
-def _vk_digest(k: int, fixed_commitments, permutation_commitments) -> int:
+def _hex_fe(v: int) -> str:
+    """`{:?}` of a halo2curves field element: 0x and the canonical value, 64 hex digits, most significant first"""
+    return "0x" + format(v, "064x")
+
+
+def _debug_expr(e, cs: ConstraintSystem, index) -> str:
+    """`{:?}` of a `plonk::Expression` (derive(Debug) over the enum's tuple and struct variants)"""
+    t = e[0]
+    if t == "const":
+        return f"Constant({_hex_fe(e[1])})"
+    if t in ("fixed", "advice", "instance"):
+        q = index[t][(e[1], e[2])]
+        name = {"fixed": "Fixed", "advice": "Advice", "instance": "Instance"}[t]
+        phase = ""
+        if t == "advice":
+            ph = (cs.advice_column_phase or [0] * cs.num_advice_columns)[e[1]]
+            phase = f", phase: Phase({ph})"
+        return f"{name} {{ query_index: {q}, column_index: {e[1]}, rotation: Rotation({e[2]}){phase} }}"
+    if t == "challenge":
+        ph = (cs.challenge_phase or [0] * cs.num_challenges)[e[1]]
+        return f"Challenge(Challenge {{ index: {e[1]}, phase: Phase({ph}) }})"
+    if t == "neg":
+        return f"Negated({_debug_expr(e[1], cs, index)})"
+    if t == "sum":
+        return f"Sum({_debug_expr(e[1], cs, index)}, {_debug_expr(e[2], cs, index)})"
+    if t == "prod":
+        return f"Product({_debug_expr(e[1], cs, index)}, {_debug_expr(e[2], cs, index)})"
+    if t == "scaled":
+        return f"Scaled({_debug_expr(e[1], cs, index)}, {_hex_fe(e[2])})"
+    raise ValueError(t)
+
+
+def pinned_vk_debug(cs: ConstraintSystem, k: int, extended_k: int, omega: int, fixed_commitments, permutation_commitments) -> str:
+    """The text upstream hashes into `transcript_repr`: `format!("{:?}", vk.pinned())` of halo2_proofs 0.3.0 --
+    `PinnedVerificationKey { base_modulus, scalar_modulus, domain: PinnedEvaluationDomain { k, extended_k, omega }, cs:
+    PinnedConstraintSystem { .. }, fixed_commitments, permutation: VerifyingKey { commitments } }`.  Restated from the
+    published derive(Debug) layout; unpinned (no key or proof bytes of the reference exist to check it against)."""
+    adv_q, fix_q, inst_q = collect_queries(cs)
+    index = {"advice": {q: i for i, q in enumerate(adv_q)}, "fixed": {q: i for i, q in enumerate(fix_q)},
+             "instance": {q: i for i, q in enumerate(inst_q)}}
+    col = lambda kind, i: f"Column {{ index: {i}, column_type: {kind} }}"                      # noqa: E731
+    queries = lambda kind, qs: "[" + ", ".join(f"({col(kind, c)}, Rotation({r}))" for c, r in qs) + "]"   # noqa: E731
+    kind_name = {ANY_ADVICE: "Advice", ANY_FIXED: "Fixed", ANY_INSTANCE: "Instance"}
+    point = lambda p: "Infinity" if p is None else f"({_hex_fe(p[0])}, {_hex_fe(p[1])})"       # noqa: E731
+    phases = cs.advice_column_phase or [0] * cs.num_advice_columns
+    gates = ", ".join(_debug_expr(poly, cs, index) for gate in cs.gates for poly in gate)
+    lookups = ", ".join(
+        "Argument { input_expressions: [" + ", ".join(_debug_expr(e, cs, index) for e in lk.input_expressions)
+        + "], table_expressions: [" + ", ".join(_debug_expr(e, cs, index) for e in lk.table_expressions) + "] }"
+        for lk in cs.lookups)
+    pinned_cs = (
+        f"PinnedConstraintSystem {{ num_fixed_columns: {cs.num_fixed_columns}, num_advice_columns: {cs.num_advice_columns}, "
+        f"num_instance_columns: {cs.num_instance_columns}, num_selectors: {cs.num_selectors}, "
+        f"num_challenges: {cs.num_challenges}, advice_column_phase: [{', '.join(str(p) for p in phases)}], "
+        f"challenge_phase: [{', '.join(str(p) for p in (cs.challenge_phase or [0] * cs.num_challenges))}], "
+        f"gates: [{gates}], advice_queries: {queries('Advice', adv_q)}, instance_queries: {queries('Instance', inst_q)}, "
+        f"fixed_queries: {queries('Fixed', fix_q)}, permutation: Argument {{ columns: ["
+        + ", ".join(col(kind_name[kind], i) for kind, i in cs.permutation_columns)
+        + f"] }}, lookups: [{lookups}], constants: [], minimum_degree: "
+        + ("None" if cs.minimum_degree is None else f"Some({cs.minimum_degree})") + " }")
+    return (f"PinnedVerificationKey {{ base_modulus: \"{_hex_fe(FQ_MODULUS)}\", scalar_modulus: \"{_hex_fe(P)}\", "
+            f"domain: PinnedEvaluationDomain {{ k: {k}, extended_k: {extended_k}, omega: {_hex_fe(omega)} }}, cs: {pinned_cs}, "
+            f"fixed_commitments: [{', '.join(point(c) for c in fixed_commitments)}], "
+            f"permutation: VerifyingKey {{ commitments: [{', '.join(point(c) for c in permutation_commitments)}] }} }}")
+
+
+def _vk_digest(cs: ConstraintSystem, k: int, extended_k: int, omega: int, fixed_commitments, permutation_commitments) -> int:
+    """`VerifyingKey::from_parts`: transcript_repr = from_uniform_bytes(Blake2b-512("Halo2-Verify-Key", len as u64 LE || text))
+    over the `{:?}` text of the pinned key -- the digest binds the whole constraint system, not only the commitments."""
+    text = pinned_vk_debug(cs, k, extended_k, omega, fixed_commitments, permutation_commitments).encode()
     h = hashlib.blake2b(digest_size=64, person=b"Halo2-Verify-Key")
-    h.update(k.to_bytes(4, "little"))
-    for c in fixed_commitments + permutation_commitments:
-        h.update(compress_point(c))
+    h.update(len(text).to_bytes(8, "little"))
+    h.update(text)
     return int.from_bytes(h.digest(), "little") % P
+
+
+# ---- ChaCha20 (the `rand_chacha::ChaCha20Rng` keystream: 64-bit block counter from 0, zero stream id) ------------------
+def chacha20_blocks(seed: bytes, first_block: int, count: int) -> np.ndarray:
+    """(count, 16) uint32 keystream words of blocks first_block .. first_block + count - 1"""
+    assert len(seed) == 32
+    st = np.zeros((count, 16), dtype=np.uint32)
+    st[:, 0:4] = np.frombuffer(b"expand 32-byte k", dtype="<u4")
+    st[:, 4:12] = np.frombuffer(seed, dtype="<u4")
+    ctr = np.arange(first_block, first_block + count, dtype=np.uint64)
+    st[:, 12] = (ctr & np.uint64(0xFFFFFFFF)).astype(np.uint32)
+    st[:, 13] = (ctr >> np.uint64(32)).astype(np.uint32)
+    x = st.copy()
+
+    def rotl(v, c):
+        return (v << np.uint32(c)) | (v >> np.uint32(32 - c))
+
+    def quarter(a, b, c, d):
+        x[:, a] += x[:, b]; x[:, d] = rotl(x[:, d] ^ x[:, a], 16)      # noqa: E702
+        x[:, c] += x[:, d]; x[:, b] = rotl(x[:, b] ^ x[:, c], 12)      # noqa: E702
+        x[:, a] += x[:, b]; x[:, d] = rotl(x[:, d] ^ x[:, a], 8)       # noqa: E702
+        x[:, c] += x[:, d]; x[:, b] = rotl(x[:, b] ^ x[:, c], 7)       # noqa: E702
+    for _ in range(10):
+        quarter(0, 4, 8, 12); quarter(1, 5, 9, 13); quarter(2, 6, 10, 14); quarter(3, 7, 11, 15)      # noqa: E702
+        quarter(0, 5, 10, 15); quarter(1, 6, 11, 12); quarter(2, 7, 8, 13); quarter(3, 4, 9, 14)      # noqa: E702
+    return x + st
+
+
+def random_poly_per_thread_streams(rng, n: int, threads: int) -> np.ndarray:
+    """The random polynomial of `vanishing::Argument::commit` as upstream draws it: n_chunks = threads (+ 1 when threads does
+    not divide n) ChaCha20 generators, each seeded with 32 bytes from the main RNG in order; chunk j (n / threads
+    coefficients) is filled from generator j, one `Fr::random` per coefficient = the next eight 64-bit words of the stream
+    (one 64-byte block) read as a little-endian 512-bit integer and reduced mod r.  Returns (n, 4) Montgomery limbs."""
+    if threads < 1:
+        raise ValueError("threads must be positive")
+    chunk = max(1, n // threads)
+    n_chunks = threads + (1 if n % threads else 0)
+    seeds = [rng.fill_bytes(32) for _ in range(n_chunks)]
+    out = []
+    for j in range(n_chunks):
+        count = min(chunk, n - j * chunk)
+        if count <= 0:
+            break
+        words = chacha20_blocks(seeds[j], 0, count)
+        raw = np.ascontiguousarray(words).view(np.uint8).reshape(count, 64)
+        out.append(fr_limbs([int.from_bytes(raw[i].tobytes(), "little") % P for i in range(count)]))
+    return np.concatenate(out)
 
 
 def save_proving_key(ctx, dom, pk: ProvingKey, path: str, layout: str = "v3") -> None:
@@ -383,12 +534,14 @@ def load_proving_key(ctx, dom, cs: ConstraintSystem, path: str, num_selectors: i
     pk.polys.permutation_cosets = up(raw.permutation_cosets)
     pk.fixed_commitments = [affine_ints(c) for c in raw.vk.fixed_commitments]
     pk.permutation_commitments = [affine_ints(c) for c in raw.vk.permutation_commitments]
-    pk.transcript_repr = _vk_digest(dom.k, pk.fixed_commitments, pk.permutation_commitments)
+    pk.transcript_repr = _vk_digest(cs, dom.k, dom.extended_k, fr_from_mont_limbs(dom.constant(0)), pk.fixed_commitments,
+                                    pk.permutation_commitments)
     return pk
 
 
 def create_proof(ctx, dom, params: ParamsKZG, pk: ProvingKey, advice, instance, rng: FieldRng, transcript: Blake2bWrite,
-                 timings: dict | None = None, dist=None, coset_groups: int | None = None):
+                 timings: dict | None = None, dist=None, coset_groups: int | None = None,
+                 random_poly_threads: int | None = None):
     """One circuit.  advice: per column the values of the usable rows (a list of canonical integers, or a
     (usable rows, 4) uint64 array of Montgomery limbs; the remaining rows are blinding), or a callable
     (phase, challenges so far) -> such a list, called once per phase of `cs.phases()` as upstream re-runs witness
@@ -405,7 +558,9 @@ def create_proof(ctx, dom, params: ParamsKZG, pk: ProvingKey, advice, instance, 
     A lookup input outside its table raises on the lookup's owner; the other ranks then fail in the next collective.
     coset_groups (single rank): evaluate the quotient numerator in that many passes over disjoint coset groups, which
     bounds the resident extended data to 1 / coset_groups of the whole; None picks the smallest count that fits the free
-    device memory (1 on a whole MI355X at the SuperCircuit's width).  The proof bytes do not depend on it."""
+    device memory (1 on a whole MI355X at the SuperCircuit's width).  The proof bytes do not depend on it.
+    random_poly_threads: draw the vanishing argument's random polynomial as upstream does for that many rayon threads
+    (`random_poly_per_thread_streams`); None draws 2^k residues from `rng.limbs` in one go (the fast path of benchmarks)."""
     cs = pk.cs
     n, en = dom.n, dom.extended_len
     bf = cs.blinding_factors()
@@ -670,7 +825,8 @@ def create_proof(ctx, dom, params: ParamsKZG, pk: ProvingKey, advice, instance, 
 
         # ---- vanishing argument: random polynomial ----------------------------------------------------------
         mark("random_poly")
-        d_random = ctx.upload(rng.limbs(n))
+        d_random = ctx.upload(rng.limbs(n) if random_poly_threads is None
+                              else random_poly_per_thread_streams(rng, n, random_poly_threads))
         owned.append(d_random)
         rng.fr()
         transcript.write_point(params.commit([d_random])[0])
