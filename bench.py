@@ -407,7 +407,7 @@ def main():
                             "merge = the final merge level fused with level 1 of the reduce, reduce = its level 2"}
 
     if world > 1:
-        t = torch.tensor([elapsed, msm_ms, ntt_ms], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed, msm_ms, ntt_ms], dtype=torch.float64, device=group_device())
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed, msm_ms, ntt_ms = (float(x) for x in t.cpu())
 
@@ -466,12 +466,16 @@ def main():
            extra, evalh, watchdog=watchdog)
 
 
+def group_device():
+    """where the small tensors of a reduction live: on the GPU under RCCL (it moves nothing else), in host memory otherwise"""
+    return "cuda" if dist.get_backend() == "nccl" else "cpu"
+
+
 def gather_rank_ids(rank, device_index):
     """[{rank, device, pci_bus}] of every rank, gathered over the process group (device tensors: RCCL moves nothing else)"""
     props = torch.cuda.get_device_properties(device_index)
     mine = torch.tensor([rank, device_index, int(getattr(props, "pci_bus_id", -1)), os.getpid()], dtype=torch.int64, device="cuda")
-    got = [torch.empty_like(mine) for _ in range(dist.get_world_size())]
-    dist.all_gather(got, mine)
+    got = sharding.all_gather_rows(mine, dist)
     return [dict(zip(("rank", "device", "pci_bus", "pid"), (int(v) for v in g.cpu()))) for g in got]
 
 
@@ -511,7 +515,7 @@ def measure_create_proof(ctx, bid, dist_=None):
     ranks = 1
     if dist_ is not None:
         ranks = dist_.get_world_size()
-        t = torch.tensor([seconds], dtype=torch.float64, device="cuda")
+        t = torch.tensor([seconds], dtype=torch.float64, device=group_device())
         dist_.all_reduce(t, op=dist_.ReduceOp.MAX)
         seconds = float(t.cpu()[0])
     return {"seconds": seconds, "ranks": ranks, "keygen_seconds": keygen_seconds, "phases_s": phases, "proof_bytes": len(proof),
@@ -701,7 +705,7 @@ def measure_evalh_split(ctx, dom, stream, gen, world, rank):
     torch.cuda.synchronize()
     dist.barrier()
     dt = time.perf_counter() - t0
-    t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+    t = torch.tensor([dt], dtype=torch.float64, device=group_device())
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return {"ranks": world, "ranks_with_rows": owners, "rows_per_owner": int(mine[2]) if mine is not None else 0,
             "cosets": 1 << (dom.extended_k - dom.k),
@@ -717,14 +721,14 @@ def finish(args, ctx, dist, world, rank, local_rank, bid, scalars, n, en, elapse
         # sums are all-gathered and folded; the fold must be the point a single GPU computes over the whole range
         try:
             shared = scalars.clone()
-            dist.broadcast(shared, src=0)
+            sharding.broadcast_(shared, 0, dist)
             torch.cuda.synchronize()
             full = sharding.msm_base_split(
                 n, lambda first, cnt: ctx.msm_range_dev(bid, first, shared.data_ptr() + 32 * first, cnt),
                 ctx.g1_sum_jacobian, dist, device=torch.device("cuda", local_rank))
             single = ctx.msm_range_dev(bid, 0, shared.data_ptr(), n)
             split_ok = bool(np.array_equal(ctx.g1_to_affine(full), ctx.g1_to_affine(single)) and np.asarray(single).any())
-            flag = torch.tensor([1 if split_ok else 0], dtype=torch.int64, device="cuda")
+            flag = torch.tensor([1 if split_ok else 0], dtype=torch.int64, device=group_device())
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)
             split_ok = bool(int(flag.cpu()[0]))
         except Exception as exc:                          # reported as a failed check; the measured line is still printed

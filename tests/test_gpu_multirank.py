@@ -20,8 +20,17 @@ def _free_port():
     return p
 
 
+def _dump_stacks_if_stuck(seconds=100):
+    """a rank that is still running after `seconds` prints every thread's stack and exits: a hang becomes a failure that
+    names its place"""
+    import faulthandler
+    import sys
+    faulthandler.dump_traceback_later(seconds, exit=True, file=sys.stderr)
+
+
 def _worker(rank, world, port, q):
     import sys
+    _dump_stacks_if_stuck()
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     for p in (root, os.path.join(root, "oracle"), os.path.join(root, "tests")):
         sys.path.insert(0, p)
@@ -104,6 +113,10 @@ def _worker(rank, world, port, q):
         dist.barrier()
         dom.close()
         ctx.close()
+    except Exception:
+        import traceback
+        q.put(f"rank {rank} failed:\n{traceback.format_exc()}")     # the test fails at once instead of waiting
+        raise
     finally:
         dist.destroy_process_group()
 
@@ -117,10 +130,14 @@ def test_two_ranks_match_the_unsharded_pipeline():
     for p in procs:
         p.start()
     try:
-        ok_cols, ok_split, ok_h, owners = q.get(timeout=240)
+        result = q.get(timeout=240)
     finally:
         for p in procs:
             p.join(timeout=120)
+            if p.is_alive():
+                p.kill()
+    assert not isinstance(result, str), result
+    ok_cols, ok_split, ok_h, owners = result
     assert all(p.exitcode == 0 for p in procs)
     assert ok_cols, "column-sharded commitments differ from the unsharded ones"
     assert ok_split, "base-range split MSM differs from the whole MSM"
@@ -130,6 +147,7 @@ def test_two_ranks_match_the_unsharded_pipeline():
 
 def _prover_worker(rank, world, port, q):
     import sys
+    _dump_stacks_if_stuck()
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     for p in (root, os.path.join(root, "oracle"), os.path.join(root, "tests")):
         sys.path.insert(0, p)

@@ -637,7 +637,7 @@ def create_proof(ctx, dom, params: ParamsKZG, pk: ProvingKey, advice, instance, 
                     j = i
                     while j + 1 < len(owned_slots) and owned_slots[j + 1] == owned_slots[j] + 1:
                         j += 1
-                    dist.broadcast(t_block[owned_slots[i] * n:(owned_slots[j] + 1) * n], src=r)
+                    sharding.broadcast_(t_block[owned_slots[i] * n:(owned_slots[j] + 1) * n], r, dist)
                     i = j + 1
             torch.cuda.synchronize()
         adv, inst = slot[:n_adv], slot[n_adv:n_adv + n_inst]

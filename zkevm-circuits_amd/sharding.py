@@ -56,6 +56,36 @@ def _on_group_device(t, dist):
     return t.cuda() if dist.get_backend() == "nccl" else t
 
 
+# Device tensors travel as they are over RCCL.  Under any other backend (gloo: the rehearsal of the multi-rank path on
+# fewer GPUs than ranks, and the CPU tests) they are staged through host memory here, explicitly, so that the backend only
+# ever sees host tensors: gloo's own handling of device tensors was seen to hang in an all-gather when a third process
+# held the same GPU.
+def broadcast_(t, src: int, dist):
+    """in-place broadcast of a (device or host) tensor from rank `src`"""
+    if dist.get_backend() == "nccl" or not t.is_cuda:
+        dist.broadcast(t, src=src)
+        return
+    import torch
+    host = t.cpu() if dist.get_rank() == src else torch.empty(t.shape, dtype=t.dtype)
+    dist.broadcast(host, src=src)
+    if dist.get_rank() != src:
+        t.copy_(host)
+
+
+def all_gather_rows(piece, dist):
+    """[tensor of rank 0, tensor of rank 1, ..] of equally shaped pieces, each on the device `piece` lives on"""
+    import torch
+    world = dist.get_world_size()
+    if dist.get_backend() == "nccl" or not piece.is_cuda:
+        gathered = [torch.empty_like(piece) for _ in range(world)]
+        dist.all_gather(gathered, piece.contiguous())
+        return gathered
+    host = piece.contiguous().cpu()
+    gathered = [torch.empty_like(host) for _ in range(world)]
+    dist.all_gather(gathered, host)
+    return [g.to(piece.device) for g in gathered]
+
+
 def gather_commitments(local: dict, num_columns: int, dist=None):
     """local: {column index: 12-limb Jacobian} of the columns this rank committed, under any partition in which every
     column has exactly one owner.  Returns the (num_columns, 12) array in column order on every rank (transcript order
@@ -86,10 +116,10 @@ def msm_base_split(n: int, msm_range, fold, dist=None, device=None):
     first, count = base_range_for_rank(n, rank, world)
     part = np.asarray(msm_range(first, count), dtype=np.uint64).reshape(12)
     t = torch.from_numpy(part.view(np.int64).copy())
-    t = t.to(device) if device is not None else _on_group_device(t, dist)
-    gathered = torch.empty((world, 12), dtype=torch.int64, device=t.device)
-    dist.all_gather(list(gathered.unbind(0)), t)
-    return fold(gathered.cpu().numpy().view(np.uint64))
+    if dist.get_backend() == "nccl":
+        t = t.to(device) if device is not None else t.cuda()
+    gathered = all_gather_rows(t, dist)
+    return fold(np.stack([g.cpu().numpy().view(np.uint64) for g in gathered]))
 
 
 def coset_partition(extended_k: int, k: int, world: int):
@@ -146,8 +176,7 @@ def evaluate_h_by_cosets(extended_k: int, k: int, evaluate, dist=None):
     else:
         ref = evaluate([], 0, 0)          # an empty tensor on the right device, for the collective's shape
         piece = torch.zeros((rows, 4), dtype=torch.int64, device=ref.device)
-    gathered = [torch.empty_like(piece) for _ in range(world)]
-    dist.all_gather(gathered, piece.contiguous())
+    gathered = all_gather_rows(piece, dist)
     return [(p[0], p[1], gathered[r]) for r, p in enumerate(parts) if p is not None]
 
 
