@@ -12,7 +12,7 @@ print("ctx", time.perf_counter() - T0, flush=True)
 ctx = zk.Context(0)
 print("ctx ok", flush=True)
 k = 19
-cs = synthetic.standin_cs(units=52, lanes=8, wide_lookups=8, lookup_width=10, extra_gates=38)
+cs, _shape = synthetic.supercircuit_standin("standard")
 dom = zk.Domain(ctx, cs.degree(), k)
 bid = ctx.register_bases(ctx.g1_multiples(dom.n))
 print("bases ok", flush=True)
