@@ -407,3 +407,21 @@ def test_upstream_random_polynomial_and_query_order_modes(ctx, co):
             ctx.free(p)
     params.close()
     dom.close()
+
+
+def test_workspace_kept_between_proofs_gives_the_same_bytes(ctx, setup):
+    """`ProofWorkspace`: the large blocks outlive the call and serve the next proof (also one with another witness);
+    the bytes equal those of a call that allocates and frees"""
+    k, cs, dom, params, pk, vk, advice, instance = setup
+    proof = _prove(ctx, setup, advice, instance)
+    ws = prover.ProofWorkspace(ctx)
+    first = prover.create_proof(ctx, dom, params, pk, advice, instance, prover.FieldRng(1), prover.Blake2bWrite(), workspace=ws)
+    held = dict(ws.blocks)
+    assert held and first == proof
+    other = prover.create_proof(ctx, dom, params, pk, advice, instance, prover.FieldRng(2), prover.Blake2bWrite(), workspace=ws)
+    assert other != proof and ws.blocks == held
+    vm.verify_proof(cs, k, vk, instance, other, TAU)
+    again = prover.create_proof(ctx, dom, params, pk, advice, instance, prover.FieldRng(1), prover.Blake2bWrite(), workspace=ws)
+    assert again == proof
+    ws.close()
+    assert not ws.blocks

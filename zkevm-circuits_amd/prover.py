@@ -539,9 +539,34 @@ def load_proving_key(ctx, dom, cs: ConstraintSystem, path: str, num_selectors: i
     return pk
 
 
+class ProofWorkspace:
+    """The large device blocks of `create_proof` -- the polynomial block, the block of extended cosets (123 GB at the
+    SuperCircuit's width), h -- kept between proofs of one proving key.  A prover that serves proof after proof passes the
+    same workspace to every call: releasing a block of that size and asking for it again costs seconds in the driver
+    (measured: 4.1 s of `hipMalloc` in the second of two consecutive stand-in proofs, against 1.7 s for the proof itself),
+    which a first proof on fresh memory does not pay.  `close()` returns the blocks."""
+
+    def __init__(self, ctx):
+        self.ctx = ctx
+        self.blocks = {}          # (name, bytes) -> device pointer
+
+    def take(self, name: str, nbytes: int) -> int:
+        p = self.blocks.get((name, nbytes))
+        if p is None:
+            for key in [k for k in self.blocks if k[0] == name]:      # another circuit's size: make room first
+                self.ctx.free(self.blocks.pop(key))
+            p = self.blocks[(name, nbytes)] = self.ctx.alloc(nbytes)
+        return p
+
+    def close(self):
+        for p in self.blocks.values():
+            self.ctx.free(p)
+        self.blocks = {}
+
+
 def create_proof(ctx, dom, params: ParamsKZG, pk: ProvingKey, advice, instance, rng: FieldRng, transcript: Blake2bWrite,
                  timings: dict | None = None, dist=None, coset_groups: int | None = None,
-                 random_poly_threads: int | None = None):
+                 random_poly_threads: int | None = None, workspace: ProofWorkspace | None = None):
     """One circuit.  advice: per column the values of the usable rows (a list of canonical integers, or a
     (usable rows, 4) uint64 array of Montgomery limbs; the remaining rows are blinding), or a callable
     (phase, challenges so far) -> such a list, called once per phase of `cs.phases()` as upstream re-runs witness
@@ -560,7 +585,8 @@ def create_proof(ctx, dom, params: ParamsKZG, pk: ProvingKey, advice, instance, 
     bounds the resident extended data to 1 / coset_groups of the whole; None picks the smallest count that fits the free
     device memory (1 on a whole MI355X at the SuperCircuit's width).  The proof bytes do not depend on it.
     random_poly_threads: draw the vanishing argument's random polynomial as upstream does for that many rayon threads
-    (`random_poly_per_thread_streams`); None draws 2^k residues from `rng.limbs` in one go (the fast path of benchmarks)."""
+    (`random_poly_per_thread_streams`); None draws 2^k residues from `rng.limbs` in one go (the fast path of benchmarks).
+    workspace: a `ProofWorkspace` kept by a caller that proves repeatedly: the large blocks then outlive the call."""
     cs = pk.cs
     n, en = dom.n, dom.extended_len
     bf = cs.blinding_factors()
@@ -574,7 +600,10 @@ def create_proof(ctx, dom, params: ParamsKZG, pk: ProvingKey, advice, instance, 
     omega = fr_from_mont_limbs(dom.constant(0))
     owned = []
 
-    def alloc(rows):
+    def alloc(rows, keep_as=None):
+        """keep_as: the name under which a caller's workspace keeps this block for the next proof"""
+        if keep_as is not None and workspace is not None:
+            return workspace.take(keep_as, rows * 32)
         p = ctx.alloc(rows * 32)
         owned.append(p)
         return p
@@ -623,7 +652,7 @@ def create_proof(ctx, dom, params: ParamsKZG, pk: ProvingKey, advice, instance, 
             torch.cuda.synchronize()
             block = t_block.data_ptr()
         else:
-            block = alloc(n * max(total, 1))
+            block = alloc(n * max(total, 1), "polynomials")
         slot = [block + i * n * 32 for i in range(total)]
 
         def exchange(slots_by_owner):
@@ -656,10 +685,11 @@ def create_proof(ctx, dom, params: ParamsKZG, pk: ProvingKey, advice, instance, 
         to_extended = dom.coeff_to_extended_split_dev if split else dom.coeff_to_extended_dev
         early_ext = early_coeff = None
         early_done = set()
+        held = workspace is not None and ("extended", en * max(total, 1) * 32) in workspace.blocks
         if (not sharded and coset_groups in (None, 1) and pk.polys.cosets is None and n_adv
-                and en * 32 * (total + 3 * BATCH) + n * 32 * n_adv <= 0.85 * ctx.mem_info()[0]):
-            early_ext = alloc(en * max(total, 1))
-            early_coeff = alloc(n * n_adv)
+                and (held or en * 32 * (total + 3 * BATCH) + n * 32 * n_adv <= 0.85 * ctx.mem_info()[0])):
+            early_ext = alloc(en * max(total, 1), "extended")
+            early_coeff = alloc(n * n_adv, "advice coefficients")
 
         def extend_early(cols):
             """coefficient and extended form of freshly committed advice columns (maximal runs of neighbouring columns
@@ -864,7 +894,7 @@ def create_proof(ctx, dom, params: ParamsKZG, pk: ProvingKey, advice, instance, 
         call = evalh_host.EvalhCall(cs, pk.ev)
         call.challenges = ch_limbs
         call.y, call.beta, call.gamma, call.theta = limb(y), limb(beta), limb(gamma), limb(theta)
-        d_h = alloc(en)
+        d_h = alloc(en, "h")
 
         def fill(of_poly, of_key):
             """of_poly: coefficient polynomial -> its evaluations; of_key: extended key vector -> the same rows of it"""
@@ -895,7 +925,7 @@ def create_proof(ctx, dom, params: ParamsKZG, pk: ProvingKey, advice, instance, 
                 raise ValueError("coset_groups must be a power of two between 1 and the number of cosets")
             BATCH = max(1, min(BATCH, int(0.1 * free_bytes) // (3 * en * 32)))
         if not sharded and coset_groups == 1:
-            ext_block = early_ext if early_ext is not None else alloc(en * max(total, 1))
+            ext_block = early_ext if early_ext is not None else alloc(en * max(total, 1), "extended")
             for s0, cnt in runs(todo):
                 to_extended(slot[s0], ext_block + s0 * en * 32, cnt)
             fill(lambda p: ext_block + (p - block) // (n * 32) * en * 32, lambda p: p)
@@ -972,7 +1002,7 @@ def create_proof(ctx, dom, params: ParamsKZG, pk: ProvingKey, advice, instance, 
         mark("quotient_pieces")
         dom.divide_by_vanishing_poly_dev(d_h)
         pieces = dom.quotient_poly_degree
-        d_hc = alloc(n * pieces)
+        d_hc = alloc(n * pieces, "quotient pieces")
         dom.extended_to_coeff_dev(d_h, d_hc)
         h_pieces = [d_hc + i * n * 32 for i in range(pieces)]
         for _ in h_pieces:
