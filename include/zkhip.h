@@ -149,6 +149,10 @@ int zkhip_coeff_to_extended_split_dev(zkhip_domain* dom, const uint64_t* d_coeff
 /* Values of a polynomial of degree < 2^(ext_k-1) on the even-indexed rows of the extended domain -> its values on the
  * odd-indexed rows (one inverse and one forward transform of half the extended size).  batch members back to back. */
 int zkhip_extend_half_dev(zkhip_domain* dom, const uint64_t* d_even, uint64_t* d_odd, size_t batch);
+/* coeff_to_extended onto the even-indexed rows only: per member the 2^(ext_k-1) values that the first half of
+ * zkhip_coeff_to_extended_split_dev holds, written with a stride of out_stride elements between members (2^ext_k to fill
+ * the even halves of vectors in the split layout and leave their odd halves alone), by one transform of half the size. */
+int zkhip_coeff_to_extended_half_dev(zkhip_domain* dom, const uint64_t* d_coeff, uint64_t* d_out, size_t out_stride, size_t batch);
 int zkhip_divide_by_vanishing_poly_dev(zkhip_domain* dom, uint64_t* d_ext, size_t batch);
 
 /* ------------------------------------------------------------------ evaluate_h --------------------
@@ -249,6 +253,14 @@ int zkhip_evaluate_h_cache_stats(zkhip_ctx* ctx, uint64_t out[2]);
  * generation runs it (`ProvingKey::ev`).  Only the counts, the graphs and the permutation column kinds / indices of the
  * descriptor are read; every polynomial pointer may be NULL. */
 int zkhip_evaluate_h_prepare(zkhip_domain* dom, const zkhip_evalh_desc* desc);
+/* Which columns the program of the descriptor's shape reads (built and kept like zkhip_evaluate_h_prepare does): used[c] = 1
+ * or 0 for column c of the order  fixed | advice | instance | l0, l_last, l_active | X (only with a permutation argument) |
+ * permutation products | permutation sigmas | per lookup (product, permuted input, permuted table);  *count = their number
+ * (<= capacity).  With desc.term_select = ZKHIP_TERMS_HIGH this names the columns whose odd-indexed extended rows the split
+ * evaluation reads at all: the others are extended to the even-indexed half only (zkhip_coeff_to_extended_half_dev).  No
+ * reference counterpart. */
+int zkhip_evaluate_h_columns_used(zkhip_domain* dom, const zkhip_evalh_desc* desc, uint8_t* used, uint32_t capacity,
+                                  uint32_t* count);
 
 /* ------------------------------------------------------------------ grand products and openings -----
  * The prover steps adjacent to the hot path (the rest of `plonk::prover::create_proof`, reached from

@@ -218,22 +218,33 @@ def main():
         low, high, whole = evalh_host.split_gain(dom, cs, call.ev)
         split_programs = {"low": low, "high": high, "whole": whole}
         split = whole > 0 and low >= _prover.SPLIT_MIN_LOW_SHARE * whole
-    to_ext = dom.coeff_to_extended_split_dev if split else dom.coeff_to_extended_dev
+    half_extended = 0
     if split:
         evalh_host.warm_up_split(ctx, dom)          # as key generation does: twiddle tables of the half-size transforms
+        # columns that no term above the degree bound reads are extended onto the even-indexed rows only
+        used = evalh_host.columns_used(dom, cs, call.ev, (ffi.TERMS_HIGH, (en // n) // 2))
+        half_extended = sum(not f for f in list(used["advice"]) + list(used["instance"]) + list(used["perm_z"])
+                            + [g for t in used["lookups"] for g in t])
+
+        def to_ext(src, dst, cnt, flags):
+            evalh_host.extend_for_split(dom, flags, src, dst)
+    else:
+        def to_ext(src, dst, cnt, flags):
+            dom.coeff_to_extended_dev(src, dst, cnt)
 
     # coefficient polynomials -> extended cosets (advice | instance | per lookup z, a', s' | perm z)
     def extend_all():
         o = 0
-        batched(lambda s, c: to_ext(colptr(advice, s, n), colptr(ext, o + s, en), c), A)
+        f = used if split else None
+        batched(lambda s, c: to_ext(colptr(advice, s, n), colptr(ext, o + s, en), c, f and f["advice"][s:s + c]), A)
         o += A
-        to_ext(instance.data_ptr(), colptr(ext, o, en), I)
+        to_ext(instance.data_ptr(), colptr(ext, o, en), I, f and f["instance"])
         o += I
         for i in range(L):
-            to_ext(colptr(lk_z, i, n), colptr(ext, o + 3 * i, en), 1)
-            to_ext(colptr(lk_cols, 4 * i + 2, n), colptr(ext, o + 3 * i + 1, en), 2)
+            to_ext(colptr(lk_z, i, n), colptr(ext, o + 3 * i, en), 1, f and f["lookups"][i][:1])
+            to_ext(colptr(lk_cols, 4 * i + 2, n), colptr(ext, o + 3 * i + 1, en), 2, f and f["lookups"][i][1:])
         o += 3 * L
-        to_ext(perm_z.data_ptr(), colptr(ext, o, en), sets)
+        to_ext(perm_z.data_ptr(), colptr(ext, o, en), sets, f and f["perm_z"])
     ph.run("coeff_to_extended", extend_all)
 
     call.fixed = [colptr(fixed_ext, i, en) for i in range(F)]
@@ -331,6 +342,7 @@ def main():
         "total_s": total, "phases_s": ph.t, "msm_count": n_msm, "msm_total_s": msm_s, "msm_ms_each": msm_s / n_msm * 1e3,
         "coset_ntt_count": A + I + 3 * L + sets, "evalh_kernel_ms": evalh_kernel_ms, "evalh_program": evalh_program,
         "evaluate_h_low_degree_split": {"used": split, "multiplications_per_row": split_programs,
+                                        "polynomials_extended_to_the_even_rows_only": half_extended,
                                         "what": "terms of degree <= cosets / 2 evaluated on the even-indexed rows only and "
                                                 "extended by two half-size transforms"}, "eval_polynomial_count": n_queries,
         "shplonk": {"polynomials": len(shapes), "queries": n_queries, "poly_lincomb_calls": lincomb_n,

@@ -155,12 +155,14 @@ extern "C" {
     pub fn zkhip_divide_by_vanishing_poly_dev(dom: *mut zkhip_domain, d_ext: *mut u64, batch: usize) -> c_int;
     pub fn zkhip_coeff_to_extended_split_dev(dom: *mut zkhip_domain, d_coeff: *const u64, d_out: *mut u64, batch: usize) -> c_int;
     pub fn zkhip_extend_half_dev(dom: *mut zkhip_domain, d_even: *const u64, d_odd: *mut u64, batch: usize) -> c_int;
+    pub fn zkhip_coeff_to_extended_half_dev(dom: *mut zkhip_domain, d_coeff: *const u64, d_out: *mut u64, out_stride: usize, batch: usize) -> c_int;
 
     // ---- plonk::evaluation::Evaluator::evaluate_h
     pub fn zkhip_evaluate_h(dom: *mut zkhip_domain, desc: *const zkhip_evalh_desc, out: *mut u64) -> c_int;
     pub fn zkhip_evaluate_h_last_stats(ctx: *mut zkhip_ctx, out: *mut u64) -> c_int;
     pub fn zkhip_evaluate_h_cache_stats(ctx: *mut zkhip_ctx, out: *mut u64) -> c_int;
     pub fn zkhip_evaluate_h_prepare(dom: *mut zkhip_domain, desc: *const zkhip_evalh_desc) -> c_int;
+    pub fn zkhip_evaluate_h_columns_used(dom: *mut zkhip_domain, desc: *const zkhip_evalh_desc, used: *mut u8, capacity: u32, count: *mut u32) -> c_int;
 
     // ---- grand products and openings (the rest of plonk::prover::create_proof)
     pub fn zkhip_batch_invert_dev(ctx: *mut zkhip_ctx, field: c_int, d_a: *mut u64, n: usize) -> c_int;

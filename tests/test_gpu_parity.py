@@ -439,6 +439,19 @@ def test_split_extension_layout_and_half_domain_extension(ctx, co):
         got = ctx.download(d_out, (2, en, 4))
         for g, e in ((got[0], ea), (got[1], eb)):
             assert np.array_equal(g[:half], e[0::2]) and np.array_equal(g[half:], e[1::2])
+        # the even-indexed rows alone, by one transform of half the size: back to back, and into the even halves of
+        # vectors in the split layout (whose odd halves stay as they were)
+        d_half = ctx.alloc(2 * half * 32)
+        d.coeff_to_extended_half_dev(d_in, d_half, None, 2)
+        assert np.array_equal(ctx.download(d_half, (2, half, 4)), np.stack([ea[0::2], eb[0::2]]))
+        ctx.upload(np.concatenate([eb, ea]), d_out)
+        d.coeff_to_extended_half_dev(d_in, d_out, en, 2)
+        got = ctx.download(d_out, (2, en, 4))
+        assert np.array_equal(got[0][:half], ea[0::2]) and np.array_equal(got[1][:half], eb[0::2])
+        assert np.array_equal(got[0][half:], eb[half:]) and np.array_equal(got[1][half:], ea[half:])
+        ctx.free(d_half)
+        with pytest.raises(zk.ZkhipError):
+            d.coeff_to_extended_half_dev(d_in, d_out, half - 1, 2)
         # degree < n <= en / 2: one polynomial; and, from four cosets on, a product of two (degree < 2n <= en / 2)
         d_odd = ctx.alloc(2 * half * 32)
         d_even = ctx.upload(np.concatenate([ea[0::2], eb[0::2]]))

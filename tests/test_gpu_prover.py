@@ -252,6 +252,34 @@ def test_wide_circuit_proof_verifies(ctx, co, k, units, degree9):
     dom.close()
 
 
+def test_columns_that_only_low_degree_terms_read_are_extended_to_half_the_domain(ctx, co):
+    """degree nine, eight cosets: the lookup terms have degree <= 4, so no term above the bound names a lookup polynomial
+    and the split key extends those onto the even-indexed rows only; the bytes equal those of a key without the split"""
+    from zkevm_circuits_amd import synthetic
+    k, units = 9, 4
+    cs = synthetic.satisfied_cs(units, degree9=True, plain_lookups=True)
+    dom = zk.Domain(ctx, cs.degree(), k)
+    params = prover.ParamsKZG(ctx, dom, _srs(co, dom.n))
+    advice, instance, fixed, asm = wide_witness(cs, dom.n, k, units)
+    keys = {flag: prover.keygen(ctx, dom, params, cs, fixed, asm, low_degree_split=flag) for flag in (False, True)}
+    used = keys[True].high_degree_columns
+    assert keys[False].high_degree_columns is None
+    assert len(used["advice"]) == cs.num_advice_columns and len(used["lookups"]) == len(cs.lookups)
+    assert not any(f for t in used["lookups"] for f in t)        # every lookup polynomial: even-indexed rows only
+    assert any(used["advice"]) and any(used["perm_z"])           # the degree-nine gate and the permutation products: all rows
+    proofs = {flag: prover.create_proof(ctx, dom, params, key, advice, instance, prover.FieldRng(3), prover.Blake2bWrite())
+              for flag, key in keys.items()}
+    assert proofs[True] == proofs[False]
+    vk = {"fixed_commitments": keys[True].fixed_commitments, "permutation_commitments": keys[True].permutation_commitments,
+          "transcript_repr": keys[True].transcript_repr}
+    vm.verify_proof(cs, k, vk, instance, proofs[True], TAU)
+    for key in keys.values():
+        for p in key.pointers():
+            ctx.free(p)
+    params.close()
+    dom.close()
+
+
 @pytest.mark.parametrize("units,extra_gates", [(16, 0), (76, 0), (76, 40)])
 def test_full_size_wide_proof_verifies(ctx, co, units, extra_gates):
     """k = 19 with 16 units: 80 advice columns, 16 lookups, 49 permutation columns, a degree-nine gate, i.e. 146

@@ -334,6 +334,40 @@ int zkhip_coeff_to_extended_split_dev(zkhip_domain* dom, const uint64_t* d_coeff
     return domain_coeff_to_extended(dom, (const fe*)d_coeff, (fe*)d_out, batch, t0, t1, true);
 }
 
+static int half_plans(zkhip_domain* dom) {
+    if (dom->plan_half_fwd) return ZKHIP_OK;
+    uint64_t w[4], wi[4];
+    h_mul(HFR, w, dom->extended_omega, dom->extended_omega);
+    h_mul(HFR, wi, dom->extended_omega_inv, dom->extended_omega_inv);
+    int rc = zkhip_internal_get_plan(dom->ctx, dom->extended_k - 1, w, &dom->plan_half_fwd);
+    if (!rc) rc = zkhip_internal_get_plan(dom->ctx, dom->extended_k - 1, wi, &dom->plan_half_inv);
+    return rc;
+}
+
+int zkhip_coeff_to_extended_half_dev(zkhip_domain* dom, const uint64_t* d_coeff, uint64_t* d_out, size_t out_stride, size_t batch) {
+    if (!dom) return ZKHIP_ERR_INVALID;
+    zkhip_ctx* ctx = dom->ctx;
+    ZK_CHECK(ctx, d_coeff && d_out && batch >= 1, "coeff_to_extended_half: null pointer or empty batch");
+    ZK_CHECK(ctx, (const void*)d_coeff != (const void*)d_out, "coeff_to_extended_half: in and out must differ");
+    ZK_CHECK(ctx, dom->extended_k > dom->k, "coeff_to_extended_half: the extended domain has a single coset");
+    const size_t n = (size_t)1 << dom->k, hn = (size_t)1 << (dom->extended_k - 1);
+    ZK_CHECK(ctx, out_stride >= hn, "coeff_to_extended_half: members %zu elements apart, each %zu long", out_stride, hn);
+    ZK_HIP(ctx, hipSetDevice(ctx->device));
+    int rc = half_plans(dom);
+    if (rc) return rc;
+    if ((rc = ensure_scratch(ctx, 2 * batch * hn * 32))) return rc;
+    fe* t0 = (fe*)ctx->scratch;
+    fe* t1 = t0 + batch * hn;
+    // values on zeta <w^2>: the same zeta^(i mod 3) scaling of the coefficients, then the transform of half the size
+    NttFuse fuse;
+    fuse.pre_mode = 1;
+    to_fe(fuse.pre[0], HFR.r);
+    to_fe(fuse.pre[1], dom->g_coset);
+    to_fe(fuse.pre[2], dom->g_coset_inv);
+    return ntt_run(ctx, dom->plan_half_fwd, (const fe*)d_coeff, n, (uint32_t)n, (fe*)d_out, out_stride, (uint32_t)hn, batch, fuse,
+                   t0, t1);
+}
+
 int zkhip_extend_half_dev(zkhip_domain* dom, const uint64_t* d_even, uint64_t* d_odd, size_t batch) {
     if (!dom) return ZKHIP_ERR_INVALID;
     zkhip_ctx* ctx = dom->ctx;
@@ -343,14 +377,8 @@ int zkhip_extend_half_dev(zkhip_domain* dom, const uint64_t* d_even, uint64_t* d
     ZK_HIP(ctx, hipSetDevice(ctx->device));
     const uint32_t hk = dom->extended_k - 1;
     const size_t hn = (size_t)1 << hk;
-    int rc = ZKHIP_OK;
-    if (!dom->plan_half_fwd) {
-        uint64_t w[4], wi[4];
-        h_mul(HFR, w, dom->extended_omega, dom->extended_omega);
-        h_mul(HFR, wi, dom->extended_omega_inv, dom->extended_omega_inv);
-        if ((rc = zkhip_internal_get_plan(ctx, hk, w, &dom->plan_half_fwd))) return rc;
-        if ((rc = zkhip_internal_get_plan(ctx, hk, wi, &dom->plan_half_inv))) return rc;
-    }
+    int rc = half_plans(dom);
+    if (rc) return rc;
     // d_odd = inverse transform of the values on zeta <w^2> (the coefficients of P(zeta X), not yet divided by their
     // count); coefficient m times w^m / count; forward transform: P on zeta w <w^2>, the odd-indexed points
     rc = ensure_scratch(ctx, 2 * batch * hn * 32);

@@ -1101,6 +1101,7 @@ struct EvalhProgram {
     uint32_t n_terms = 0, sc_y0 = 0;     // scalars sc_y0 + i hold y^(n_terms - 1 - i): the weight of term i of h
     std::vector<uint32_t> gaps;          // followed by y^gaps[q]
     uint64_t stats[4] = {0, 0, 0, 0};
+    std::vector<uint8_t> col_used;       // per column of the unified table: does any instruction read it
 };
 
 // Position of every column group in the unified column table:
@@ -1362,6 +1363,13 @@ static int build_program(zkhip_ctx* ctx, const zkhip_evalh_desc* desc, bool lagr
         memcpy(k32, FrParams::TWO5, 32);
         for (size_t i = 0; i + 4 <= b.consts.size(); i += 4) h_mul(HFR, &b.consts[i], &b.consts[i], k32);
     }
+    out.col_used.assign(L.total, 0);
+    for (size_t pc = 0; pc < ni; pc++)
+        for (size_t q = 2; q < IW; q++) {
+            const uint32_t w = b.words[pc * IW + q];
+            if ((w >> 28) == K_COL) out.col_used[(w & 0x0fffffffu) >> 12] = 1;
+        }
+    if ((result >> 28) == K_COL) out.col_used[(result & 0x0fffffffu) >> 12] = 1;
     out.words.swap(b.words);
     out.consts.swap(b.consts);
     out.rots.swap(b.rots);
@@ -1476,6 +1484,22 @@ extern "C" int zkhip_evaluate_h_prepare(zkhip_domain* dom, const zkhip_evalh_des
     rc = get_program(ctx, desc, desc->basis == ZKHIP_BASIS_LAGRANGE, prog);
     if (!rc) memcpy(ctx->evalh_stats, prog->stats, sizeof ctx->evalh_stats);   // zkhip_evaluate_h_last_stats: of this program
     return rc;
+}
+
+extern "C" int zkhip_evaluate_h_columns_used(zkhip_domain* dom, const zkhip_evalh_desc* desc, uint8_t* used, uint32_t capacity,
+                                             uint32_t* count) {
+    if (!dom) return ZKHIP_ERR_INVALID;
+    zkhip_ctx* ctx = dom->ctx;
+    ZK_CHECK(ctx, desc && used && count, "evaluate_h_columns_used: null pointer");
+    int rc = check_shape(ctx, desc);
+    if (rc) return rc;
+    std::shared_ptr<EvalhProgram> prog;
+    if ((rc = get_program(ctx, desc, desc->basis == ZKHIP_BASIS_LAGRANGE, prog))) return rc;
+    ZK_CHECK(ctx, prog->col_used.size() <= capacity, "evaluate_h_columns_used: %zu columns, room for %u", prog->col_used.size(),
+             capacity);
+    memcpy(used, prog->col_used.data(), prog->col_used.size());
+    *count = (uint32_t)prog->col_used.size();
+    return ZKHIP_OK;
 }
 
 extern "C" int zkhip_evaluate_h(zkhip_domain* dom, const zkhip_evalh_desc* desc, uint64_t* out) {

@@ -108,6 +108,12 @@ def prepare(dom, cs: ConstraintSystem, ev: Evaluator, terms=None):
     upstream builds `ProvingKey::ev`.  No column data is needed: the descriptor carries counts and graphs only.
     terms: the (selection, degree bound) of `EvalhCall.terms`; returns the program's size (instructions,
     multiplications, column reads, value slots per row)."""
+    dom.evaluate_h_prepare(_shape_only(cs, ev, terms).build(ffi.MEM_DEVICE, ffi.FORM_EXTENDED))
+    return dom.ctx.evaluate_h_last_stats()
+
+
+def _shape_only(cs: ConstraintSystem, ev: Evaluator, terms=None) -> EvalhCall:
+    """a call that carries the counts and graphs of the constraint system and no column data"""
     call = EvalhCall(cs, ev)
     call.terms = terms
     call.fixed, call.advice, call.instance = [0] * cs.num_fixed_columns, [0] * cs.num_advice_columns, [0] * cs.num_instance_columns
@@ -117,8 +123,31 @@ def prepare(dom, cs: ConstraintSystem, ev: Evaluator, terms=None):
     call.lookups = [(0, 0, 0)] * len(cs.lookups)
     call.perm_sigma = [0] * len(cs.permutation_columns)
     call.perm_z = [0] * cs.num_permutation_sets()
-    dom.evaluate_h_prepare(call.build(ffi.MEM_DEVICE, ffi.FORM_EXTENDED))
-    return dom.ctx.evaluate_h_last_stats()
+    return call
+
+
+def columns_used(dom, cs: ConstraintSystem, ev: Evaluator, terms=None):
+    """Which columns the program of this constraint system (restricted to `terms` as in `prepare`) reads: a dict of
+    boolean lists  fixed / advice / instance / l (l0, l_last, l_active) / perm_z / perm_sigma  and  lookups  (one
+    (product, permuted input, permuted table) triple per lookup)."""
+    flags = [bool(v) for v in dom.evaluate_h_columns_used(_shape_only(cs, ev, terms).build(ffi.MEM_DEVICE, ffi.FORM_EXTENDED))]
+    out, at = {}, 0
+
+    def take(count):
+        nonlocal at
+        at += count
+        return flags[at - count:at]
+
+    out["fixed"], out["advice"], out["instance"] = take(cs.num_fixed_columns), take(cs.num_advice_columns), take(cs.num_instance_columns)
+    out["l"] = take(3)
+    sets = cs.num_permutation_sets()
+    if sets:
+        take(1)                                                    # the column of X values, which the library keeps itself
+    out["perm_z"] = take(sets)
+    out["perm_sigma"] = take(len(cs.permutation_columns) if sets else 0)
+    out["lookups"] = [tuple(take(3)) for _ in cs.lookups]
+    assert at == len(flags), (at, len(flags))
+    return out
 
 
 # ---- low-degree terms on half the extended domain ---------------------------------------------------------------------
@@ -150,6 +179,24 @@ def warm_up_split(ctx, dom):
     dom.extend_half_dev(d, d + half * 32)
     ctx.sync()
     ctx.free(d)
+
+
+def extend_for_split(dom, whole_rows, src: int, dst: int):
+    """Coefficient polynomials back to back at src -> extended vectors in the parity-split layout back to back at dst, one
+    per flag of `whole_rows`: a flagged polynomial gets every row (`coeff_to_extended_split_dev`), another -- one that no
+    term above the degree bound reads, `columns_used(.., (TERMS_HIGH, bound))` -- the even-indexed half only, by a
+    transform of half the size; its odd-indexed half is left as it is and never read."""
+    n, en = dom.n, dom.extended_len
+    i, cnt = 0, len(whole_rows)
+    while i < cnt:
+        j = i
+        while j + 1 < cnt and bool(whole_rows[j + 1]) == bool(whole_rows[i]):
+            j += 1
+        if whole_rows[i]:
+            dom.coeff_to_extended_split_dev(src + i * n * 32, dst + i * en * 32, j - i + 1)
+        else:
+            dom.coeff_to_extended_half_dev(src + i * n * 32, dst + i * en * 32, en, j - i + 1)
+        i = j + 1
 
 
 def shifted(call: EvalhCall, offset: int) -> EvalhCall:

@@ -29,7 +29,8 @@ EXPORTS = [
     "zkhip_divide_by_vanishing_poly",
     "zkhip_lagrange_to_coeff_dev", "zkhip_coeff_to_lagrange_dev", "zkhip_coeff_to_extended_dev",
     "zkhip_extended_to_coeff_dev", "zkhip_divide_by_vanishing_poly_dev",
-    "zkhip_coeff_to_extended_split_dev", "zkhip_extend_half_dev",
+    "zkhip_coeff_to_extended_split_dev", "zkhip_extend_half_dev", "zkhip_coeff_to_extended_half_dev",
+    "zkhip_evaluate_h_columns_used",
     "zkhip_evaluate_h", "zkhip_evaluate_h_last_stats", "zkhip_evaluate_h_cache_stats", "zkhip_evaluate_h_prepare",
     "zkhip_coeff_to_cosets_dev", "zkhip_extended_to_cosets_dev", "zkhip_cosets_to_extended_dev",
     "zkhip_batch_invert_dev", "zkhip_prefix_product_dev", "zkhip_prefix_product_noalloc_dev", "zkhip_permutation_product_dev", "zkhip_lookup_product_dev",
@@ -582,6 +583,13 @@ class Domain:
         """values of a polynomial of degree < 2^(extended_k - 1) on the even-indexed extended rows -> on the odd-indexed"""
         self.ctx._ck(self._l.zkhip_extend_half_dev(self.h, C.c_void_p(d_even), C.c_void_p(d_odd), C.c_size_t(batch)))
 
+    def coeff_to_extended_half_dev(self, d_coeff: int, d_out: int, out_stride: int | None = None, batch: int = 1):
+        """coeff_to_extended onto the even-indexed extended rows only (the first half of the parity-split layout); members
+        land out_stride elements apart (default: back to back)"""
+        stride = self.extended_len // 2 if out_stride is None else out_stride
+        self.ctx._ck(self._l.zkhip_coeff_to_extended_half_dev(self.h, C.c_void_p(d_coeff), C.c_void_p(d_out),
+                                                              C.c_size_t(stride), C.c_size_t(batch)))
+
     def extended_to_coeff_dev(self, d_ext: int, d_out: int, batch: int = 1):
         self.ctx._ck(self._l.zkhip_extended_to_coeff_dev(self.h, C.c_void_p(d_ext), C.c_void_p(d_out),
                                                          C.c_size_t(batch)))
@@ -641,6 +649,15 @@ class Domain:
     def evaluate_h_prepare(self, desc: EvalhDesc):
         """`Evaluator::new(cs)`: builds the program of the descriptor's shape and keeps it in the context"""
         self.ctx._ck(self._l.zkhip_evaluate_h_prepare(self.h, C.byref(desc)))
+
+    def evaluate_h_columns_used(self, desc: EvalhDesc):
+        """one flag per column of the program's column table (see zkhip_evaluate_h_columns_used for the order)"""
+        cap = (desc.num_fixed + desc.num_advice + desc.num_instance + 4 + desc.num_perm_sets + desc.num_perm_columns
+               + 3 * desc.num_lookups)
+        out = np.zeros(cap, dtype=np.uint8)
+        count = C.c_uint32(0)
+        self.ctx._ck(self._l.zkhip_evaluate_h_columns_used(self.h, C.byref(desc), _p(out), C.c_uint32(cap), C.byref(count)))
+        return out[:count.value]
 
     def evaluate_h(self, desc: EvalhDesc, out_dev: int | None = None):
         """`Evaluator::evaluate_h`.  Host descriptor -> numpy result; device descriptor -> writes out_dev."""

@@ -281,6 +281,7 @@ class ProvingKey:
         self.transcript_repr = 0
         self.ev = None                        # plonk.Evaluator, built once per key as upstream's `ProvingKey::ev`
         self.split_programs = None            # multiplications per row of the low / high / whole evaluate_h programs
+        self.high_degree_columns = None       # split evaluation: `evalh_host.columns_used` of the terms above the bound
 
     def pointers(self):
         return self.polys.pointers() + self.fixed_values
@@ -327,6 +328,7 @@ def keygen(ctx, dom, params: ParamsKZG, cs: ConstraintSystem, fixed, assembly, d
                                split=split)
     if split:
         evalh_host.warm_up_split(ctx, dom)
+        pk.high_degree_columns = evalh_host.columns_used(dom, cs, pk.ev, (ffi.TERMS_HIGH, (dom.extended_len // dom.n) // 2))
     pk.fixed_values = [ctx.upload(a) for a in fixed_limbs]
     if pk.fixed_values:
         pk.fixed_commitments = [affine_ints(j) for j in params.commit_lagrange(pk.fixed_values)]
@@ -683,6 +685,20 @@ def create_proof(ctx, dom, params: ParamsKZG, pk: ProvingKey, advice, instance, 
             raise ValueError("the proving key stores its extended vectors split by row parity (keygen(..., low_degree_split)): "
                              "it proves on one GPU with every coset resident")
         to_extended = dom.coeff_to_extended_split_dev if split else dom.coeff_to_extended_dev
+        # split evaluation: the odd-indexed rows of a column are read by the terms above the degree bound only, so a
+        # column that none of them names is extended onto the even-indexed half alone (a transform of half the size)
+        whole_rows = [True] * max(total, 1)
+        if split and pk.high_degree_columns is not None:
+            used = pk.high_degree_columns
+            whole_rows = (list(used["advice"]) + list(used["instance"]) + [f for t in used["lookups"] for f in t]
+                          + list(used["perm_z"]))
+
+        def extend_slots(s0, cnt, src, dst):
+            """coefficient form of the polynomial slots s0 .. s0 + cnt - 1 (back to back at src) -> extended form at dst"""
+            if split:
+                evalh_host.extend_for_split(dom, whole_rows[s0:s0 + cnt], src, dst)
+            else:
+                to_extended(src, dst, cnt)
         early_ext = early_coeff = None
         early_done = set()
         held = workspace is not None and ("extended", en * max(total, 1) * 32) in workspace.blocks
@@ -705,7 +721,7 @@ def create_proof(ctx, dom, params: ParamsKZG, pk: ProvingKey, advice, instance, 
                 c0, cnt = cols[i], j - i + 1
                 ctx.copy_dev(early_coeff + c0 * n * 32, adv[c0], cnt * n * 32)
                 dom.lagrange_to_coeff_dev(early_coeff + c0 * n * 32, cnt)
-                to_extended(early_coeff + c0 * n * 32, early_ext + c0 * en * 32, cnt)
+                extend_slots(c0, cnt, early_coeff + c0 * n * 32, early_ext + c0 * en * 32)
                 early_done.update(cols[i:j + 1])
                 i = j + 1
 
@@ -927,7 +943,7 @@ def create_proof(ctx, dom, params: ParamsKZG, pk: ProvingKey, advice, instance, 
         if not sharded and coset_groups == 1:
             ext_block = early_ext if early_ext is not None else alloc(en * max(total, 1), "extended")
             for s0, cnt in runs(todo):
-                to_extended(slot[s0], ext_block + s0 * en * 32, cnt)
+                extend_slots(s0, cnt, slot[s0], ext_block + s0 * en * 32)
             fill(lambda p: ext_block + (p - block) // (n * 32) * en * 32, lambda p: p)
             mark("quotient_evaluate_h")
             if split:

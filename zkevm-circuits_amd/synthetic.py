@@ -70,7 +70,7 @@ def synthetic_cs(num_advice=8, num_fixed=4, num_instance=1, num_gate_polys=16, m
     return cs
 
 
-def satisfied_cs(units, degree9=False, extra_gates=0, lookup_copies=1, perm_units=None):
+def satisfied_cs(units, degree9=False, extra_gates=0, lookup_copies=1, perm_units=None, plain_lookups=False):
     """A constraint system that `satisfied_witness` satisfies, for proofs that a verifier can check: `units` copies side
     by side of five advice columns a, b, c, s, d with the gates q (a b - c), a challenge multiple of it,
     q_acc (s(+1) - s - c) and q_prev (d - a(-1) - b), one lookup of (q a, q b) in a fixed table of squares per unit, three
@@ -79,7 +79,9 @@ def satisfied_cs(units, degree9=False, extra_gates=0, lookup_copies=1, perm_unit
     lookup_copies: how often a unit declares its lookup (an int, or one count per unit): halo2 does not merge equal lookup
     arguments, so every copy costs the prover a compression, a sort, a grand product and three commitments -- the way to
     give a stand-in the lookup count of a real circuit without more columns.  perm_units: only the first that many units
-    put their columns into the permutation argument (None: all), for circuits with few equality-enabled columns."""
+    put their columns into the permutation argument (None: all), for circuits with few equality-enabled columns.
+    plain_lookups: the lookups read (a, b) on every row, without the selector (the witness has (0, 0), a table row, where
+    q = 0): inputs of degree one, as cell-manager lookups have them, so the lookup's product term has degree four."""
     copies = [lookup_copies] * units if isinstance(lookup_copies, int) else list(lookup_copies)
     assert len(copies) == units
     perm_units = units if perm_units is None else min(perm_units, units)
@@ -108,7 +110,7 @@ def satisfied_cs(units, degree9=False, extra_gates=0, lookup_copies=1, perm_unit
         cs.gates.append([Product(q_acc, Sub(Sub(Advice(5 * u + 3, 1), s), c)),
                          Product(q_prev, Sub(Sub(d, Advice(5 * u, -1)), b))])
         for _ in range(copies[u]):
-            cs.lookups.append(Lookup([Product(q, a), Product(q, b)], [Fixed(2), Fixed(3)]))
+            cs.lookups.append(Lookup([a, b] if plain_lookups else [Product(q, a), Product(q, b)], [Fixed(2), Fixed(3)]))
         if u < perm_units:
             cs.permutation_columns += [(ANY_ADVICE, 5 * u + 3), (ANY_ADVICE, 5 * u), (ANY_ADVICE, 5 * u + 2)]
     cs.permutation_columns.append((ANY_INSTANCE, 0))
