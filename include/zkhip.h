@@ -253,6 +253,15 @@ int zkhip_evaluate_h_cache_stats(zkhip_ctx* ctx, uint64_t out[2]);
  * generation runs it (`ProvingKey::ev`).  Only the counts, the graphs and the permutation column kinds / indices of the
  * descriptor are read; every polynomial pointer may be NULL. */
 int zkhip_evaluate_h_prepare(zkhip_domain* dom, const zkhip_evalh_desc* desc);
+/* Several graphs over the same Lagrange-basis columns in one call: what `plonk::lookup::prover::Argument::commit_permuted`
+ * (reached from /root/reference/zkevm-circuits/benches/benchmark_list/main.rs:353-354 through create_proof) does lookup after
+ * lookup with `compress_expressions` -- one theta-compressed input and one table expression per lookup, each a graph whose value
+ * over the 2^k rows goes to d_outs[i].  desc: basis = ZKHIP_BASIS_LAGRANGE, mem = ZKHIP_MEM_DEVICE, the fixed / advice /
+ * instance columns (2^k rows each), challenges and theta; its custom_gates, lookup and permutation fields are not read.
+ * Equal to `count` calls of zkhip_evaluate_h with custom_gates = &graphs[i], without the host waiting for the device
+ * between them: the programs are staged together and launched back to back. */
+int zkhip_evaluate_graphs_dev(zkhip_domain* dom, const zkhip_evalh_desc* desc, const zkhip_graph* graphs, uint32_t count,
+                              uint64_t* const* d_outs);
 /* Which columns the program of the descriptor's shape reads (built and kept like zkhip_evaluate_h_prepare does): used[c] = 1
  * or 0 for column c of the order  fixed | advice | instance | l0, l_last, l_active | X (only with a permutation argument) |
  * permutation products | permutation sigmas | per lookup (product, permuted input, permuted table);  *count = their number

@@ -162,6 +162,7 @@ extern "C" {
     pub fn zkhip_evaluate_h_last_stats(ctx: *mut zkhip_ctx, out: *mut u64) -> c_int;
     pub fn zkhip_evaluate_h_cache_stats(ctx: *mut zkhip_ctx, out: *mut u64) -> c_int;
     pub fn zkhip_evaluate_h_prepare(dom: *mut zkhip_domain, desc: *const zkhip_evalh_desc) -> c_int;
+    pub fn zkhip_evaluate_graphs_dev(dom: *mut zkhip_domain, desc: *const zkhip_evalh_desc, graphs: *const zkhip_graph, count: u32, d_outs: *const *mut u64) -> c_int;
     pub fn zkhip_evaluate_h_columns_used(dom: *mut zkhip_domain, desc: *const zkhip_evalh_desc, used: *mut u8, capacity: u32, count: *mut u32) -> c_int;
 
     // ---- grand products and openings (the rest of plonk::prover::create_proof)

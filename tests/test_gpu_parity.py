@@ -1404,6 +1404,27 @@ def test_lookup_compress_expressions_on_lagrange_basis(ctx, k, kw):
     call_h = evalh_host.lookup_compress_call(cs, cs.lookups[0].input_expressions, cols["fixed"], cols["advice"],
                                              cols["instance"], challenges, theta)
     assert np.array_equal(ctx.download(d_out, (n, 4)), d.evaluate_h(call_h.build(ffi.MEM_HOST, ffi.FORM_EXTENDED)))
+    # every lookup's two sides in one call (the kernels back to back, one wait): the same values as graph by graph; twice,
+    # so that the second call finds its programs cached and rewrites the staged tables of the first
+    expected = []
+    for lk in cs.lookups:
+        for exprs in (lk.input_expressions, lk.table_expressions):
+            c = evalh_host.lookup_compress_call(cs, exprs, cols["fixed"], cols["advice"], cols["instance"], challenges, theta)
+            expected.append(d.evaluate_h(c.build(ffi.MEM_HOST, ffi.FORM_EXTENDED)))
+    d_ins = [ctx.alloc(n * 32) for _ in cs.lookups]
+    d_tbs = [ctx.alloc(n * 32) for _ in cs.lookups]
+    for subset in (cs.lookups, cs.lookups[:1]):
+        evalh_host.compress_lookups_dev(d, cs, subset, dev["fixed"], dev["advice"], dev["instance"], challenges, theta,
+                                        d_ins[:len(subset)], d_tbs[:len(subset)])
+        for i in range(len(subset)):
+            assert np.array_equal(ctx.download(d_ins[i], (n, 4)), expected[2 * i])
+            assert np.array_equal(ctx.download(d_tbs[i], (n, 4)), expected[2 * i + 1])
+    evalh_host.compress_lookups_dev(d, cs, [], dev["fixed"], dev["advice"], dev["instance"], challenges, theta, [], [])
+    with pytest.raises(ffi.ZkhipError):       # a null output
+        evalh_host.compress_lookups_dev(d, cs, cs.lookups[:1], dev["fixed"], dev["advice"], dev["instance"], challenges, theta,
+                                        [0], d_tbs[:1])
+    for p_ in d_ins + d_tbs:
+        ctx.free(p_)
     # the Lagrange basis takes neither lookups nor coefficient form
     with pytest.raises(ffi.ZkhipError):
         d.evaluate_h(call_h.build(ffi.MEM_HOST, ffi.FORM_COEFF))

@@ -33,13 +33,14 @@ if os.environ.get("TRACE_SYNC"):
         wrap(dom, name)
     wrap(ctx, "msm_batch_dev")
 print("keygen ok", time.perf_counter() - T0, flush=True)
-prover.create_proof(ctx, dom, params, pk, advice, instance, prover.FieldRng(k), prover.Blake2bWrite())
+ws = prover.ProofWorkspace(ctx)
+prover.create_proof(ctx, dom, params, pk, advice, instance, prover.FieldRng(k), prover.Blake2bWrite(), workspace=ws)
 print("first proof ok", time.perf_counter() - T0, flush=True)
 pr = cProfile.Profile()
 t0 = time.perf_counter()
 pr.enable()
 ph = {}
-prover.create_proof(ctx, dom, params, pk, advice, instance, prover.FieldRng(k), prover.Blake2bWrite(), ph)
+prover.create_proof(ctx, dom, params, pk, advice, instance, prover.FieldRng(k), prover.Blake2bWrite(), ph, workspace=ws)
 pr.disable()
 print("create_proof", time.perf_counter() - t0, ph)
 pstats.Stats(pr).sort_stats("cumulative").print_stats(45)

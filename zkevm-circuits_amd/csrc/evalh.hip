@@ -1463,6 +1463,113 @@ static int check_shape(zkhip_ctx* ctx, const zkhip_evalh_desc* desc) {
     return ZKHIP_OK;
 }
 
+// The scalar table of one call, appended to `scal` in the interpreter's 2^261 Montgomery domain (x R -> 32 x R): beta,
+// gamma, theta, y, one, the challenges, `extra` (beta * delta^c per permutation column), then the program's term weights
+// y^(n_terms - 1 - i) and the y^gap of its groups.
+static int call_scalars(zkhip_ctx* ctx, const zkhip_evalh_desc* desc, const EvalhProgram& prog, const std::vector<uint64_t>& extra,
+                        std::vector<uint64_t>& scal) {
+    const size_t at = scal.size();
+    scal.resize(at + (size_t)(SC_CHALLENGE0 + desc->num_challenges) * 4);
+    uint64_t* s = &scal[at];
+    memcpy(&s[4 * SC_BETA], desc->beta, 32);
+    memcpy(&s[4 * SC_GAMMA], desc->gamma, 32);
+    memcpy(&s[4 * SC_THETA], desc->theta, 32);
+    memcpy(&s[4 * SC_Y], desc->y, 32);
+    memcpy(&s[4 * SC_ONE], HFR.r, 32);
+    if (desc->num_challenges) memcpy(&s[4 * SC_CHALLENGE0], desc->challenges, (size_t)desc->num_challenges * 32);
+    scal.insert(scal.end(), extra.begin(), extra.end());
+    if (prog.n_terms) {
+        ZK_CHECK(ctx, scal.size() - at == (size_t)prog.sc_y0 * 4, "evaluate_h: internal error, scalar table mismatch");
+        scal.resize(at + ((size_t)prog.sc_y0 + prog.n_terms) * 4);
+        uint64_t cur[4], y[4];
+        memcpy(cur, HFR.r, 32);
+        memcpy(y, desc->y, 32);
+        for (uint32_t i = prog.n_terms; i-- > 0;) {      // term i weighs y^(n_terms - 1 - i)
+            memcpy(&scal[at + ((size_t)prog.sc_y0 + i) * 4], cur, 32);
+            h_mul(HFR, cur, cur, y);
+        }
+        for (uint32_t g : prog.gaps) {
+            h_pow(HFR, cur, y, g);
+            scal.insert(scal.end(), cur, cur + 4);
+        }
+    }
+    uint64_t k32[4];
+    memcpy(k32, FrParams::TWO5, 32);
+    for (size_t i = at; i + 4 <= scal.size(); i += 4) h_mul(HFR, &scal[i], &scal[i], k32);
+    return ZKHIP_OK;
+}
+
+// size of call_scalars' table for this program, in field elements
+static size_t call_scalar_count(const zkhip_evalh_desc* desc, const EvalhProgram& prog, size_t extra_elements) {
+    return (size_t)SC_CHALLENGE0 + desc->num_challenges + extra_elements + (prog.n_terms ? prog.n_terms + prog.gaps.size() : 0);
+}
+
+// Link: operand words -> (header, device pointer).  `linked`: n_instr * INS_WORDS words; res_link: the result operand.
+static int link_program(zkhip_ctx* ctx, const EvalhProgram& prog, const std::vector<const fe*>& cols, int32_t rot_scale,
+                        const fe* d_scal, const fe* d_consts, uint32_t* linked, uint32_t res_link[3]) {
+    for (int32_t r : prog.rots)
+        ZK_CHECK(ctx, std::abs((int64_t)r) * rot_scale < (1 << 26), "evaluate_h: rotation %d out of range", r);
+    auto link = [&](uint32_t w, uint32_t* o) {
+        const uint32_t kind = w >> 28, pl = w & 0x0fffffffu;
+        uint64_t ptr = 0;
+        uint32_t hdr;
+        switch (kind) {
+            case K_CONST: hdr = L_UNI << 28; ptr = (uint64_t)(uintptr_t)(d_consts + pl); break;
+            case K_SCALAR: hdr = L_UNI << 28; ptr = (uint64_t)(uintptr_t)(d_scal + pl); break;
+            case K_COL: {
+                const int32_t delta = prog.rots[pl & 0xfff] * rot_scale;
+                hdr = (L_ROW << 28) | ((uint32_t)delta & 0x0fffffffu);
+                ptr = (uint64_t)(uintptr_t)cols[pl >> 12];
+                break;
+            }
+            case K_SLOT: hdr = (L_SLOT << 28) | pl; break;
+            case K_ACC: hdr = L_ACC << 28; break;
+            default: hdr = L_ZERO << 28; break;
+        }
+        o[0] = hdr;
+        o[1] = (uint32_t)ptr;
+        o[2] = (uint32_t)(ptr >> 32);
+    };
+    const size_t n_instr = prog.words.size() / IW;
+    memset(linked, 0, n_instr * INS_WORDS * 4);
+    for (size_t pc = 0; pc < n_instr; pc++) {
+        uint32_t* o = &linked[pc * INS_WORDS];
+        const uint32_t* w = &prog.words[pc * IW];
+        o[0] = w[0] | ((w[1] == DST_ACC_V ? DST_ACC : w[1]) << DST_SHIFT);
+        link(w[2], o + 1);
+        link(w[3], o + 4);
+        link(w[4], o + 7);
+        link(w[5], o + 10);
+    }
+    link(prog.result, res_link);
+    return ZKHIP_OK;
+}
+
+static int launch_program(zkhip_ctx* ctx, const EvalhProgram& prog, const uint32_t* d_prog, const uint32_t res_link[3],
+                          int32_t* d_spill, uint32_t log_rows, size_t row_first, size_t rows, fe* d_out) {
+    InterpArgs a;
+    memset(&a, 0, sizeof a);
+    a.n_instr = (uint32_t)(prog.words.size() / IW);
+    a.result_hdr = res_link[0];
+    a.lds_slots = prog.lds_slots;
+    a.spill = prog.n_slots > prog.lds_slots ? d_spill : nullptr;
+    a.log_size = log_rows;
+    a.row_first = (uint32_t)row_first;
+    a.rows = (uint32_t)rows;
+    a.out = d_out;
+    const size_t lds_bytes = (size_t)(prog.lds_slots > 1 ? prog.lds_slots - 1 : 1) * EV_THREADS * 36;
+    if (!ctx->evalh_attr_set) {
+        ZK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(evalh_interp_kernel),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        ctx->evalh_attr_set = true;
+    }
+    TimedRegion tr(ctx, "evalh");
+    hipLaunchKernelGGL(evalh_interp_kernel, dim3((unsigned)((rows + EV_THREADS - 1) / EV_THREADS)), dim3(EV_THREADS), lds_bytes,
+                       ctx->stream, d_prog, a);
+    ZK_HIP(ctx, hipGetLastError());
+    return ZKHIP_OK;
+}
+
 void evalh_drop_ctx(zkhip_ctx* ctx) {
     ctx->evalh_cache.clear();
     for (int i = 0; i < 4; i++) {
@@ -1638,35 +1745,9 @@ extern "C" int zkhip_evaluate_h(zkhip_domain* dom, const zkhip_evalh_desc* desc,
     }
     ZK_CHECK(ctx, cols.size() == L.total && prog->n_cols == L.total, "evaluate_h: internal error, column table mismatch");
 
-    // ---- scalars of this call, in the interpreter's 2^261 Montgomery domain: x R -> 32 x R ----------------------
-    std::vector<uint64_t> scal((size_t)(SC_CHALLENGE0 + desc->num_challenges) * 4);
-    memcpy(&scal[4 * SC_BETA], desc->beta, 32);
-    memcpy(&scal[4 * SC_GAMMA], desc->gamma, 32);
-    memcpy(&scal[4 * SC_THETA], desc->theta, 32);
-    memcpy(&scal[4 * SC_Y], desc->y, 32);
-    memcpy(&scal[4 * SC_ONE], HFR.r, 32);
-    if (desc->num_challenges) memcpy(&scal[4 * SC_CHALLENGE0], desc->challenges, (size_t)desc->num_challenges * 32);
-    scal.insert(scal.end(), extra_scalars.begin(), extra_scalars.end());
-    if (prog->n_terms) {
-        ZK_CHECK(ctx, scal.size() == (size_t)prog->sc_y0 * 4, "evaluate_h: internal error, scalar table mismatch");
-        scal.resize(((size_t)prog->sc_y0 + prog->n_terms) * 4);
-        uint64_t cur[4], y[4];
-        memcpy(cur, HFR.r, 32);
-        memcpy(y, desc->y, 32);
-        for (uint32_t i = prog->n_terms; i-- > 0;) {      // term i weighs y^(n_terms - 1 - i)
-            memcpy(&scal[((size_t)prog->sc_y0 + i) * 4], cur, 32);
-            h_mul(HFR, cur, cur, y);
-        }
-        for (uint32_t g : prog->gaps) {
-            h_pow(HFR, cur, y, g);
-            scal.insert(scal.end(), cur, cur + 4);
-        }
-    }
-    {
-        uint64_t k32[4];
-        memcpy(k32, FrParams::TWO5, 32);
-        for (size_t i = 0; i + 4 <= scal.size(); i += 4) h_mul(HFR, &scal[i], &scal[i], k32);
-    }
+    // ---- scalars of this call ------------------------------------------------------------------------------------
+    std::vector<uint64_t> scal;
+    if ((rc = call_scalars(ctx, desc, *prog, extra_scalars, scal))) return rc;
 
     const size_t n_instr = prog->words.size() / IW;
     void*& d_prog_v = ctx->evalh_buf[0];
@@ -1686,45 +1767,11 @@ extern "C" int zkhip_evaluate_h(zkhip_domain* dom, const zkhip_evalh_desc* desc,
     if (!prog->consts.empty())
         ZK_HIP(ctx, hipMemcpyAsync(d_consts, prog->consts.data(), prog->consts.size() * 8, hipMemcpyHostToDevice, ctx->stream));
 
-    // ---- link: operand words -> (header, device pointer) -------------------------------------------------------
-    const int32_t rot_scale = (int32_t)cl.num;
-    for (int32_t r : prog->rots)
-        ZK_CHECK(ctx, std::abs((int64_t)r) * rot_scale < (1 << 26), "evaluate_h: rotation %d out of range", r);
-    auto link = [&](uint32_t w, uint32_t* o) {
-        const uint32_t kind = w >> 28, pl = w & 0x0fffffffu;
-        uint64_t ptr = 0;
-        uint32_t hdr;
-        switch (kind) {
-            case K_CONST: hdr = L_UNI << 28; ptr = (uint64_t)(uintptr_t)(d_consts + pl); break;
-            case K_SCALAR: hdr = L_UNI << 28; ptr = (uint64_t)(uintptr_t)(d_scal + pl); break;
-            case K_COL: {
-                const int32_t delta = prog->rots[pl & 0xfff] * rot_scale;
-                hdr = (L_ROW << 28) | ((uint32_t)delta & 0x0fffffffu);
-                ptr = (uint64_t)(uintptr_t)cols[pl >> 12];
-                break;
-            }
-            case K_SLOT: hdr = (L_SLOT << 28) | pl; break;
-            case K_ACC: hdr = L_ACC << 28; break;
-            default: hdr = L_ZERO << 28; break;
-        }
-        o[0] = hdr;
-        o[1] = (uint32_t)ptr;
-        o[2] = (uint32_t)(ptr >> 32);
-    };
     std::vector<uint32_t>& linked = ctx->evalh_linked;
-    linked.assign(n_instr * INS_WORDS, 0);
-    for (size_t pc = 0; pc < n_instr; pc++) {
-        uint32_t* o = &linked[pc * INS_WORDS];
-        const uint32_t* w = &prog->words[pc * IW];
-        o[0] = w[0] | ((w[1] == DST_ACC_V ? DST_ACC : w[1]) << DST_SHIFT);
-        link(w[2], o + 1);
-        link(w[3], o + 4);
-        link(w[4], o + 7);
-        link(w[5], o + 10);
-    }
+    linked.resize(std::max<size_t>(1, n_instr * INS_WORDS));
     uint32_t res_link[3];
-    link(prog->result, res_link);
-    if (n_instr) ZK_HIP(ctx, hipMemcpyAsync(d_prog_v, linked.data(), linked.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+    if ((rc = link_program(ctx, *prog, cols, (int32_t)cl.num, d_scal, d_consts, linked.data(), res_link))) return rc;
+    if (n_instr) ZK_HIP(ctx, hipMemcpyAsync(d_prog_v, linked.data(), n_instr * INS_WORDS * 4, hipMemcpyHostToDevice, ctx->stream));
     fe* d_out;
     if (host) {
         void* p;
@@ -1733,32 +1780,98 @@ extern "C" int zkhip_evaluate_h(zkhip_domain* dom, const zkhip_evalh_desc* desc,
     } else {
         d_out = (fe*)out;
     }
-    InterpArgs a;
-    memset(&a, 0, sizeof a);
-    a.n_instr = (uint32_t)n_instr;
-    a.result_hdr = res_link[0];
-    a.lds_slots = prog->lds_slots;
-    a.spill = prog->n_slots > prog->lds_slots ? (int32_t*)d_spill_v : nullptr;
-    a.log_size = log_rows;
-    a.row_first = (uint32_t)row_first;
-    a.rows = (uint32_t)rows;
-    a.out = d_out;
-    const size_t lds_bytes = (size_t)(prog->lds_slots > 1 ? prog->lds_slots - 1 : 1) * EV_THREADS * 36;
-    if (!ctx->evalh_attr_set) {
-        ZK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(evalh_interp_kernel),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        ctx->evalh_attr_set = true;
-    }
-    {
-        TimedRegion tr(ctx, "evalh");
-        hipLaunchKernelGGL(evalh_interp_kernel, dim3((unsigned)((rows + EV_THREADS - 1) / EV_THREADS)), dim3(EV_THREADS),
-                           lds_bytes, ctx->stream, (const uint32_t*)d_prog_v, a);
-        ZK_HIP(ctx, hipGetLastError());
-    }
+    if ((rc = launch_program(ctx, *prog, (const uint32_t*)d_prog_v, res_link, (int32_t*)d_spill_v, log_rows, row_first, rows, d_out)))
+        return rc;
     if (host) ZK_HIP(ctx, hipMemcpyAsync(out, d_out, rows * 32, hipMemcpyDeviceToHost, ctx->stream));
     // the scalars, the linked program and the spill buffer belong to the context and are rewritten by the next call
     ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return ZKHIP_OK;
+}
+
+extern "C" int zkhip_evaluate_graphs_dev(zkhip_domain* dom, const zkhip_evalh_desc* desc, const zkhip_graph* graphs, uint32_t count,
+                                         uint64_t* const* d_outs) {
+    if (!dom) return ZKHIP_ERR_INVALID;
+    zkhip_ctx* ctx = dom->ctx;
+    ZK_CHECK(ctx, desc && (count == 0 || (graphs && d_outs)), "evaluate_graphs: null pointer");
+    ZK_CHECK(ctx, desc->basis == ZKHIP_BASIS_LAGRANGE && desc->mem == ZKHIP_MEM_DEVICE && desc->poly_form == ZKHIP_FORM_EXTENDED &&
+                      !desc->row_count,
+             "evaluate_graphs: the graphs run over the 2^k rows of device-resident Lagrange-basis columns");
+    ZK_CHECK(ctx, !desc->num_fixed || desc->fixed_cosets, "evaluate_graphs: fixed columns missing");
+    ZK_CHECK(ctx, !desc->num_advice || desc->advice, "evaluate_graphs: advice columns missing");
+    ZK_CHECK(ctx, !desc->num_instance || desc->instance, "evaluate_graphs: instance columns missing");
+    ZK_CHECK(ctx, !desc->num_challenges || desc->challenges, "evaluate_graphs: challenges missing");
+    if (!count) return ZKHIP_OK;
+    ZK_HIP(ctx, hipSetDevice(ctx->device));
+    const uint32_t k = dom->k;
+    const size_t n = (size_t)1 << k;
+    std::vector<const fe*> cols;
+    cols.reserve((size_t)desc->num_fixed + desc->num_advice + desc->num_instance);
+    auto push = [&](const uint64_t* const* ps, uint32_t cnt) -> int {
+        for (uint32_t i = 0; i < cnt; i++) {
+            ZK_CHECK(ctx, ps[i] != nullptr, "evaluate_graphs: null column pointer");
+            cols.push_back((const fe*)ps[i]);
+        }
+        return (int)ZKHIP_OK;
+    };
+    int rc;
+    if ((rc = push(desc->fixed_cosets, desc->num_fixed)) || (rc = push(desc->advice, desc->num_advice)) ||
+        (rc = push(desc->instance, desc->num_instance)))
+        return rc;
+    // the programs (from the context's cache after the first proof) and where each one's words, scalars and constants go
+    std::vector<std::shared_ptr<EvalhProgram>> progs(count);
+    std::vector<size_t> at_words(count + 1, 0), at_scal(count + 1, 0), at_consts(count + 1, 0);
+    size_t spill_bytes = 0;
+    zkhip_evalh_desc one = *desc;
+    one.num_lookups = one.num_perm_sets = one.num_perm_columns = one.num_cosets = 0;
+    const std::vector<uint64_t> no_extra;
+    for (uint32_t i = 0; i < count; i++) {
+        ZK_CHECK(ctx, d_outs[i] != nullptr, "evaluate_graphs: null output pointer");
+        one.custom_gates = &graphs[i];
+        if ((rc = check_shape(ctx, &one)) || (rc = get_program(ctx, &one, true, progs[i]))) return rc;
+        const EvalhProgram& p = *progs[i];
+        ZK_CHECK(ctx, p.n_cols == cols.size(), "evaluate_graphs: internal error, column table mismatch");
+        at_words[i + 1] = at_words[i] + (p.words.size() / IW) * INS_WORDS;
+        at_scal[i + 1] = at_scal[i] + call_scalar_count(&one, p, 0) * 4;
+        at_consts[i + 1] = at_consts[i] + p.consts.size();
+        if (p.n_slots > p.lds_slots) spill_bytes = std::max(spill_bytes, (size_t)(p.n_slots - p.lds_slots) * n * 36);
+    }
+    if ((rc = grow(ctx, ctx->evalh_buf[0], ctx->evalh_buf_bytes[0], std::max<size_t>(1, at_words[count]) * 4)) ||
+        (rc = grow(ctx, ctx->evalh_buf[1], ctx->evalh_buf_bytes[1], at_scal[count] * 8)) ||
+        (rc = grow(ctx, ctx->evalh_buf[2], ctx->evalh_buf_bytes[2], std::max<size_t>(32, at_consts[count] * 8))) ||
+        (spill_bytes && (rc = grow(ctx, ctx->evalh_buf[3], ctx->evalh_buf_bytes[3], spill_bytes))))
+        return rc;
+    uint32_t* d_words = (uint32_t*)ctx->evalh_buf[0];
+    uint64_t* d_scal = (uint64_t*)ctx->evalh_buf[1];
+    uint64_t* d_consts = (uint64_t*)ctx->evalh_buf[2];
+    // one staging pass on the host, three copies, then the launches back to back: the kernels of one stream run in order,
+    // so they share the spill buffer, and nothing waits for the host between them
+    std::vector<uint32_t>& linked = ctx->evalh_linked;
+    linked.resize(std::max<size_t>(1, at_words[count]));
+    std::vector<uint64_t> scal, consts;
+    scal.reserve(at_scal[count]);
+    consts.reserve(at_consts[count]);
+    std::vector<uint32_t> res_links((size_t)count * 3);
+    for (uint32_t i = 0; i < count; i++) {
+        const EvalhProgram& p = *progs[i];
+        one.custom_gates = &graphs[i];
+        if ((rc = call_scalars(ctx, &one, p, no_extra, scal))) return rc;
+        ZK_CHECK(ctx, scal.size() == at_scal[i + 1], "evaluate_graphs: internal error, scalar table size");
+        consts.insert(consts.end(), p.consts.begin(), p.consts.end());
+        if ((rc = link_program(ctx, p, cols, 1, (const fe*)(d_scal + at_scal[i]), (const fe*)(d_consts + at_consts[i]),
+                               &linked[at_words[i]], &res_links[(size_t)i * 3])))
+            return rc;
+    }
+    ZK_HIP(ctx, hipMemcpyAsync(d_scal, scal.data(), scal.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+    if (!consts.empty()) ZK_HIP(ctx, hipMemcpyAsync(d_consts, consts.data(), consts.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+    if (at_words[count])
+        ZK_HIP(ctx, hipMemcpyAsync(d_words, linked.data(), at_words[count] * 4, hipMemcpyHostToDevice, ctx->stream));
+    for (uint32_t i = 0; i < count; i++)
+        if ((rc = launch_program(ctx, *progs[i], d_words + at_words[i], &res_links[(size_t)i * 3], (int32_t*)ctx->evalh_buf[3], k, 0,
+                                 n, (fe*)d_outs[i])))
+            break;
+    // the staged tables belong to the context and are rewritten by the next call
+    ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return rc;
 }
 
 extern "C" int zkhip_evaluate_h_cache_stats(zkhip_ctx* ctx, uint64_t out[2]) {

@@ -70,9 +70,11 @@ class EvalhCall:
         if self.basis == ffi.BASIS_EXTENDED:
             d.l0, d.l_last, d.l_active_row = ptr(self.l0), ptr(self.l_last), ptr(self.l_active)
         d.basis = self.basis
-        gates = b.graph(self.graph if self.graph is not None else ev.custom_gates, fr_to_mont_limbs)
-        b.keep.append(gates)
-        d.custom_gates = C.pointer(gates)
+        g = self.graph if self.graph is not None else ev.custom_gates
+        if g is not None:                      # None: a descriptor for `Domain.evaluate_graphs_dev`, which brings its graphs
+            gates = b.graph(g, fr_to_mont_limbs)
+            b.keep.append(gates)
+            d.custom_gates = C.pointer(gates)
         lk_arr = (ffi.Lookup * max(len(self.lookups), 1))()
         for i, (g, (prod, pin, ptab)) in enumerate(zip(ev.lookups, self.lookups)):
             lk_arr[i].graph = b.graph(g, fr_to_mont_limbs)
@@ -263,6 +265,33 @@ def lookup_compress_call(cs: ConstraintSystem, expressions, fixed, advice, insta
     call.y = call.beta = call.gamma = np.zeros(4, dtype=np.uint64)
     call.theta = theta
     return call
+
+
+def compress_lookups_dev(dom, cs: ConstraintSystem, lookups, fixed, advice, instance, challenges, theta, d_inputs, d_tables):
+    """`compress_expressions` of `Argument::commit_permuted` for every lookup of `lookups` in one library call: the
+    theta-compressed input expressions of lookup i go to d_inputs[i], its table expressions to d_tables[i] (device vectors
+    of 2^k elements) -- what `lookup_compress_call` + `Domain.evaluate_h` do pair by pair, without a wait per graph.  The
+    graphs are built once per lookup and kept on it."""
+    if not lookups:
+        return
+    b = ffi.DescBuilder()
+    graphs = (ffi.Graph * (2 * len(lookups)))()
+    outs = []
+    for i, lk in enumerate(lookups):
+        pair = lk.__dict__.get("_compress_graphs")
+        if pair is None:
+            pair = lk.__dict__["_compress_graphs"] = (compress_graph(lk.input_expressions), compress_graph(lk.table_expressions))
+        graphs[2 * i], graphs[2 * i + 1] = b.graph(pair[0], fr_to_mont_limbs), b.graph(pair[1], fr_to_mont_limbs)
+        outs += [d_inputs[i], d_tables[i]]
+    call = EvalhCall(cs, ev=_NoGraphs())
+    call.basis = ffi.BASIS_LAGRANGE
+    call.fixed, call.advice, call.instance = fixed, advice, instance
+    call.challenges = challenges
+    call.y = call.beta = call.gamma = np.zeros(4, dtype=np.uint64)
+    call.theta = theta
+    desc = call.build(ffi.MEM_DEVICE, ffi.FORM_EXTENDED)
+    dom.evaluate_graphs_dev(desc, graphs, outs)
+    del b
 
 
 class _NoGraphs:

@@ -30,7 +30,7 @@ EXPORTS = [
     "zkhip_lagrange_to_coeff_dev", "zkhip_coeff_to_lagrange_dev", "zkhip_coeff_to_extended_dev",
     "zkhip_extended_to_coeff_dev", "zkhip_divide_by_vanishing_poly_dev",
     "zkhip_coeff_to_extended_split_dev", "zkhip_extend_half_dev", "zkhip_coeff_to_extended_half_dev",
-    "zkhip_evaluate_h_columns_used",
+    "zkhip_evaluate_h_columns_used", "zkhip_evaluate_graphs_dev",
     "zkhip_evaluate_h", "zkhip_evaluate_h_last_stats", "zkhip_evaluate_h_cache_stats", "zkhip_evaluate_h_prepare",
     "zkhip_coeff_to_cosets_dev", "zkhip_extended_to_cosets_dev", "zkhip_cosets_to_extended_dev",
     "zkhip_batch_invert_dev", "zkhip_prefix_product_dev", "zkhip_prefix_product_noalloc_dev", "zkhip_permutation_product_dev", "zkhip_lookup_product_dev",
@@ -649,6 +649,12 @@ class Domain:
     def evaluate_h_prepare(self, desc: EvalhDesc):
         """`Evaluator::new(cs)`: builds the program of the descriptor's shape and keeps it in the context"""
         self.ctx._ck(self._l.zkhip_evaluate_h_prepare(self.h, C.byref(desc)))
+
+    def evaluate_graphs_dev(self, desc: EvalhDesc, graphs, d_outs):
+        """graphs: a ctypes array of Graph over the descriptor's Lagrange-basis device columns; d_outs: one device vector of
+        2^k elements per graph.  One call, one wait at its end."""
+        outs = (C.c_void_p * max(len(d_outs), 1))(*[C.c_void_p(int(p)) for p in d_outs])
+        self.ctx._ck(self._l.zkhip_evaluate_graphs_dev(self.h, C.byref(desc), graphs, C.c_uint32(len(d_outs)), outs))
 
     def evaluate_h_columns_used(self, desc: EvalhDesc):
         """one flag per column of the program's column table (see zkhip_evaluate_h_columns_used for the order)"""

@@ -816,12 +816,11 @@ def create_proof(ctx, dom, params: ParamsKZG, pk: ProvingKey, advice, instance, 
             if o != rank:
                 lookups.append([0, 0, d_pa, d_ps, 0])
                 continue
-            d_in, d_tb = alloc(n), alloc(n)
-            for exprs, d_out in ((lk.input_expressions, d_in), (lk.table_expressions, d_tb)):
-                call = evalh_host.lookup_compress_call(cs, exprs, pk.fixed_values, adv, inst, ch_limbs, limb(theta))
-                dom.evaluate_h(call.build(ffi.MEM_DEVICE, ffi.FORM_EXTENDED), d_out)
-            lookups.append([d_in, d_tb, d_pa, d_ps, 0])
+            lookups.append([alloc(n), alloc(n), d_pa, d_ps, 0])
         mine = [lk for lk, o in zip(lookups, lk_owner) if o == rank]
+        # the compressed input and table expressions of all (own) lookups: one call, the kernels back to back
+        evalh_host.compress_lookups_dev(dom, cs, [lk for lk, o in zip(cs.lookups, lk_owner) if o == rank], pk.fixed_values, adv,
+                                        inst, ch_limbs, limb(theta), [lk[0] for lk in mine], [lk[1] for lk in mine])
         # the permuted columns of all lookups in one sequence of launches; blinding rows and blinds in upstream's order
         if mine:
             dom.lookup_permute_batch_dev([lk[0] for lk in mine], [lk[1] for lk in mine], usable,
