@@ -64,6 +64,17 @@ def _worker(rank, world, port, n, ncols, q):
                 h_back[j::1 << (ek - k)] = rows.numpy()[s_::len(cosets)]
         assert np.array_equal(h_back, h_full)
         assert sorted(j for cosets, _ in whole for j in cosets) == list(range(1 << (ek - k)))
+    # (4) a block of polynomials of which every rank has filled its contiguous share (uneven shares, one rank with
+    # nothing when there are more ranks than columns): one padded all-gather, afterwards every rank holds the whole block
+    for cols_ in (ncols, world + 1, world - 1):
+        rows_per = 6
+        whole_block = torch.from_numpy(np.random.default_rng(5).integers(0, 2 ** 63, size=(cols_ * rows_per, 4), dtype=np.int64))
+        runs = [(f * rows_per, c * rows_per) for f, c in sharding.column_blocks(cols_, world)]
+        blk = torch.zeros_like(whole_block)
+        f, c = runs[rank]
+        blk[f:f + c] = whole_block[f:f + c]
+        sharding.exchange_runs(blk, runs, dist)
+        assert torch.equal(blk, whole_block), (cols_, rank)
     q.put((rank, co.g1_to_affine(full), np.stack([co.g1_to_affine(j) for j in allc])))
     dist.barrier()
     dist.destroy_process_group()

@@ -658,9 +658,15 @@ def create_proof(ctx, dom, params: ParamsKZG, pk: ProvingKey, advice, instance, 
         slot = [block + i * n * 32 for i in range(total)]
 
         def exchange(slots_by_owner):
-            """slots_by_owner[r]: the slots of the block that rank r has filled; afterwards every rank holds them all
-            (maximal runs of neighbouring slots travel as one broadcast each)"""
+            """slots_by_owner[r]: the slots of the block that rank r has filled; afterwards every rank holds them all:
+            one all-gather when every rank's slots are one run of neighbours (the contiguous blocks of `block_owner` are),
+            otherwise maximal runs of neighbouring slots travel as one broadcast each"""
             ctx.sync()
+            sorted_slots = [sorted(o) for o in slots_by_owner]
+            if all(not o or o[-1] - o[0] + 1 == len(o) for o in sorted_slots):
+                sharding.exchange_runs(t_block, [((o[0] if o else 0) * n, len(o) * n) for o in sorted_slots], dist)
+                torch.cuda.synchronize()
+                return
             for r, owned_slots in enumerate(slots_by_owner):
                 owned_slots = sorted(owned_slots)
                 i = 0

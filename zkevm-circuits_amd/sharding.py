@@ -86,6 +86,34 @@ def all_gather_rows(piece, dist):
     return [g.to(piece.device) for g in gathered]
 
 
+def exchange_runs(block, runs, dist):
+    """block: a (rows, 4) tensor that every rank holds; runs[r] = (first row, row count) of the part that rank r has filled
+    (count 0: nothing).  Afterwards every rank holds every part: ONE all-gather of the parts, padded to the longest (a ring
+    all-gather keeps every xGMI link of every GPU busy at once, where a broadcast per owner is bound by the links of one
+    source at a time), then the received parts are copied into place."""
+    import torch
+    rank, world = dist.get_rank(), dist.get_world_size()
+    longest = max(count for _, count in runs)
+    if longest == 0:
+        return
+    first, count = runs[rank]
+    if count == longest:
+        mine = block[first:first + count]
+    else:
+        mine = torch.zeros((longest,) + tuple(block.shape[1:]), dtype=block.dtype, device=block.device)
+        if count:
+            mine[:count].copy_(block[first:first + count])
+    if dist.get_backend() == "nccl":
+        out = torch.empty((world * longest,) + tuple(block.shape[1:]), dtype=block.dtype, device=block.device)
+        dist.all_gather_into_tensor(out, mine.contiguous())
+        parts = [out[r * longest:(r + 1) * longest] for r in range(world)]
+    else:
+        parts = all_gather_rows(mine, dist)
+    for r, (f, c) in enumerate(runs):
+        if r != rank and c:
+            block[f:f + c].copy_(parts[r][:c])
+
+
 def gather_commitments(local: dict, num_columns: int, dist=None):
     """local: {column index: 12-limb Jacobian} of the columns this rank committed, under any partition in which every
     column has exactly one owner.  Returns the (num_columns, 12) array in column order on every rank (transcript order
