@@ -311,6 +311,13 @@ int zkhip_permutation_product_dev(zkhip_domain* dom, const uint64_t* const* d_va
 int zkhip_lookup_product_dev(zkhip_domain* dom, const uint64_t* d_compressed_input, const uint64_t* d_compressed_table,
                              const uint64_t* d_permuted_input, const uint64_t* d_permuted_table, const uint64_t beta[4],
                              const uint64_t gamma[4], uint64_t* d_z);
+/* zkhip_lookup_product_dev for `count` lookups (the loop over `lookups` in `plonk::prover::create_proof`, between the beta /
+ * gamma challenges and the commitments of the products): the same values, with the denominators of up to 32 lookups inverted
+ * by one launch.  The z vectors must be distinct. */
+int zkhip_lookup_product_batch_dev(zkhip_domain* dom, const uint64_t* const* d_compressed_inputs,
+                                   const uint64_t* const* d_compressed_tables, const uint64_t* const* d_permuted_inputs,
+                                   const uint64_t* const* d_permuted_tables, const uint64_t beta[4], const uint64_t gamma[4],
+                                   uint64_t* const* d_zs, uint32_t count);
 int zkhip_eval_polynomial_dev(zkhip_ctx* ctx, const uint64_t* d_coeff, size_t n, const uint64_t x[4], uint64_t out[4]);
 /* `count` calls of `arithmetic::eval_polynomial` in one launch and one synchronisation: out[i] = d_coeffs[i](points[i]),
  * every polynomial with n coefficients (the evaluations `create_proof` writes to the transcript before the multi-open:

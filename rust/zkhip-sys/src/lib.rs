@@ -173,6 +173,9 @@ extern "C" {
         beta: *const u64, gamma: *const u64, delta_start: *const u64, z0: *const u64, d_z: *mut u64) -> c_int;
     pub fn zkhip_lookup_product_dev(dom: *mut zkhip_domain, d_compressed_input: *const u64, d_compressed_table: *const u64,
         d_permuted_input: *const u64, d_permuted_table: *const u64, beta: *const u64, gamma: *const u64, d_z: *mut u64) -> c_int;
+    pub fn zkhip_lookup_product_batch_dev(dom: *mut zkhip_domain, d_compressed_inputs: *const *const u64, d_compressed_tables: *const *const u64,
+        d_permuted_inputs: *const *const u64, d_permuted_tables: *const *const u64, beta: *const u64, gamma: *const u64,
+        d_zs: *const *mut u64, count: u32) -> c_int;
     pub fn zkhip_eval_polynomial_dev(ctx: *mut zkhip_ctx, d_coeff: *const u64, n: usize, x: *const u64, out: *mut u64) -> c_int;
     pub fn zkhip_eval_polynomials_dev(ctx: *mut zkhip_ctx, d_coeffs: *const *const u64, points: *const u64, count: u32, n: usize,
         out: *mut u64) -> c_int;

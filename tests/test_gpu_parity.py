@@ -798,7 +798,28 @@ def test_permutation_and_lookup_products(ctx, k, cols):
     d.lookup_product_dev(ptrs[0], ptrs[1], ptrs[2], ptrs[3], beta, gamma, d_z)
     exp = hm.lookup_product(fr_ints(a), fr_ints(s), fr_ints(ap), fr_ints(sp), fr_ints(beta[None])[0], fr_ints(gamma[None])[0])
     assert fr_ints(ctx.download(d_z, (n, 4))) == exp
-    for p in d_vals + d_sigs + ptrs + [d_z]:
+    # several lookups in one call (more than one group of 32 at the small size; a zero denominator stays zero as in the
+    # single call): the same vectors as lookup after lookup
+    count = 35 if k <= 9 else 3
+    sets = []
+    for i in range(count):
+        a, s, ap, sp = (rand_fr(rng, n) for _ in range(4))
+        if i == 1:
+            ap[5] = fr_arr([(-fr_ints(beta[None])[0]) % P])[0]           # a' + beta = 0 on one row
+        sets.append([ctx.upload(x) for x in (a, s, ap, sp)])
+    singles = []
+    for q in sets:
+        d.lookup_product_dev(q[0], q[1], q[2], q[3], beta, gamma, d_z)
+        singles.append(ctx.download(d_z, (n, 4)))
+    d_zs = [ctx.alloc(n * 32) for _ in range(count)]
+    d.lookup_product_batch_dev([q[0] for q in sets], [q[1] for q in sets], [q[2] for q in sets], [q[3] for q in sets],
+                               beta, gamma, d_zs)
+    for i in range(count):
+        assert np.array_equal(ctx.download(d_zs[i], (n, 4)), singles[i]), i
+    d.lookup_product_batch_dev([], [], [], [], beta, gamma, [])
+    with pytest.raises(zk.ZkhipError):
+        d.lookup_product_batch_dev([sets[0][0]], [sets[0][1]], [sets[0][2]], [0], beta, gamma, d_zs[:1])
+    for p in d_vals + d_sigs + ptrs + [d_z] + d_zs + [x for q in sets for x in q]:
         ctx.free(p)
     d.close()
 

@@ -70,6 +70,35 @@ __global__ void __launch_bounds__(PO_THREADS) batch_invert_kernel(fe* a, fe* pre
     }
 }
 
+// The same over `total` elements that live in several vectors of 2^log_n elements each (element i is element
+// i mod 2^log_n of vecs[i >> log_n]): the inversions of many grand products share one launch, whose lanes then hold enough
+// elements each (64 at 32 vectors of 2^19) that the 380-multiplication chain is a small part of a lane's work and every
+// SIMD has four waves to interleave -- a lone vector of 2^19 elements gives a lane 8 elements and a SIMD one wave.
+template <class F, class FP>
+__global__ void __launch_bounds__(PO_THREADS) batch_invert_multi_kernel(fe* const* vecs, uint32_t log_n, size_t total, fe* prefix,
+                                                                        size_t lanes) {
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= lanes || t >= total) return;
+    const size_t mask = ((size_t)1 << log_n) - 1;
+    fe run = F::one();
+    for (size_t i = t; i < total; i += lanes) {
+        store_fe(prefix + i, run);
+        const fe v = load_fe(vecs[i >> log_n] + (i & mask));
+        if (!F::is_zero(v)) run = F::mul(run, v);
+    }
+    fe inv = field_invert<F, FP>(run);
+    size_t last = t + ((total - 1 - t) / lanes) * lanes;
+    for (size_t i = last;; i -= lanes) {
+        fe* at = vecs[i >> log_n] + (i & mask);
+        const fe v = load_fe(at);
+        if (!F::is_zero(v)) {
+            store_fe(at, F::mul(load_fe(prefix + i), inv));
+            inv = F::mul(inv, v);
+        }
+        if (i < lanes) break;
+    }
+}
+
 // ---- prefix product ----------------------------------------------------------------------------------
 constexpr int PP_PER = 8;                       // elements per lane
 constexpr int PP_BLOCK = PO_THREADS * PP_PER;   // elements per block
@@ -591,6 +620,59 @@ int zkhip_lookup_product_dev(zkhip_domain* dom, const uint64_t* d_compressed_inp
     fe one;
     memcpy(one.l, HFR.r, 32);
     return prefix_product_dev(ctx, z, z, d_totals, n, one);
+}
+
+int zkhip_lookup_product_batch_dev(zkhip_domain* dom, const uint64_t* const* d_compressed_inputs,
+                                   const uint64_t* const* d_compressed_tables, const uint64_t* const* d_permuted_inputs,
+                                   const uint64_t* const* d_permuted_tables, const uint64_t beta[4], const uint64_t gamma[4],
+                                   uint64_t* const* d_zs, uint32_t count) {
+    if (!dom) return ZKHIP_ERR_INVALID;
+    zkhip_ctx* ctx = dom->ctx;
+    if (count == 0) return ZKHIP_OK;
+    ZK_CHECK(ctx, d_compressed_inputs && d_compressed_tables && d_permuted_inputs && d_permuted_tables && beta && gamma && d_zs,
+             "lookup_product_batch: null pointer");
+    for (uint32_t i = 0; i < count; i++)
+        ZK_CHECK(ctx, d_compressed_inputs[i] && d_compressed_tables[i] && d_permuted_inputs[i] && d_permuted_tables[i] && d_zs[i],
+                 "lookup_product_batch: null vector of lookup %u", i);
+    ZK_HIP(ctx, hipSetDevice(ctx->device));
+    constexpr uint32_t GROUP = 32;          // lookups whose denominators are inverted by one launch
+    const size_t n = (size_t)1 << dom->k;
+    const size_t nblocks = (n + PP_BLOCK - 1) / PP_BLOCK;
+    const uint32_t group = std::min(count, GROUP);
+    // scratch: [inversion prefixes group * n][block totals nblocks + 1][pointers to the z vectors]
+    int rc = ensure_scratch(ctx, ((size_t)group * n + nblocks + 1) * 32 + (size_t)count * sizeof(void*));
+    if (rc) return rc;
+    fe* d_tmp = (fe*)ctx->scratch;
+    fe* d_totals = d_tmp + (size_t)group * n;
+    fe** d_ptrs = (fe**)(d_totals + nblocks + 1);
+    ZK_HIP(ctx, hipMemcpyAsync(d_ptrs, d_zs, (size_t)count * sizeof(void*), hipMemcpyHostToDevice, ctx->stream));
+    ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));   // the table is the caller's pageable host memory, free to die on return
+    TimedRegion tr(ctx, "grand_product");
+    const dim3 grid((unsigned)((n + PO_THREADS - 1) / PO_THREADS));
+    const fe b = fe_from(beta), g = fe_from(gamma);
+    fe one;
+    memcpy(one.l, HFR.r, 32);
+    for (uint32_t g0 = 0; g0 < count; g0 += GROUP) {
+        const uint32_t cnt = std::min(GROUP, count - g0);
+        for (uint32_t i = g0; i < g0 + cnt; i++)
+            hipLaunchKernelGGL(shifted_product_kernel, grid, dim3(PO_THREADS), 0, ctx->stream, (const fe*)d_permuted_inputs[i],
+                               (const fe*)d_permuted_tables[i], b, g, (fe*)d_zs[i], n);
+        ZK_HIP(ctx, hipGetLastError());
+        const size_t total = (size_t)cnt * n;
+        // four waves on every SIMD when the group is large enough to give each lane 16 elements, never fewer than one
+        const size_t lanes = std::max<size_t>((size_t)ctx->num_cus * 256, std::min<size_t>((size_t)ctx->num_cus * 1024, total / 16));
+        hipLaunchKernelGGL((batch_invert_multi_kernel<Fr, FrParams>), dim3((unsigned)((lanes + PO_THREADS - 1) / PO_THREADS)),
+                           dim3(PO_THREADS), 0, ctx->stream, d_ptrs + g0, dom->k, total, d_tmp, lanes);
+        ZK_HIP(ctx, hipGetLastError());
+        for (uint32_t i = g0; i < g0 + cnt; i++) {
+            fe* z = (fe*)d_zs[i];
+            hipLaunchKernelGGL(shifted_product_mul_kernel, grid, dim3(PO_THREADS), 0, ctx->stream, (const fe*)d_compressed_inputs[i],
+                               (const fe*)d_compressed_tables[i], b, g, z, n);
+            ZK_HIP(ctx, hipGetLastError());
+            if ((rc = prefix_product_dev(ctx, z, z, d_totals, n, one))) return rc;
+        }
+    }
+    return ZKHIP_OK;
 }
 
 int zkhip_eval_polynomial_dev(zkhip_ctx* ctx, const uint64_t* d_coeff, size_t n, const uint64_t x[4], uint64_t out[4]) {

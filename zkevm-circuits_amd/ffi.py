@@ -33,7 +33,7 @@ EXPORTS = [
     "zkhip_evaluate_h_columns_used", "zkhip_evaluate_graphs_dev",
     "zkhip_evaluate_h", "zkhip_evaluate_h_last_stats", "zkhip_evaluate_h_cache_stats", "zkhip_evaluate_h_prepare",
     "zkhip_coeff_to_cosets_dev", "zkhip_extended_to_cosets_dev", "zkhip_cosets_to_extended_dev",
-    "zkhip_batch_invert_dev", "zkhip_prefix_product_dev", "zkhip_prefix_product_noalloc_dev", "zkhip_permutation_product_dev", "zkhip_lookup_product_dev",
+    "zkhip_batch_invert_dev", "zkhip_prefix_product_dev", "zkhip_prefix_product_noalloc_dev", "zkhip_permutation_product_dev", "zkhip_lookup_product_dev", "zkhip_lookup_product_batch_dev",
     "zkhip_eval_polynomial_dev", "zkhip_eval_polynomials_dev", "zkhip_poly_lincomb_dev", "zkhip_kate_division_dev", "zkhip_lookup_permute_dev", "zkhip_lookup_permute_batch_dev", "zkhip_permutation_sigma_dev",
     "zkhip_timing_enable", "zkhip_timing_reset", "zkhip_timing_get",
 ]
@@ -645,6 +645,16 @@ class Domain:
         self.ctx._ck(self._l.zkhip_lookup_product_dev(self.h, C.c_void_p(d_input), C.c_void_p(d_table),
                                                       C.c_void_p(d_permuted_input), C.c_void_p(d_permuted_table), _p(beta),
                                                       _p(gamma), C.c_void_p(d_z)))
+
+    def lookup_product_batch_dev(self, d_inputs, d_tables, d_permuted_inputs, d_permuted_tables, beta, gamma, d_zs):
+        """`lookup_product_dev` for many lookups: the denominators of up to 32 of them are inverted by one launch"""
+        beta, gamma = u64(beta), u64(gamma)
+        count = len(d_zs)
+        assert len(d_inputs) == len(d_tables) == len(d_permuted_inputs) == len(d_permuted_tables) == count
+        arr = lambda ps: (C.c_void_p * max(count, 1))(*[C.c_void_p(int(p)) for p in ps])       # noqa: E731
+        self.ctx._ck(self._l.zkhip_lookup_product_batch_dev(self.h, arr(d_inputs), arr(d_tables), arr(d_permuted_inputs),
+                                                            arr(d_permuted_tables), _p(beta), _p(gamma), arr(d_zs),
+                                                            C.c_uint32(count)))
 
     def evaluate_h_prepare(self, desc: EvalhDesc):
         """`Evaluator::new(cs)`: builds the program of the descriptor's shape and keeps it in the context"""

@@ -864,9 +864,11 @@ def create_proof(ctx, dom, params: ParamsKZG, pk: ProvingKey, advice, instance, 
 
         # ---- lookup grand products --------------------------------------------------------------------------
         mark("lookup_product")
+        own = [(lk, d_z) for lk, (d_z, _, _), o in zip(lookups, lk_slots, lk_owner) if o == rank]
+        if own:
+            dom.lookup_product_batch_dev([lk[0] for lk, _ in own], [lk[1] for lk, _ in own], [lk[2] for lk, _ in own],
+                                         [lk[3] for lk, _ in own], limb(beta), limb(gamma), [d_z for _, d_z in own])
         for lk, (d_z, _, _), o in zip(lookups, lk_slots, lk_owner):
-            if o == rank:
-                dom.lookup_product_dev(lk[0], lk[1], lk[2], lk[3], limb(beta), limb(gamma), d_z)
             blind_rows(d_z, usable + 1, o == rank)
             rng.fr()
             lk[4] = d_z
