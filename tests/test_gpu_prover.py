@@ -238,6 +238,14 @@ def test_wide_circuit_proof_verifies(ctx, co, k, units, degree9):
         a[:] = prover.fr_limbs(col)
         pinned.append(a)
     assert prover.create_proof(ctx, dom, params, pk, pinned, instance, prover.FieldRng(k), prover.Blake2bWrite()) == proof
+    # the witness already in device memory (uploaded by the caller while it was produced): the same bytes again
+    resident = [prover.DeviceColumn(ctx.upload(a), len(a)) for a in pinned]
+    assert prover.create_proof(ctx, dom, params, pk, resident, instance, prover.FieldRng(k), prover.Blake2bWrite()) == proof
+    with pytest.raises(ValueError):
+        prover.create_proof(ctx, dom, params, pk, [prover.DeviceColumn(resident[0].ptr, 5)] + resident[1:], instance,
+                            prover.FieldRng(k), prover.Blake2bWrite())
+    for col in resident:
+        ctx.free(col.ptr)
     for a in pinned:
         ctx.host_free(a)
     # one wrong cell in the last unit: d != a(-1) + b on one row

@@ -541,6 +541,19 @@ def load_proving_key(ctx, dom, cs: ConstraintSystem, path: str, num_selectors: i
     return pk
 
 
+class DeviceColumn:
+    """An advice column that already lives in device memory: `rows` Montgomery-limb elements at `ptr` (the usable rows; a
+    witness generator that uploads columns while it produces them, or a prover that serves proofs back to back and sends
+    the next witness over the host link while this proof runs, hands `create_proof` these instead of host arrays).  The
+    memory stays the caller's: the prover copies it into its polynomial block."""
+
+    def __init__(self, ptr: int, rows: int):
+        self.ptr, self.rows = int(ptr), int(rows)
+
+    def __len__(self):
+        return self.rows
+
+
 class ProofWorkspace:
     """The large device blocks of `create_proof` -- the polynomial block, the block of extended cosets (123 GB at the
     SuperCircuit's width), h -- kept between proofs of one proving key.  A prover that serves proof after proof passes the
@@ -569,8 +582,8 @@ class ProofWorkspace:
 def create_proof(ctx, dom, params: ParamsKZG, pk: ProvingKey, advice, instance, rng: FieldRng, transcript: Blake2bWrite,
                  timings: dict | None = None, dist=None, coset_groups: int | None = None,
                  random_poly_threads: int | None = None, workspace: ProofWorkspace | None = None):
-    """One circuit.  advice: per column the values of the usable rows (a list of canonical integers, or a
-    (usable rows, 4) uint64 array of Montgomery limbs; the remaining rows are blinding), or a callable
+    """One circuit.  advice: per column the values of the usable rows (a list of canonical integers, a
+    (usable rows, 4) uint64 array of Montgomery limbs, or a `DeviceColumn`; the remaining rows are blinding), or a callable
     (phase, challenges so far) -> such a list, called once per phase of `cs.phases()` as upstream re-runs witness
     synthesis per phase (only the phase's own columns are read from it); instance: per column at most that many
     canonical integers.  Writes the proof into `transcript` and returns its bytes.  timings: filled with the wall
@@ -745,6 +758,8 @@ def create_proof(ctx, dom, params: ParamsKZG, pk: ProvingKey, advice, instance, 
             assigned = advice(phase, list(challenges)) if callable(advice) else advice
             for c in columns:
                 col = assigned[c]
+                if isinstance(col, DeviceColumn) and (col.rows != usable or not col.ptr):
+                    raise ValueError("a device-resident advice column holds the usable rows")
                 if len(col) != usable or (isinstance(col, np.ndarray) and (col.dtype != np.uint64 or col.shape != (usable, 4))):
                     raise ValueError("an advice column holds the usable rows (integers, or (usable rows, 4) uint64 limbs)")
             points = []
@@ -757,13 +772,27 @@ def create_proof(ctx, dom, params: ParamsKZG, pk: ProvingKey, advice, instance, 
                     blinding = draws(n - usable)
                     if r != rank:
                         continue
-                    if isinstance(col, np.ndarray):
+                    if isinstance(col, DeviceColumn):
+                        ctx.copy_dev(d, col.ptr, usable * 32)
+                        ctx.upload(fr_limbs(blinding), d + usable * 32)
+                    elif isinstance(col, np.ndarray):
                         ctx.upload(col, d)
                         ctx.upload(fr_limbs(blinding), d + usable * 32)
                     else:
                         ctx.upload(np.concatenate([fr_limbs(col), fr_limbs(blinding)]), d)
                 points.extend(params.commit_lagrange([adv[c] for c in columns], dist, owner))
                 exchange([[c for c, o in zip(columns, owner) if o == r] for r in range(world)])
+            elif columns and all(isinstance(assigned[c], DeviceColumn) for c in columns):
+                # device-resident columns: copied into the block group by group, each group committed and extended while
+                # the next is copied
+                GROUP = 32
+                for g0 in range(0, len(columns), GROUP):
+                    group = columns[g0:g0 + GROUP]
+                    for c in group:
+                        ctx.copy_dev(adv[c], assigned[c].ptr, usable * 32)
+                        blind_rows(adv[c], usable)
+                    points.extend(params.commit_lagrange([adv[c] for c in group], dist))
+                    extend_early(group)
             elif columns and all(isinstance(assigned[c], np.ndarray) and assigned[c].flags.c_contiguous
                                  and ctx.is_pinned(assigned[c]) for c in columns):
                 # page-locked columns: the copies of one group of columns run on the transfer stream while the group
@@ -796,7 +825,10 @@ def create_proof(ctx, dom, params: ParamsKZG, pk: ProvingKey, advice, instance, 
                 for c in columns:                               # the unusable rows of every column are blinding
                     col, d = assigned[c], adv[c]
                     blinding = fr_limbs(draws(n - usable))
-                    if isinstance(col, np.ndarray):
+                    if isinstance(col, DeviceColumn):
+                        ctx.copy_dev(d, col.ptr, usable * 32)
+                        ctx.upload(blinding, d + usable * 32)
+                    elif isinstance(col, np.ndarray):
                         ctx.upload(col, d)
                         ctx.upload(blinding, d + usable * 32)
                     else:
