@@ -614,6 +614,7 @@ def create_proof(ctx, dom, params: ParamsKZG, pk: ProvingKey, advice, instance, 
         raise ValueError("an advice column holds the usable rows (integers, or (usable rows, 4) uint64 limbs)")
     omega = fr_from_mont_limbs(dom.constant(0))
     owned = []
+    pinned_stages = []            # page-locked staging buffers, released when the proof is done
 
     def alloc(rows, keep_as=None):
         """keep_as: the name under which a caller's workspace keeps this block for the next proof"""
@@ -797,30 +798,34 @@ def create_proof(ctx, dom, params: ParamsKZG, pk: ProvingKey, advice, instance, 
                                  and ctx.is_pinned(assigned[c]) for c in columns):
                 # page-locked columns: the copies of one group of columns run on the transfer stream while the group
                 # before it is committed, so that the link and the multiplier work side by side
-                GROUP = 32
+                # (a short first group: the multiplier has nothing to do until it has arrived).  The extension of a group
+                # is queued two commitments later, and what is still owed after the last commitment runs while the host
+                # writes the points to the transcript and prepares the lookups; the staging buffer is released at the end
+                # of the proof for the same reason (releasing page-locked memory waits for the device).
+                GROUP, FIRST, LAG = 32, 8, 2
                 stage = ctx.host_zeros((len(columns), n - usable, 4))      # the blinding rows of every column
-                try:
-                    groups = [columns[g0:g0 + GROUP] for g0 in range(0, len(columns), GROUP)]
+                pinned_stages.append(stage)
+                starts = [0] + list(range(min(FIRST, len(columns)), len(columns), GROUP))
+                groups = [columns[a:b] for a, b in zip(starts, starts[1:] + [len(columns)])]
 
-                    def issue(gi):
-                        for i, c in enumerate(groups[gi], gi * GROUP):
-                            stage[i] = fr_limbs(draws(n - usable))
-                            ctx.upload_overlapped(assigned[c], adv[c])
-                            ctx.upload_overlapped(stage[i], adv[c] + usable * 32)
+                def issue(gi):
+                    for i, c in enumerate(groups[gi], starts[gi]):
+                        stage[i] = fr_limbs(draws(n - usable))
+                        ctx.upload_overlapped(assigned[c], adv[c])
+                        ctx.upload_overlapped(stage[i], adv[c] + usable * 32)
 
-                    issue(0)
-                    for gi, group in enumerate(groups):
-                        ctx.upload_fence()                      # the compute stream waits for this group's copies
-                        if gi + 1 < len(groups):
-                            # queued before any kernel of this round: the first copy after a fence starts behind what the
-                            # compute stream holds at that moment, which is nothing but the wait above
-                            issue(gi + 1)
-                        if gi:
-                            extend_early(groups[gi - 1])
-                        points.extend(params.commit_lagrange([adv[c] for c in group], dist))
-                    extend_early(groups[-1])
-                finally:
-                    ctx.host_free(stage)
+                issue(0)
+                for gi, group in enumerate(groups):
+                    ctx.upload_fence()                      # the compute stream waits for this group's copies
+                    if gi + 1 < len(groups):
+                        # queued before any kernel of this round: the first copy after a fence starts behind what the
+                        # compute stream holds at that moment, which is nothing but the wait above
+                        issue(gi + 1)
+                    if gi >= LAG:
+                        extend_early(groups[gi - LAG])
+                    points.extend(params.commit_lagrange([adv[c] for c in group], dist))
+                for group in groups[max(0, len(groups) - LAG):]:
+                    extend_early(group)
             else:
                 for c in columns:                               # the unusable rows of every column are blinding
                     col, d = assigned[c], adv[c]
@@ -1111,4 +1116,6 @@ def create_proof(ctx, dom, params: ParamsKZG, pk: ProvingKey, advice, instance, 
     finally:
         for p in owned:
             ctx.free(p)
+        for a in pinned_stages:
+            ctx.host_free(a)
     return transcript.finalize()
