@@ -592,7 +592,7 @@ def create_proof(ctx, dom, params: ParamsKZG, pk: ProvingKey, advice, instance, 
     by column (contiguous blocks of columns per rank): the upload of the witness, every commitment, and -- by lookup -- the
     compression, the permuted columns, the grand product and the coefficient forms of a lookup's three polynomials;
     sharded by coset: the quotient numerator (zkevm_circuits_amd/sharding.py).  Exchanged: the uploaded advice columns and
-    the lookups' polynomials (one broadcast per owner and phase, 2^k-sized vectors), the commitments (96 bytes each), the
+    the lookups' polynomials (one all-gather per phase, 2^k-sized vectors), the commitments (96 bytes each), the
     pieces of h.  Replicated: the transcript and the RNG (every rank draws every value, so the streams stay in step), the
     permutation argument, the evaluations and the multi-open.  Every rank returns the same bytes as a single-rank call.
     A lookup input outside its table raises on the lookup's owner; the other ranks then fail in the next collective.
