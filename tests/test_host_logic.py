@@ -450,3 +450,45 @@ def test_pinned_verifying_key_text_and_query_lists():
     cs2.__dict__.pop("_memo_cache", None)
     with pytest.raises(ValueError):
         prover.collect_queries(cs2)
+
+
+def test_split_extension_runs_and_column_flags_without_a_device():
+    """`evalh_host.extend_for_split` sends maximal runs of equally flagged polynomials to the whole / the half-domain
+    extension with the right addresses, and `columns_used` cuts the library's flat flag list into the constraint
+    system's column groups (a recording stand-in takes the place of the device domain)"""
+    from zkevm_circuits_amd import evalh_host
+
+    class Dom:
+        n, extended_len = 8, 32
+        calls = []
+
+        def coeff_to_extended_split_dev(self, src, dst, batch):
+            self.calls.append(("whole", src, dst, batch))
+
+        def coeff_to_extended_half_dev(self, src, dst, stride, batch):
+            self.calls.append(("half", src, dst, stride, batch))
+
+    dom = Dom()
+    evalh_host.extend_for_split(dom, [True, True, False, True, False, False], 1000, 50000)
+    n32, en32 = 8 * 32, 32 * 32
+    assert dom.calls == [("whole", 1000, 50000, 2), ("half", 1000 + 2 * n32, 50000 + 2 * en32, 32, 1),
+                         ("whole", 1000 + 3 * n32, 50000 + 3 * en32, 1), ("half", 1000 + 4 * n32, 50000 + 4 * en32, 32, 2)]
+    dom.calls.clear()
+    evalh_host.extend_for_split(dom, [], 0, 0)
+    assert dom.calls == []
+
+    cs = synthetic.satisfied_cs(2, degree9=True, plain_lookups=True)
+    sets = cs.num_permutation_sets()
+    total = (cs.num_fixed_columns + cs.num_advice_columns + cs.num_instance_columns + 3 + 1 + sets
+             + len(cs.permutation_columns) + 3 * len(cs.lookups))
+
+    class FlagDom:
+        def evaluate_h_columns_used(self, desc):
+            assert desc.term_select == 2 and desc.term_degree_max == 4 and desc.num_lookups == len(cs.lookups)
+            return np.arange(total) % 2
+
+    used = evalh_host.columns_used(FlagDom(), cs, plonk.Evaluator(cs), (2, 4))
+    flat = (used["fixed"] + used["advice"] + used["instance"] + used["l"] + ["x"] + used["perm_z"] + used["perm_sigma"]
+            + [f for t in used["lookups"] for f in t])
+    assert len(flat) == total and len(used["lookups"]) == len(cs.lookups) and len(used["perm_z"]) == sets
+    assert [f for f in flat if f != "x"] == [bool(i % 2) for i in range(total) if flat[i] != "x"]
