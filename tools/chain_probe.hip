@@ -2,13 +2,13 @@
 // three neighbours.  The MSM's merge and reduce phases are such chains; whether two of them on one SIMD run side by side
 // or take turns decides how many lanes a bucket may be given.
 // Every lane adds the same affine point K times to an accumulator that starts from another point (no doubling, no
-// identity: the common path of xyzz_w_add), in the one-lane and the two-lane form of curve_wide.cuh.
+// identity: the common path of xyzz_w_add), in the one-lane and the two-lane form of curve_wide.hip.h.
 // Build: hipcc --offload-arch=gfx950 -O3 -I zkevm-circuits_amd/csrc -o tools/chain_probe tools/chain_probe.hip
 #include <hip/hip_runtime.h>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
-#include "curve_wide.cuh"
+#include "curve_wide.hip.h"
 
 using namespace zkhip;
 

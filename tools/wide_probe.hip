@@ -1,12 +1,12 @@
-// Development tool: checks the lazy signed-digit arithmetic (csrc/wide.cuh) against the packed Montgomery arithmetic
-// (csrc/field.cuh) on the host and on the GPU, and measures its multiplication rate.
+// Development tool: checks the lazy signed-digit arithmetic (csrc/wide.hip.h) against the packed Montgomery arithmetic
+// (csrc/field.hip.h) on the host and on the GPU, and measures its multiplication rate.
 // Build: hipcc --offload-arch=gfx950 -O3 -I zkevm-circuits_amd/csrc -o tools/wide_probe tools/wide_probe.hip
 #include <hip/hip_runtime.h>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
-#include "wide.cuh"
+#include "wide.hip.h"
 
 using namespace zkhip;
 

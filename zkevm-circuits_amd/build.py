@@ -22,7 +22,7 @@ def _newer(target, deps):
 def build(force: bool = False, verbose: bool = False) -> str:
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     srcs = [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
-    deps = srcs + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".h", ".cuh"))]
+    deps = srcs + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".h",))]
     deps.append(os.path.join(HERE, "..", "include", "zkhip.h"))
     objs = []
     os.makedirs(os.path.join(HERE, "build"), exist_ok=True)

@@ -3,7 +3,7 @@
 #include <memory>
 #include "common.h"
 #include "ntt.h"
-#include "wide.cuh"
+#include "wide.hip.h"
 
 using namespace zkhip;
 
@@ -105,7 +105,7 @@ __global__ void __launch_bounds__(256) probe_kernel(fe* io, int iters) {
 }
 
 // ---- self-test of the lazy arithmetic ----------------------------------------------------------------
-// The multiplier of wide.cuh leans on how the compiler lowers it (hidden digit signs, one chain of multiply-adds per
+// The multiplier of wide.hip.h leans on how the compiler lowers it (hidden digit signs, one chain of multiply-adds per
 // column): this checks every form of it against the packed Montgomery arithmetic on the device it will run on.
 // Returns a bit mask of the failed checks of (a, b, c, d).
 template <class FP, bool CHAIN>

@@ -9,7 +9,7 @@
 #include <string>
 #include <vector>
 #include "../../include/zkhip.h"
-#include "field.cuh"
+#include "field.hip.h"
 
 namespace zkhip {
 

@@ -5,7 +5,7 @@
 // exceptional cases (identity operands, P + P, P + (-P)) are handled: bases of the form [i]G make
 // "accumulator equals the incoming point" a normal event, not a corner case.
 #pragma once
-#include "field.cuh"
+#include "field.hip.h"
 
 namespace zkhip {
 

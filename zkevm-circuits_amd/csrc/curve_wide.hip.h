@@ -1,15 +1,15 @@
-// XYZZ bucket accumulation on the lazy signed-digit arithmetic of wide.cuh (the MSM accumulate kernel's inner loop).
+// XYZZ bucket accumulation on the lazy signed-digit arithmetic of wide.hip.h (the MSM accumulate kernel's inner loop).
 //
 // Coordinates live in the 2^261 Montgomery domain (the MSM tables are stored in it; see msm.hip).  A mixed addition
 // is 8 mul + 2 sqr (the two products of y3 share one reduction), digit-wise subtractions and one carry
 // normalisation; nothing is reduced modulo p.
-// Digit-magnitude bookkeeping (see wide.cuh): acc.x, acc.y, acc.zz, acc.zzz are normalised; every subtraction below
+// Digit-magnitude bookkeeping (see wide.hip.h): acc.x, acc.y, acc.zz, acc.zzz are normalised; every subtraction below
 // takes two normalised values, so its result is a valid mul / sqr operand; x3 (four terms) and y3 are normalised
 // before they are stored.  Value bookkeeping: with |x| < 3.3 p, |y| < 1.2 p at entry, P and Rr stay below 4.3 p and
 // 2.3 p, all products land in (-0.15 p, 1.15 p), and x3, y3 satisfy the entry bounds again.
 #pragma once
-#include "curve.cuh"
-#include "wide.cuh"
+#include "curve.hip.h"
+#include "wide.hip.h"
 
 namespace zkhip {
 

@@ -12,7 +12,7 @@
 //   * values get slots by liveness; the slots with the densest use stay on chip (slot 0 in registers, the next ones
 //     in LDS as [slot][digit][lane]), the rest spill to a [slot][digit][row] buffer in HBM.  The launch reserves only
 //     the LDS the program needs, so that four 256-lane workgroups share a CU;
-//   * arithmetic runs in the lazy signed-digit form of wide.cuh (nine 29-bit digits, Montgomery radix 2^261): a
+//   * arithmetic runs in the lazy signed-digit form of wide.hip.h (nine 29-bit digits, Montgomery radix 2^261): a
 //     multiply-add is one Montgomery product, nine digit additions and a carry pass, with no comparison against p;
 //     the host bounds every value's magnitude while it builds the program and the kernel canonicalises the result.
 // Every instruction is r = (a * b | a) (+ c | - c | nothing), r = c - a * b, or r = a * b +- c * d where both products
@@ -30,7 +30,7 @@
 #include <map>
 #include <memory>
 #include "domain.h"
-#include "wide.cuh"
+#include "wide.hip.h"
 
 using namespace zkhip;
 
@@ -101,7 +101,7 @@ __device__ __forceinline__ fe ev_raw(const Opnd& o, uint32_t idx, uint32_t mask)
     v.l[4] = b.x; v.l[5] = b.y; v.l[6] = b.z; v.l[7] = b.w;
     return v;
 }
-// Values are held in the lazy signed-digit form of wide.cuh, 2^261 Montgomery domain, always normalised.  Columns
+// Values are held in the lazy signed-digit form of wide.hip.h, 2^261 Montgomery domain, always normalised.  Columns
 // enter through from_fe_shl5 (value up to 32 p); the host tracks magnitudes and keeps every stored value below EV_LIMIT p.
 // Value slots: slot 0 is a register of the lane, slots 1 .. lds_slots-1 live in LDS, the rest in the spill buffer.
 __device__ __forceinline__ fw ev_value(const InterpArgs& a, const Opnd& o, const fe& raw, const int32_t* lds, const fw& acc,

@@ -5,15 +5,15 @@
 // power of omega; every stage is one launch over n / 2 butterflies, one lane per butterfly.  Runs once per parameter set.
 //
 // Points travel between the stages as XYZZ with coordinates in the 2^261 Montgomery domain of the lazy signed-digit
-// arithmetic (csrc/wide.cuh).  The scalar multiplication walks the non-adjacent form of the twiddle, most significant
+// arithmetic (csrc/wide.hip.h).  The scalar multiplication walks the non-adjacent form of the twiddle, most significant
 // digit first (digit i = bit i + 1 of 3 k minus bit i + 1 of k; a third of the digits are nonzero).  A stage has n / 2m
 // butterflies per twiddle: while that is at least 64, the 64 lanes of a wave take butterflies of ONE twiddle, so the digits
 // are wave-uniform and a zero digit skips the addition for the whole wave (in a wave of mixed twiddles some lane always
 // needs it); the last six stages have fewer butterflies per twiddle than lanes and pay the addition at every digit.
 #include <cstring>
 #include "common.h"
-#include "curve.cuh"
-#include "curve_wide.cuh"
+#include "curve.hip.h"
+#include "curve_wide.hip.h"
 #include "ntt.h"
 
 using namespace zkhip;

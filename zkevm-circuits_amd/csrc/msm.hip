@@ -2,7 +2,7 @@
 //
 // Registration (once per SRS): for window width c and W = ceil(255 / c) windows the library stores the
 // affine tables T_w[i] = 2^(c w) * G_i for every w (coordinates in the 2^261 Montgomery domain of the accumulate
-// kernel's lazy arithmetic, csrc/wide.cuh).  With 288 GB of HBM the W-fold copy is cheap (k = 19:
+// kernel's lazy arithmetic, csrc/wide.hip.h).  With 288 GB of HBM the W-fold copy is cheap (k = 19:
 // 512 MiB) and it collapses all windows into ONE set of 2^(c-1) signed-digit buckets: no per-window bucket
 // sets, no doubling ladder at the end, 16x less bucket-reduction work.
 //
@@ -29,8 +29,8 @@
 #include <map>
 #include <mutex>
 #include "common.h"
-#include "curve.cuh"
-#include "curve_wide.cuh"
+#include "curve.hip.h"
+#include "curve_wide.hip.h"
 
 using namespace zkhip;
 

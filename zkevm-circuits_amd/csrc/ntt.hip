@@ -12,7 +12,7 @@
 //
 // Transforms of 2^11 points and more use `ntt_tile_kernel` (below); the LDS-per-stage kernel above it serves the
 // small ones.  The tile kernel keeps the same pass / tile / index structure and changes the inside of a pass:
-//   * arithmetic in the lazy signed-digit form of wide.cuh: a butterfly is one Montgomery product and 18 digit
+//   * arithmetic in the lazy signed-digit form of wide.hip.h: a butterfly is one Montgomery product and 18 digit
 //     additions, elements are carry-normalised once per LDS round trip, and nothing is compared against p;
 //   * decimation in time on bit-reversed tile rows, two stages at a time in registers: a lane owns four elements
 //     of one column, so a radix-2^7 pass crosses LDS four times instead of seven;
@@ -24,7 +24,7 @@
 #include <cstring>
 #include "common.h"
 #include "ntt.h"
-#include "wide.cuh"
+#include "wide.hip.h"
 
 namespace zkhip {
 

@@ -18,7 +18,7 @@
 #include <vector>
 #include "common.h"
 #include "domain.h"
-#include "wide.cuh"
+#include "wide.hip.h"
 
 using namespace zkhip;
 

@@ -24,7 +24,7 @@
 // A value x kept as x 2^261 in wide form is obtained from the in-memory x 2^256 by one packed multiplication
 // with FP::TWO5, and returns to x 2^256 through mul(v, r256()).
 #pragma once
-#include "field.cuh"
+#include "field.hip.h"
 
 namespace zkhip {
 
