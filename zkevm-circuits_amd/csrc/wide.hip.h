@@ -183,7 +183,7 @@ struct Wide {
     // acc + x y as one link of a chain of multiply-adds (the sum is opaque afterwards, so the chain keeps its order)
     ZK_DEV static void chain(int64_t& acc, int32_t x, int32_t y) {
         acc += (int64_t)x * y;
-#if defined(__HIP_DEVICE_COMPILE__)
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(ZK_NO_CHAIN_VEIL)
         if (CHAIN) asm("" : "+v"(acc));
 #endif
     }
