@@ -32,11 +32,17 @@ struct fw {
     int32_t d[9];
 };
 
-// CHAIN: the multiplier adds every column's terms to its accumulator as ONE chain of dependent multiply-adds (see chain()).
-// That is the shortest instruction stream, and right for a kernel with several waves per SIMD to fill the wait state
-// between dependent 64-bit multiply-adds; a kernel that is a lone wave's dependency chain (the MSM's merge and reduce)
-// is faster with the optimiser's own two interleaved chains per column, joined by a 64-bit addition.
-template <class FP, bool CHAIN = false>
+// CHAIN: the multiplier adds every column's terms to its accumulator as ONE chain of dependent multiply-adds (see chain()):
+// the shortest instruction stream (the optimiser's own form is two interleaved chains per column joined by a 64-bit
+// addition).  The empty asm statements that pin the chain make the compiler put a wait state (s_nop 0) behind each of them
+// -- it must assume that an asm statement wrote its output with a partial-register write -- which halves a wave's issue
+// rate; the library's build removes those wait states from the assembly (zkevm-circuits_amd/build.py), and with them gone
+// the chain form is the faster one in every kernel, the lone-wave dependency chains of the MSM's merge and reduce included
+// (with the wait states in place those were 25 % slower in this form, which is why the parameter exists).
+#ifndef ZK_CHAIN_DEFAULT
+#define ZK_CHAIN_DEFAULT true
+#endif
+template <class FP, bool CHAIN = ZK_CHAIN_DEFAULT>
 struct Wide {
     // Hides from the optimiser what it has proved about a digit (a masked digit is non-negative).  A product of a
     // sign-extended digit and a digit known to be non-negative is otherwise lowered to an UNSIGNED 64-bit multiply-add
