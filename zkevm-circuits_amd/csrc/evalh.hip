@@ -148,7 +148,7 @@ __device__ __forceinline__ void ev_stage(Staged& s, prog_ptr w, uint32_t idx, ui
     if (kb == L_ROW || kb == L_UNI) s.rb = ev_raw(s.b, idx, mask);
     if (kc == L_ROW || kc == L_UNI) s.rc = ev_raw(s.c, idx, mask);
 }
-// the multiplier of the interpreter: four waves per SIMD cover the wait state between dependent multiply-adds
+// the multiplier of the interpreter: one dependent chain of multiply-adds per column (see Wide::chain)
 #ifndef ZKHIP_EVALH_CHAIN_MUL
 #define ZKHIP_EVALH_CHAIN_MUL 1
 #endif

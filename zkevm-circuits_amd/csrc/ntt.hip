@@ -58,8 +58,8 @@ ZK_DEV fe omega_pow(const NttPassArgs& a, uint32_t e) {
 
 ZK_DEV uint32_t bitrev(uint32_t v, uint32_t bits) { return bits ? (__brev(v) >> (32 - bits)) : 0; }
 
-// The butterfly products as single dependent multiply-add chains per column (see Wide::chain): the tile kernel runs
-// enough waves per SIMD to cover the wait states; 2^19 -> 2^21 0.289 -> 0.280 ms, 64 columns 0.2325 -> 0.2295 ms each.
+// The butterfly products as single dependent multiply-add chains per column (see Wide::chain): 2^19 -> 2^21
+// 0.289 -> 0.280 ms, 64 columns 0.2325 -> 0.2295 ms each when it was introduced.
 #ifndef ZKHIP_NTT_CHAIN_MUL
 #define ZKHIP_NTT_CHAIN_MUL 1
 #endif
