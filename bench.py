@@ -289,6 +289,7 @@ def main():
     ap.add_argument("--skip-cpu", action="store_true")
     ap.add_argument("--skip-extras", action="store_true",
                     help="only the timed steps: the kernel averages of a rocprofv3 run then describe exactly the timed region")
+    ap.add_argument("--skip-pmc", action="store_true", help="quote HBM traffic from profiles/ instead of collecting the counters now")
     ap.add_argument("--skip-proof", action="store_true", help="leave out the whole-proof measurement (create_proof_k19)")
     ap.add_argument("--skip-replay", action="store_true", help="leave out the replay of the SuperCircuit's operator multiset")
     ap.add_argument("--evalh-k", type=int, default=K)
@@ -581,6 +582,68 @@ def run_replay():
     raise RuntimeError(f"replay.py printed no JSON line (exit {out.returncode}): {out.stderr[-300:]}")
 
 
+def live_traffic(static):
+    """HBM bytes per launch of the two kernels of the roofline objects, from counters collected NOW: two child runs of this
+    file's timed region under `rocprofv3 --pmc` (FETCH_SIZE and WRITE_SIZE cannot share a pass; the program itself stands
+    behind `--`), each under a hard time limit.  The counter-to-bytes factors of the access shapes (a streamed 32-byte read
+    is tallied at half its size on gfx950, a 64-byte gather at its size) are the ones `tools/gather_probe` measured, read
+    from `static` (profiles/pmc_traffic.json).  Returns None when the profiler is absent, already wraps this process, or a
+    pass fails: the caller then quotes the committed file and says so."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    rocprof = shutil.which("rocprofv3")
+    if not rocprof or not static or any("rocprof" in os.environ.get(v, "").lower() for v in ("LD_PRELOAD", "ROCP_TOOL_LIBRARIES")):
+        return None
+    calib = static.get("calibration", {})
+    gather = calib.get("gather64", {}).get("counter_over_true")
+    stream32 = calib.get("stream32", {}).get("counter_over_true")
+    if not gather or not stream32:
+        return None
+    tmp = tempfile.mkdtemp(prefix="zkhip_pmc_", dir="/tmp")
+    per_kernel = {}
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            out = os.path.join(tmp, counter)
+            cmd = ["timeout", "-s", "KILL", "150", rocprof, "--pmc", counter, "--output-format", "csv", "-d", out, "--",
+                   sys.executable, os.path.abspath(__file__), "--skip-cpu", "--skip-extras", "--steps", "6", "--warmup", "1"]
+            env = dict(os.environ, TMPDIR="/tmp")
+            for v in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+                env.pop(v, None)
+            done = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=200)
+            if done.returncode != 0:
+                return None
+            total, count = {}, {}
+            for f in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
+                with open(f) as fh:
+                    for r in csv.DictReader(fh):
+                        if r["Counter_Name"] != counter:
+                            continue
+                        name = r["Kernel_Name"].split("(")[0].split("<")[0].replace("void ", "").replace("zkhip::", "").strip()
+                        total[name] = total.get(name, 0.0) + float(r["Counter_Value"])
+                        count[name] = count.get(name, 0) + 1
+            per_kernel[counter] = {k: (total[k] / count[k] * 1024.0, count[k]) for k in total}      # the counters are in KiB
+    except (OSError, subprocess.SubprocessError, KeyError, ValueError):
+        return None
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    fetch, write = per_kernel.get("FETCH_SIZE", {}), per_kernel.get("WRITE_SIZE", {})
+    if "accumulate_kernel" not in fetch or "ntt_tile_kernel" not in fetch:
+        return None
+    how = "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE over this command's timed region, collected by this run (two child runs)"
+    f_b, w_b = fetch["accumulate_kernel"][0], write.get("accumulate_kernel", (0.0, 0))[0]
+    acc = {"fetch_counter_bytes": f_b, "write_counter_bytes": w_b, "fetch_correction": 1.0 / gather,
+           "fetch_correction_from": "gather64 (64-byte gathers of table points dominate its reads)",
+           "bytes_per_launch": f_b / gather + w_b, "launches_counted": fetch["accumulate_kernel"][1], "source": how}
+    f_b, w_b = fetch["ntt_tile_kernel"][0], write.get("ntt_tile_kernel", (0.0, 0))[0]
+    ntt = {"fetch_counter_bytes_per_launch": f_b, "write_counter_bytes_per_launch": w_b, "launches_per_transform": 3,
+           "fetch_correction": 1.0 / stream32, "fetch_correction_from": "stream32 (32 contiguous bytes per lane)",
+           "bytes_per_transform": 3 * (f_b / stream32 + w_b), "launches_counted": fetch["ntt_tile_kernel"][1], "source": how}
+    return {"accumulate_kernel": acc, "ntt_tile_kernel": ntt}
+
+
 def measure_extras(ctx, dom, bid, stream, gen, n, en, extra):
     with torch.cuda.stream(stream):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -792,6 +855,15 @@ def finish(args, ctx, dist, world, rank, local_rank, bid, scalars, n, en, elapse
             rows = [r for r in probe["rows"] if r["inst"] == "v_mad_u64_u32"]
             mad_peak_measured = max(r["t_lane_ops_per_s"] for r in rows) * 1e12 if rows else None
         pmc = load_profile_json("pmc_traffic.json") or {}      # tools/collect_pmc.sh + tools/pmc_to_json.py (profiles/)
+        live = None
+        if world == 1 and not args.skip_extras and not args.skip_pmc:
+            live = live_traffic(pmc)
+        if live:
+            pmc = live
+        else:
+            for k in ("accumulate_kernel", "ntt_tile_kernel"):
+                if isinstance(pmc.get(k), dict):
+                    pmc[k]["source"] = "profiles/pmc_traffic.json: an earlier profiling run of this command (no live counter pass in this run)"
         acc_pmc, ntt_pmc = pmc.get("accumulate_kernel"), pmc.get("ntt_tile_kernel")
         # instruction counters of the same kernels (tools/collect_pmc_valu.sh + tools/pmc_valu_to_json.py): an earlier
         # profiling run of this command on another box, so each entry carries the duration of ITS run; the fractions
