@@ -43,8 +43,10 @@ constexpr int EV_THREADS = 256;
 // bit 7 = second product: a * b +- c * d under one Montgomery reduction, bits 8 / 9 = carry-normalise operand c / d
 // of a second product, bits 12.. = destination
 constexpr uint32_t F_MUL = 1, F_ADD = 2, F_SUB = 4, F_NORM = 8, F_NORM_A = 16, F_NORM_B = 32, F_RSUB = 64, F_MUL2 = 128,
-                   F_NORM_C = 256, F_NORM_D = 512;
-constexpr uint32_t F_OPS = F_MUL | F_ADD | F_SUB | F_RSUB | F_MUL2;
+                   F_NORM_C = 256, F_NORM_D = 512,
+                   F_PRE = 1024,       // with F_MUL alone: r = a (b + c), the sum formed on the way into the multiplier
+                   F_PRESUB = 2048;    // with F_PRE: r = a (b - c)
+constexpr uint32_t F_OPS = F_MUL | F_ADD | F_SUB | F_RSUB | F_MUL2 | F_PRE | F_PRESUB;
 constexpr uint32_t F_NORMS = F_NORM | F_NORM_A | F_NORM_B | F_NORM_C | F_NORM_D;
 constexpr uint32_t DST_SHIFT = 12;
 enum DevKind : uint32_t { K_CONST = 0, K_SLOT, K_COL, K_SCALAR, K_ACC, K_ZERO };
@@ -174,6 +176,10 @@ __device__ __forceinline__ void ev_execute(const InterpArgs& a, const Staged& s,
         if (w0 & F_NORM_A) t = FrW::norm(t);
         if (w0 & F_MUL) {
             fw u = ev_value(a, s.b, s.rb, lds, acc, reg0, idx);
+            if (w0 & F_PRE) {
+                const fw c = ev_value(a, s.c, s.rc, lds, acc, reg0, idx);
+                u = (w0 & F_PRESUB) ? FrW::sub(u, c) : FrW::add(u, c);
+            }
             if (w0 & F_NORM_B) u = FrW::norm(u);
             t = EvW::mul(t, u);
         }
@@ -366,8 +372,14 @@ struct Builder {
             t = {0.0, 1.0};
         } else {
             if (flags & F_MUL) {
-                v = v * bound(b) / EV_CONTRACT + 1.0;
+                double vb = bound(b);
                 Digits u = digits(b);
+                if (flags & F_PRE) {                       // the second factor is b +- c (both read from memory: digits in [0, 1])
+                    const Digits w = digits(c);
+                    vb += bound(c);
+                    u = (flags & F_PRESUB) ? Digits{u.lo - w.hi, u.hi - w.lo} : Digits{u.lo + w.lo, u.hi + w.hi};
+                }
+                v = v * vb / EV_CONTRACT + 1.0;
                 if (t.mag() * u.mag() > 2.0 && t.mag() > 1.0) {
                     flags |= F_NORM_A;
                     t = {0.0, 1.0};
@@ -375,7 +387,7 @@ struct Builder {
                 if (t.mag() * u.mag() > 2.0) flags |= F_NORM_B;
                 t = {0.0, 1.0};
             }
-            if (flags & (F_ADD | F_SUB | F_RSUB)) {
+            if (!(flags & F_PRE) && (flags & (F_ADD | F_SUB | F_RSUB))) {
                 v += bound(c);
                 const Digits w = digits(c);
                 if (!(flags & F_MUL) && t.mag() + w.mag() > 3.5) {   // int32 headroom of the digit sums
@@ -411,7 +423,7 @@ struct Builder {
     //     a b +- p q         ->  a second product in the same instruction, retired by the one Montgomery reduction.
     // The operands of the moved product must not change in between (values written once; never the running value).
     // Bounds are then recomputed from scratch: a fused result is never larger than what it replaces.
-    struct FuseStats { size_t two_products = 0, multiply_adds = 0; };
+    struct FuseStats { size_t two_products = 0, multiply_adds = 0, pre_adds = 0; };
     bool fuse_products(uint32_t result, FuseStats& fs) {
         const size_t ni = words.size() / IW;
         std::vector<uint32_t> reads(n_virtual, 0), writes(n_virtual, 0), def(n_virtual, 0);
@@ -481,7 +493,39 @@ struct Builder {
                 fs.two_products++;
             }
         }
-        // drop the moved multiplications, then redo the magnitude bookkeeping over what is left
+        // A sum or difference x +- y of two operands read from memory (columns, constants, scalars: normalised digits), made
+        // for a single consumer that is still a plain multiplication after the pass above, moves into that consumer:
+        // a (x +- y) is one instruction, and the sum never travels through a value slot.
+        auto in_mem = [](uint32_t o) { const uint32_t k = o >> 28; return k == K_COL || k == K_CONST || k == K_SCALAR; };
+        auto lone_sum = [&](uint32_t opnd, size_t pc, size_t& src) {
+            if ((opnd >> 28) != K_SLOT) return false;
+            const uint32_t v = opnd & 0x0fffffffu;
+            if (reads[v] != 1 || writes[v] != 1) return false;
+            src = def[v];
+            if (src >= pc || dead[src]) return false;
+            const uint32_t* p = &words[src * IW];
+            const uint32_t op = p[0] & F_OPS;
+            if (op != F_ADD && op != F_SUB && op != F_RSUB) return false;
+            return in_mem(p[2]) && in_mem(p[4]);
+        };
+        static const bool pre_adds = !(getenv("ZKHIP_EVALH_PREADD") && *getenv("ZKHIP_EVALH_PREADD") == '0');
+        for (size_t pc = 0; pre_adds && pc < ni; pc++) {
+            uint32_t* w = &words[pc * IW];
+            if (dead[pc] || (w[0] & F_OPS) != F_MUL) continue;
+            size_t src;
+            if (!lone_sum(w[3], pc, src)) {
+                if (!lone_sum(w[2], pc, src)) continue;
+                std::swap(w[2], w[3]);
+            }
+            const uint32_t* p = &words[src * IW];
+            const uint32_t op = p[0] & F_OPS;
+            w[3] = op == F_RSUB ? p[4] : p[2];
+            w[4] = op == F_RSUB ? p[2] : p[4];
+            w[0] = F_MUL | F_PRE | (op == F_ADD ? 0u : F_PRESUB);
+            dead[src] = 1;
+            fs.pre_adds++;
+        }
+        // drop the moved instructions, then redo the magnitude bookkeeping over what is left
         size_t keep = 0;
         for (size_t pc = 0; pc < ni; pc++) {
             if (dead[pc]) continue;
@@ -1351,11 +1395,38 @@ static int build_program(zkhip_ctx* ctx, const zkhip_evalh_desc* desc, bool lagr
             from = to;
         }
     }
+    if (getenv("ZKHIP_DEBUG") && ni > 100) {
+        // instruction shapes: flags, destination kind, operand kinds
+        std::map<std::string, size_t> shapes;
+        auto kind_of = [&](uint32_t w) -> char {
+            const uint32_t k = w >> 28, pl = w & 0x0fffffffu;
+            switch (k) {
+                case K_CONST: case K_SCALAR: return 'u';
+                case K_COL: return 'r';
+                case K_SLOT: return pl == 0 ? '0' : (pl < lds_slots ? 'l' : 's');
+                case K_ACC: return 'A';
+                default: return 'z';
+            }
+        };
+        for (size_t pc = 0; pc < ni; pc++) {
+            const uint32_t* w = &b.words[pc * IW];
+            char buf[64];
+            const char dk = w[1] == DST_ACC_V ? 'A' : (w[1] == 0 ? '0' : (w[1] < lds_slots ? 'l' : 's'));
+            snprintf(buf, sizeof buf, "%s%s%s dst=%c a=%c b=%c c=%c d=%c", (w[0] & F_MUL2) ? "MUL2" : ((w[0] & F_PRE) ? "MULP" : ((w[0] & F_MUL) ? "MUL " : "    ")),
+                     (w[0] & F_ADD) ? "+" : "", (w[0] & (F_SUB | F_RSUB)) ? "-" : "", dk, kind_of(w[2]), kind_of(w[3]), kind_of(w[4]),
+                     kind_of(w[5]));
+            shapes[buf]++;
+        }
+        std::vector<std::pair<size_t, std::string>> order;
+        for (auto& kv : shapes) order.push_back({kv.second, kv.first});
+        std::sort(order.rbegin(), order.rend());
+        for (size_t i = 0; i < order.size() && i < 25; i++) fprintf(stderr, "[zkhip]   %6zu  %s\n", order[i].first, order[i].second.c_str());
+    }
     if (getenv("ZKHIP_DEBUG"))
         fprintf(stderr, "[zkhip] evaluate_h program: %zu instructions (%zu products, %zu of them second products sharing a "
-                        "reduction, %zu multiply-adds formed; %zu column reads, %zu spill accesses), %u columns, "
+                        "reduction, %zu multiply-adds formed, %zu sums moved into a product; %zu column reads, %zu spill accesses), %u columns, "
                         "%zu rotations, %u values -> %u slots (%u in LDS)\n",
-                ni, nmul, fuse.two_products, fuse.multiply_adds, ncol, nspill, L.total, b.rots.size(), b.n_virtual,
+                ni, nmul, fuse.two_products, fuse.multiply_adds, fuse.pre_adds, ncol, nspill, L.total, b.rots.size(), b.n_virtual,
                 n_slots, lds_slots);
     // constants move to the interpreter's 2^261 Montgomery domain: x R -> 32 x R
     {
