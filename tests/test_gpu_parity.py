@@ -716,6 +716,53 @@ def test_evaluate_h_fused_products(ctx, co, width, monkeypatch):
     d.close()
 
 
+def _factors_of_sums_cs():
+    """Gates whose products have sums and differences of memory operands as factors -- the shapes the program builder turns
+    into a (b +- c) instructions: column + constant, column - column, constant - column (the reversed difference), a sum on
+    either side or on both sides of a product, and a chain of such factors behind a selector."""
+    from zkevm_circuits_amd.plonk import Advice, Constant, ConstraintSystem, Fixed, Product, Sub, Sum
+    import random
+    rnd = random.Random(11)
+    A, F = 8, 3
+    cs = ConstraintSystem(num_fixed_columns=F, num_advice_columns=A, num_instance_columns=1, num_challenges=1)
+    adv = lambda: Advice(rnd.randrange(A), rnd.choice((-1, 0, 1)))          # noqa: E731
+    const = lambda: Constant(rnd.randrange(1, 1 << 250))                    # noqa: E731
+    chain = Product(Fixed(0, 0), adv())
+    for _ in range(6):
+        chain = Product(chain, Sum(adv(), const()))
+    polys = [
+        Product(Sum(adv(), const()), adv()),
+        Product(adv(), Sub(adv(), adv())),
+        Product(Sub(const(), adv()), Fixed(1, 0)),
+        Product(Sum(adv(), adv()), Sum(adv(), const())),
+        Product(Product(Fixed(2, 0), Sub(adv(), const())), Sub(Fixed(1, 1), adv())),
+        chain,
+    ]
+    cs.gates.append(polys)
+    return cs
+
+
+def test_evaluate_h_sums_moved_into_products(ctx, co, monkeypatch):
+    """the a (b +- c) instruction against the oracle, and against the same program with every sum left an instruction of
+    its own"""
+    k = 7
+    cs = _factors_of_sums_cs()
+    d, od = zk.Domain(ctx, cs.degree(), k), co.Domain(cs.degree(), k, threads=8)
+    rng = np.random.default_rng(5)
+    call, coeff, ext = _random_call(cs, rng, d.n, d.extended_len, od)
+    call.advice, call.instance, call.lookups = ext["advice"], ext["instance"], ext["lookups"]
+    desc = call.build(ffi.MEM_HOST, ffi.FORM_EXTENDED)
+    exp = od.evaluate_h(desc)
+    assert np.array_equal(d.evaluate_h(desc), exp)
+    moved = ctx.evaluate_h_last_stats()
+    monkeypatch.setenv("ZKHIP_EVALH_PREADD", "0")
+    assert np.array_equal(d.evaluate_h(desc), exp)
+    plain = ctx.evaluate_h_last_stats()
+    assert moved["multiplications"] == plain["multiplications"]
+    assert moved["instructions"] <= plain["instructions"] - 5
+    d.close()
+
+
 def test_evaluate_h_rejects_malformed_graph(ctx):
     cs = synthetic.synthetic_cs(num_lookups=0, num_perm_cols=0)
     d = zk.Domain(ctx, cs.degree(), 6)

@@ -424,7 +424,7 @@ struct Builder {
     // The operands of the moved product must not change in between (values written once; never the running value).
     // Bounds are then recomputed from scratch: a fused result is never larger than what it replaces.
     struct FuseStats { size_t two_products = 0, multiply_adds = 0, pre_adds = 0; };
-    bool fuse_products(uint32_t result, FuseStats& fs) {
+    bool fuse_products(uint32_t result, FuseStats& fs, bool pre_adds) {
         const size_t ni = words.size() / IW;
         std::vector<uint32_t> reads(n_virtual, 0), writes(n_virtual, 0), def(n_virtual, 0);
         for (size_t pc = 0; pc < ni; pc++) {
@@ -508,7 +508,6 @@ struct Builder {
             if (op != F_ADD && op != F_SUB && op != F_RSUB) return false;
             return in_mem(p[2]) && in_mem(p[4]);
         };
-        static const bool pre_adds = !(getenv("ZKHIP_EVALH_PREADD") && *getenv("ZKHIP_EVALH_PREADD") == '0');
         for (size_t pc = 0; pre_adds && pc < ni; pc++) {
             uint32_t* w = &words[pc * IW];
             if (dead[pc] || (w[0] & F_OPS) != F_MUL) continue;
@@ -1201,7 +1200,7 @@ struct ShapeHash {
 };
 
 static int build_program(zkhip_ctx* ctx, const zkhip_evalh_desc* desc, bool lagrange, uint32_t lds_budget, bool do_fuse,
-                         EvalhProgram& out) {
+                         bool pre_adds, EvalhProgram& out) {
     const ColLayout L(desc, lagrange);
     const uint32_t c_l0 = L.c_l0, c_last = L.c_l0 + 1, c_active = L.c_l0 + 2;
     Builder b;
@@ -1364,7 +1363,7 @@ static int build_program(zkhip_ctx* ctx, const zkhip_evalh_desc* desc, bool lagr
     uint32_t result = b.finish_terms(), lds_slots = 1, n_slots = 1;
     ZK_CHECK(ctx, b.n_virtual < (1u << 28), "evaluate_h: program too large");
     Builder::FuseStats fuse;
-    if (do_fuse) ZK_CHECK(ctx, b.fuse_products(result, fuse), "evaluate_h: internal error, a fused value left its bound");
+    if (do_fuse) ZK_CHECK(ctx, b.fuse_products(result, fuse, pre_adds), "evaluate_h: internal error, a fused value left its bound");
     assign_slots(b.words, result, b.n_virtual, lds_budget, lds_slots, n_slots);
     // one multiplication = one product of two operands (an instruction with a second product counts two)
     size_t nmul = 0, ncol = 0, nspill = 0;
@@ -1481,8 +1480,10 @@ static int get_program(zkhip_ctx* ctx, const zkhip_evalh_desc* desc, bool lagran
     const uint32_t lds_budget = env_slots && *env_slots ? (uint32_t)atoi(env_slots) : 5;
     const char* env_fuse = getenv("ZKHIP_EVALH_FUSE");   // "0" keeps every product an instruction of its own
     const bool do_fuse = !(env_fuse && *env_fuse == '0');
+    const char* env_pre = getenv("ZKHIP_EVALH_PREADD");  // "0" keeps every sum an instruction of its own
+    const bool pre_adds = !(env_pre && *env_pre == '0');
     ShapeHash sh;
-    sh.word(((uint64_t)desc->basis << 32) | lds_budget | ((uint64_t)do_fuse << 31));
+    sh.word(((uint64_t)desc->basis << 32) | lds_budget | ((uint64_t)do_fuse << 31) | ((uint64_t)pre_adds << 30));
     if (desc->basis != ZKHIP_BASIS_LAGRANGE) sh.word(((uint64_t)desc->term_select << 32) | (desc->term_select ? desc->term_degree_max : 0));
     sh.word(((uint64_t)desc->num_fixed << 32) | desc->num_advice);
     sh.word(((uint64_t)desc->num_instance << 32) | desc->num_challenges);
@@ -1505,7 +1506,7 @@ static int get_program(zkhip_ctx* ctx, const zkhip_evalh_desc* desc, bool lagran
     }
     ctx->evalh_builds++;
     prog = std::make_shared<EvalhProgram>();
-    int rc = build_program(ctx, desc, lagrange, lds_budget, do_fuse, *prog);
+    int rc = build_program(ctx, desc, lagrange, lds_budget, do_fuse, pre_adds, *prog);
     if (rc) return rc;
     if (ctx->evalh_cache.size() >= 4096) ctx->evalh_cache.clear();
     ctx->evalh_cache[key] = prog;
