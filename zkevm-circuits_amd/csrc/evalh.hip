@@ -72,7 +72,16 @@ struct Opnd {
     uint32_t hdr;
     const fe* ptr;
 };
+// One program of a launch that runs several (blockIdx.y selects it): where its linked words start, and the fields of
+// InterpArgs that differ from program to program.  Read through the constant address space, like the program itself.
+struct ProgEntry {
+    uint32_t word_offset, n_instr, result_hdr, lds_slots;
+    fe* out;
+    uint64_t pad;
+};
+typedef const ProgEntry __attribute__((address_space(4))) * entry_ptr;
 struct InterpArgs {
+    const ProgEntry* table;     // null: one program, described by the fields below
     uint32_t n_instr;
     uint32_t result_hdr;        // operand of the final value (slot / running value / zero)
     uint32_t lds_slots;
@@ -204,10 +213,19 @@ __device__ __forceinline__ void ev_execute(const InterpArgs& a, const Staged& s,
     }
 }
 
-__global__ void __launch_bounds__(EV_THREADS) evalh_interp_kernel(const uint32_t* prog_generic, const InterpArgs a) {
+__global__ void __launch_bounds__(EV_THREADS) evalh_interp_kernel(const uint32_t* prog_generic, const InterpArgs a_in) {
     extern __shared__ __align__(16) unsigned char smem[];
     int32_t* lds = reinterpret_cast<int32_t*>(smem);
-    const prog_ptr prog = (prog_ptr)prog_generic;
+    prog_ptr prog = (prog_ptr)prog_generic;
+    InterpArgs a = a_in;
+    if (a_in.table) {
+        const entry_ptr e = (entry_ptr)a_in.table + blockIdx.y;
+        prog += e->word_offset;
+        a.n_instr = e->n_instr;
+        a.result_hdr = e->result_hdr;
+        a.lds_slots = e->lds_slots;
+        a.out = e->out;
+    }
     const uint32_t local = blockIdx.x * EV_THREADS + threadIdx.x;   // row inside the evaluated window
     const uint32_t mask = (1u << a.log_size) - 1;
     if (local >= a.rows) return;   // windows that are no multiple of a workgroup
@@ -1937,6 +1955,37 @@ extern "C" int zkhip_evaluate_graphs_dev(zkhip_domain* dom, const zkhip_evalh_de
     if (!consts.empty()) ZK_HIP(ctx, hipMemcpyAsync(d_consts, consts.data(), consts.size() * 8, hipMemcpyHostToDevice, ctx->stream));
     if (at_words[count])
         ZK_HIP(ctx, hipMemcpyAsync(d_words, linked.data(), at_words[count] * 4, hipMemcpyHostToDevice, ctx->stream));
+    if (!spill_bytes && count <= 65535) {
+        // no program spills value slots (they would share the spill buffer): ONE launch, blockIdx.y selects the program
+        std::vector<ProgEntry> table(count);
+        uint32_t lds_slots = 1;
+        for (uint32_t i = 0; i < count; i++) {
+            table[i] = {(uint32_t)at_words[i], (uint32_t)(progs[i]->words.size() / IW), res_links[(size_t)i * 3], progs[i]->lds_slots,
+                        (fe*)d_outs[i], 0};
+            lds_slots = std::max(lds_slots, progs[i]->lds_slots);
+        }
+        if ((rc = grow(ctx, ctx->evalh_buf[3], ctx->evalh_buf_bytes[3], table.size() * sizeof(ProgEntry)))) return rc;
+        ZK_HIP(ctx, hipMemcpyAsync(ctx->evalh_buf[3], table.data(), table.size() * sizeof(ProgEntry), hipMemcpyHostToDevice, ctx->stream));
+        InterpArgs a;
+        memset(&a, 0, sizeof a);
+        a.table = (const ProgEntry*)ctx->evalh_buf[3];
+        a.log_size = k;
+        a.rows = (uint32_t)n;
+        const size_t lds_bytes = (size_t)(lds_slots > 1 ? lds_slots - 1 : 1) * EV_THREADS * 36;
+        if (!ctx->evalh_attr_set) {
+            ZK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(evalh_interp_kernel),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            ctx->evalh_attr_set = true;
+        }
+        {
+            TimedRegion tr(ctx, "evalh");
+            hipLaunchKernelGGL(evalh_interp_kernel, dim3((unsigned)((n + EV_THREADS - 1) / EV_THREADS), count), dim3(EV_THREADS),
+                               lds_bytes, ctx->stream, (const uint32_t*)d_words, a);
+            ZK_HIP(ctx, hipGetLastError());
+        }
+        ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));   // `table` is this call's own memory
+        return ZKHIP_OK;
+    }
     for (uint32_t i = 0; i < count; i++)
         if ((rc = launch_program(ctx, *progs[i], d_words + at_words[i], &res_links[(size_t)i * 3], (int32_t*)ctx->evalh_buf[3], k, 0,
                                  n, (fe*)d_outs[i])))
