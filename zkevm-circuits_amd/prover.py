@@ -808,13 +808,20 @@ def create_proof(ctx, dom, params: ParamsKZG, pk: ProvingKey, advice, instance, 
                 starts = [0] + list(range(min(FIRST, len(columns)), len(columns), GROUP))
                 groups = [columns[a:b] for a, b in zip(starts, starts[1:] + [len(columns)])]
 
+                def draw(gi):
+                    """the blinding rows of a group, from the RNG (groups in order: the stream is that of column after column)"""
+                    if gi < len(groups):
+                        for i, _ in enumerate(groups[gi], starts[gi]):
+                            stage[i] = fr_limbs(draws(n - usable))
+
                 def issue(gi):
                     for i, c in enumerate(groups[gi], starts[gi]):
-                        stage[i] = fr_limbs(draws(n - usable))
                         ctx.upload_overlapped(assigned[c], adv[c])
                         ctx.upload_overlapped(stage[i], adv[c] + usable * 32)
 
+                draw(0)
                 issue(0)
+                draw(1)
                 for gi, group in enumerate(groups):
                     ctx.upload_fence()                      # the compute stream waits for this group's copies
                     if gi + 1 < len(groups):
@@ -823,6 +830,7 @@ def create_proof(ctx, dom, params: ParamsKZG, pk: ProvingKey, advice, instance, 
                         issue(gi + 1)
                     if gi >= LAG:
                         extend_early(groups[gi - LAG])
+                    draw(gi + 2)                            # host work under the transforms just queued
                     points.extend(params.commit_lagrange([adv[c] for c in group], dist))
                 for group in groups[max(0, len(groups) - LAG):]:
                     extend_early(group)
